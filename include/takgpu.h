@@ -1,0 +1,334 @@
+/*
+ * takgpu.h — C ABI of libtakgpu.so, the MI355X (gfx950) batched Tak self-play engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of ViliamVadocz/tak: batched AlphaZero
+ * self-play (board move-gen / step / terminal / encode, policy-value resnet forward, MCTS).
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference repo).  Plain pointers and sizes only; no torch / tch types cross this line.
+ *
+ * Conventions
+ *   - every function returns TG_OK (0) or a negative TgStatus; tg_last_error() gives the
+ *     thread-local message of the last failure.  Nothing aborts, nothing throws.
+ *   - "host" entry points take host pointers, do H2D, run the HIP kernels, D2H, and
+ *     synchronise before returning.  "_dev" entry points take device pointers that must stay
+ *     valid until the engine's stream is synchronised (tg_sync) and do not synchronise.
+ *   - the caller owns every buffer it passes; the engine never frees caller memory.
+ *   - one engine handle per GPU / per process; calls on one handle must be serialised by the
+ *     caller (same contract as `&NET` in reference train/src/self_play.rs:96).
+ *   - there is NO CPU fallback: if no HIP device is present every compute entry point fails
+ *     with TG_ERR_NO_DEVICE.
+ */
+#ifndef TAKGPU_H
+#define TAKGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TG_ABI_VERSION 1
+
+/* ---------------------------------------------------------------------------------------
+ * Status codes.  TG_PLAY_* mirror reference tak/src/error.rs:4-15 (PlayError) and
+ * :55-58 / :72-76 (StackError / TakeError) one to one.
+ * ------------------------------------------------------------------------------------- */
+typedef enum TgStatus {
+    TG_OK = 0,
+    TG_ERR_INVALID_ARG = -1,
+    TG_ERR_NO_DEVICE = -2,
+    TG_ERR_HIP = -3,
+    TG_ERR_WEIGHTS = -4,       /* missing / wrongly sized tensor at tg_net_finalize            */
+    TG_ERR_ARENA_OVERFLOW = -5,/* a game's MCTS node arena is full                              */
+    TG_ERR_NAN = -6,           /* reference panics "tried comparing nan" (search/mcts.rs:110)   */
+    TG_ERR_STATE = -7,         /* call sequence violated (e.g. search before weights)          */
+    TG_ERR_ILLEGAL_MOVE = -8   /* a move in a batch failed; per-item code in the status array  */
+} TgStatus;
+
+typedef enum TgPlayError { /* per-item result of tg_play, 0 = Ok(()) */
+    TG_PLAY_OK = 0,
+    TG_PLAY_OUT_OF_BOUNDS = 1,
+    TG_PLAY_ALREADY_OCCUPIED = 2,
+    TG_PLAY_NO_CAPSTONE = 3,
+    TG_PLAY_NO_STONES = 4,
+    TG_PLAY_OPENING_NON_FLAT = 5,
+    TG_PLAY_EMPTY_SQUARE = 6,
+    TG_PLAY_STACK_NOT_OWNED = 7,
+    TG_PLAY_STACK_WALL = 8,      /* StackError::Wall  */
+    TG_PLAY_STACK_CAP = 9,       /* StackError::Cap   */
+    TG_PLAY_TAKE_ZERO = 10,      /* TakeError::Zero   */
+    TG_PLAY_TAKE_CARRY_LIMIT = 11,
+    TG_PLAY_TAKE_STACK_SIZE = 12,
+    TG_PLAY_SPREAD_OUT_OF_BOUNDS = 13
+} TgPlayError;
+
+/* reference tak/src/game_result.rs:3-8 (GameResult) flattened to one byte */
+typedef enum TgResult {
+    TG_ONGOING = 0,
+    TG_WHITE_ROAD = 1,
+    TG_WHITE_FLAT = 2,
+    TG_BLACK_ROAD = 3,
+    TG_BLACK_FLAT = 4,
+    TG_DRAW = 5,            /* Draw { reversible_plies: false } */
+    TG_DRAW_REVERSIBLE = 6  /* Draw { reversible_plies: true }  */
+} TgResult;
+
+/* ---------------------------------------------------------------------------------------
+ * Packed game state (replaces the non-POD `Game<N>` of reference tak/src/game.rs:24-35,
+ * `Board<N>` board.rs:7-10 and `Tile` tile.rs:6-10).
+ *
+ * Square index sq = row * N + col (row = y, col = x, same as board.rs:24-27 data[y][x]).
+ * stack[sq]: colours bottom→top, bit i = colour of the i-th stone from the bottom,
+ *            0 = white, 1 = black; bits ≥ height are zero.  Max height 2·(stones+caps) ≤ 62.
+ * meta[sq]:  bits 0..5 = height (number of stones), bits 6..7 = piece type of the TOP stone
+ *            (0 flat, 1 wall, 2 cap); 0 when the square is empty (Tile::default()).
+ * Two layouts: N ≤ 5 → TgState5 (256 B, 25 slots; for N < 5 only the first N·N are used),
+ *              N = 6 → TgState6 (384 B, 36 slots).  tg_state_bytes(N) tells which.
+ * Within a state the fields are arrays over squares (SoA): a 64-lane wavefront loads one
+ * game with lane = square, fully coalesced.
+ * ------------------------------------------------------------------------------------- */
+typedef struct TgHeader {
+    uint8_t n;                 /* board size 3..6                                      */
+    uint8_t to_move;           /* 0 white, 1 black (Game::to_move)                     */
+    uint16_t ply;
+    uint8_t white_stones, white_caps, black_stones, black_caps;
+    int8_t half_komi;
+    uint8_t reversible_plies;
+    uint8_t reserved[6];
+} TgHeader; /* 16 bytes */
+
+typedef struct TgState5 {
+    uint64_t stack[25];
+    uint8_t meta[25];
+    uint8_t pad[15];
+    TgHeader h;
+} TgState5; /* 256 bytes */
+
+typedef struct TgState6 {
+    uint64_t stack[36];
+    uint8_t meta[36];
+    uint8_t pad[44];
+    TgHeader h;
+} TgState6; /* 384 bytes */
+
+#define TG_STATE5_BYTES 256
+#define TG_STATE6_BYTES 384
+#define TG_META(height, top) ((uint8_t)((height) | ((top) << 6)))
+#define TG_META_HEIGHT(m) ((m) & 63)
+#define TG_META_TOP(m) ((m) >> 6)
+
+/* size in bytes of one packed state for board size n (256 for n ≤ 5, 384 for n = 6) */
+size_t tg_state_bytes(int n);
+
+/* ---------------------------------------------------------------------------------------
+ * Move code (replaces takparse 0.5.5 `Move{square, kind}`; reference call sites
+ * tak/src/game.rs:121-125, move_gen.rs:19-75):
+ *   bits  0..5   square index row*N+col
+ *   bits  6..7   place: piece (0 flat, 1 wall, 2 cap);  spread: direction
+ *                (0 Up=row+1 '+', 1 Down=row-1 '-', 2 Left=col-1 '<', 3 Right=col+1 '>')
+ *   bits  8..15  0 for a placement; for a spread the 8-bit drop pattern, MSB first, one bit
+ *                per carried stone in drop order, 1 = this stone is the last one dropped on
+ *                its square (so popcount = squares covered, 8 - ctz = stones picked up).
+ *                drops [2,1] → 0b0110_0000.  (takparse `Pattern::mask()` layout as used by
+ *                reference alpha-tak/src/search/move_map.rs:35; see DESIGN.md "unpinned".)
+ * ------------------------------------------------------------------------------------- */
+typedef uint16_t TgMove;
+#define TG_MAX_MOVES 512 /* capacity of one move list in tg_movegen */
+
+/* ---------------------------------------------------------------------------------------
+ * Engine
+ * ------------------------------------------------------------------------------------- */
+typedef struct TgEngine TgEngine;
+
+typedef enum TgPolicyHead {
+    TG_HEAD_FC5 = 0,  /* Net5: Linear(F*25 → 1575), legacy move LUT (net5.rs:56-61, move_map.rs:21-24) */
+    TG_HEAD_CONV = 1  /* Net6: conv3x3(F → 3+4(2^N-2)), index ch*N²+row*N+col (net6.rs:56, move_map.rs:26-46) */
+} TgPolicyHead;
+
+typedef enum TgEvaluator {
+    TG_EVAL_RESNET = 0, /* the policy/value resnet (needs weights)                           */
+    TG_EVAL_DUMMY = 1,  /* DummyNet of alpha-tak/src/search/tests.rs:29-34: policy 1.0, eval 0 */
+    TG_EVAL_HASH = 2    /* test evaluator: deterministic pseudo-random policy/eval from the state */
+} TgEvaluator;
+
+typedef struct TgConfig {
+    int32_t abi_version;   /* TG_ABI_VERSION */
+    int32_t device;        /* HIP device ordinal */
+    int32_t board_size;    /* 3..6 */
+    int32_t res_blocks;    /* RES_BLOCKS (net5.rs:16 / net6.rs:16), runtime here */
+    int32_t filters;       /* FILTERS (net5.rs:17), multiple of 32 */
+    int32_t policy_head;   /* TgPolicyHead */
+    int32_t evaluator;     /* TgEvaluator */
+    int32_t max_batch;     /* largest n passed to tg_policy_eval / number of concurrent games */
+} TgConfig;
+
+int tg_engine_create(const TgConfig* cfg, TgEngine** out);
+void tg_engine_destroy(TgEngine* e);
+const char* tg_last_error(void);
+int tg_sync(TgEngine* e);
+/* the hipStream_t the engine launches on (as void*), for callers timing with HIP events */
+void* tg_stream(TgEngine* e);
+
+/* sizes — reference alpha-tak/src/repr/game.rs:12-15 (input_channels) and repr/moves.rs:6-31
+ * (possible_moves / output_size).  policy_size depends on the head. */
+int tg_input_channels(int n);
+int tg_policy_size(int n, int policy_head);
+
+/* ---------------------------------------------------------------------------------------
+ * Board operators on batches (host buffers).  `states` is n packed states of
+ * tg_state_bytes(board_size) each.
+ * ------------------------------------------------------------------------------------- */
+
+/* Game::possible_moves (tak/src/move_gen.rs:7-30), same order.  moves: n*TG_MAX_MOVES codes,
+ * counts: n.  A position with more than TG_MAX_MOVES moves yields TG_ERR_INVALID_ARG. */
+int tg_movegen(TgEngine* e, int n, const void* states, TgMove* moves, int32_t* counts);
+
+/* Game::play (tak/src/game.rs:121-130) in place; status[i] = TgPlayError.  Returns
+ * TG_ERR_ILLEGAL_MOVE if any item failed (failed items are left unchanged — the behaviour of
+ * Game::safe_play, game.rs:136-145). */
+int tg_play(TgEngine* e, int n, void* states, const TgMove* moves, uint8_t* status);
+
+/* Game::result (tak/src/game.rs:220-267); results[i] = TgResult */
+int tg_result(TgEngine* e, int n, const void* states, uint8_t* results);
+
+/* game_repr (alpha-tak/src/repr/game.rs:19-51): planes n × C_in × N × N f32, NCHW like the
+ * reference tensor (index c*N² + row*N + col). */
+int tg_encode(TgEngine* e, int n, const void* states, float* planes);
+
+/* move_index (alpha-tak/src/search/move_map.rs:19-48) for k moves; -1 where the reference
+ * would panic ("could not map turn to index"). */
+int tg_move_index(TgEngine* e, int k, const TgMove* moves, int32_t* index);
+
+/* perft of tak/tests/perft.rs:3-18 evaluated on the GPU: one count per input state.
+ * depth ≥ 0.  Expands level by level on the device (movegen+play+result kernels). */
+int tg_perft(TgEngine* e, int n, const void* states, int depth, uint64_t* counts);
+
+/* ---------------------------------------------------------------------------------------
+ * Network (replaces Network<N>, alpha-tak/src/model/network.rs:26-35, without tch types)
+ * ------------------------------------------------------------------------------------- */
+
+/* Provide one tensor in tch/libtorch layout (conv OIHW, linear [out,in], BN vectors).
+ * Names: "conv0.weight" "conv0.bias" "bn0.weight" "bn0.bias" "bn0.running_mean"
+ * "bn0.running_var"; "res{i}.conv1.weight" … "res{i}.bn2.running_var" (i = 0..R-1);
+ * "policy.weight" "policy.bias" (FC5: [1575, F*25]; CONV: [ch, F, 3, 3]); "value.weight"
+ * "value.bias" ([1, F*N*N]).  Creation order of net5.rs:29-62 / net6.rs:29-57. */
+int tg_net_set_tensor(TgEngine* e, const char* name, const float* data, size_t count);
+/* Fold BN (eval mode, eps 1e-5) into the convs, re-layout for the MFMA kernels, upload. */
+int tg_net_finalize(TgEngine* e);
+
+/* Network::policy_eval (net5.rs:120-130 / net6.rs:124-138): n states → policy n×P
+ * (full softmax, not masked) and eval n (tanh).  n = 0 is allowed (returns TG_OK). */
+int tg_policy_eval(TgEngine* e, int n, const void* states, float* policy, float* eval);
+
+/* Network::forward_mcts (net5.rs:106-111) on already-encoded planes (n × C_in × N × N, NCHW,
+ * host).  Same outputs as tg_policy_eval. */
+int tg_forward_mcts(TgEngine* e, int n, const float* planes, float* policy, float* eval);
+
+/* Device-resident variants used by bench.py: d_states / d_policy / d_eval are device
+ * pointers; no synchronisation. */
+int tg_policy_eval_dev(TgEngine* e, int n, const void* d_states, float* d_policy, float* d_eval);
+
+/* ---------------------------------------------------------------------------------------
+ * Search (replaces Node + Node::{virtual_rollout, devirtualize_path, select, apply_dirichlet,
+ * pick_move, play}, alpha-tak/src/search/{node,mcts,noise,play}.rs) for `games` independent
+ * trees stepped in lock-step, one leaf per game per iteration — the loop body of
+ * train/src/self_play.rs:181-210.
+ * ------------------------------------------------------------------------------------- */
+typedef struct TgSearchConfig {
+    int32_t games;            /* concurrent games (≤ cfg.max_batch)                          */
+    int32_t arena_nodes;      /* node capacity of one game's tree arena (two arenas per game) */
+    float exploration_base;   /* EXPLORATION_BASE 500 (mcts.rs:7) */
+    float exploration_init;   /* EXPLORATION_INIT 4   (mcts.rs:8) */
+    uint64_t seed;            /* counter-based RNG key (noise, move sampling, openings)      */
+} TgSearchConfig;
+
+int tg_search_create(TgEngine* e, const TgSearchConfig* cfg);
+/* (re)start every tree as Node::default() with the given root states (host, games packed states) */
+int tg_search_reset(TgEngine* e, const void* states);
+/* run `iters` lock-step iterations (virtual_rollout → policy_eval → devirtualize_path).
+ * active: optional host mask (games bytes, 0 = skip this game), NULL = all. */
+int tg_search_run(TgEngine* e, int iters, const uint8_t* active);
+/* Node::apply_dirichlet (noise.rs:6-16) on every active root with engine RNG
+ * (stream = (seed, game, ply)). */
+int tg_search_apply_dirichlet(TgEngine* e, float alpha, float ratio, const uint8_t* active);
+/* Node::apply_dirichlet with caller-supplied noise (games × TG_MAX_MOVES f32, row g holds one
+ * sample per child of root g) — lets a test feed the same samples to the oracle. */
+int tg_search_apply_noise(TgEngine* e, const float* noise, float ratio, const uint8_t* active);
+/* Node::improved_policy (play.rs:13-21) + root stats: per game the root's children in
+ * possible_moves order.  moves/visits/prior/q: games × TG_MAX_MOVES; counts: games;
+ * root_visits / root_q: games (any pointer may be NULL). */
+int tg_search_root(TgEngine* e, TgMove* moves, uint32_t* visits, float* prior, float* q,
+                   int32_t* counts, uint32_t* root_visits, float* root_q);
+/* Node::play (play.rs:26-43) + Game::play: advance each active game by moves[g] with tree
+ * reuse (the chosen child's subtree is compacted into the game's other arena). */
+int tg_search_play(TgEngine* e, const TgMove* moves, const uint8_t* active);
+/* current root states (games packed states) */
+int tg_search_states(TgEngine* e, void* states);
+/* canonical serialisation of game g's whole tree, depth-first in child order, one record per
+ * initialised node: {move u16, n_children u16, visits u32, virtual u32, result u32,
+ * prior f32 bits, q f32 bits}.  Returns record count through *n_records (cap = capacity). */
+typedef struct TgNodeRecord {
+    uint16_t move;
+    uint16_t n_children;
+    uint32_t visits;
+    uint32_t virtual_visits;
+    uint32_t result;
+    uint32_t prior_bits;
+    uint32_t q_bits;
+} TgNodeRecord;
+int tg_search_dump(TgEngine* e, int game, TgNodeRecord* records, size_t capacity, size_t* n_records);
+/* counters since tg_search_create: expansions = completed rollouts (terminal ones included,
+ * as in the reference's ROLLOUTS loop), evals = leaves sent to the network */
+int tg_search_counters(TgEngine* e, uint64_t* expansions, uint64_t* evals);
+
+/* ---------------------------------------------------------------------------------------
+ * Self-play driver (replaces self_play_parallel, train/src/self_play.rs:96-262).
+ * All compile-time constants of the reference (self_play.rs:10-19,94) are runtime here.
+ * ------------------------------------------------------------------------------------- */
+typedef struct TgSelfPlayConfig {
+    int32_t rollouts;        /* ROLLOUTS per move (reference 10_000; BASELINE 400 / 100)     */
+    int32_t noise_plies;     /* NOISE_PLIES 80   */
+    int32_t exploit_plies;   /* EXPLOIT_PLIES 40 */
+    float noise_alpha;       /* NOISE_ALPHA 0.2  */
+    float noise_ratio;       /* NOISE_RATIO 0.3  */
+    int32_t komi;            /* Game::with_komi(2) */
+    int32_t total_games;     /* SELF_PLAY_GAMES: finished games are replaced until
+                                completed + games ≥ total_games (self_play.rs:151,237); 0 = endless */
+    int32_t max_examples;    /* capacity of the device example ring drained by tg_selfplay_drain */
+} TgSelfPlayConfig;
+
+/* One training example, fixed-size record (reference alpha-tak/src/example.rs:29-33):
+ * the position before the move, the visit count of every legal move in possible_moves
+ * order, and the final result from the mover's perspective (self_play.rs:245-251). */
+typedef struct TgExampleHeader {
+    int32_t game_id;      /* global id of the game this example came from */
+    int32_t n_moves;
+    float result;         /* +1 / -1 / 0 from the perspective of the side to move */
+    int32_t reserved;
+} TgExampleHeader;
+
+int tg_selfplay_create(TgEngine* e, const TgSearchConfig* scfg, const TgSelfPlayConfig* cfg);
+/* run `plies` lock-step plies of self_play_parallel's outer loop (opening → instant-win scan
+ * → noise → rollouts → pick/play/recycle).  Asynchronous; tg_sync() to wait. */
+int tg_selfplay_step(TgEngine* e, int plies);
+/* statistics: finished games, emitted examples, expansions, network evals */
+typedef struct TgSelfPlayStats {
+    uint64_t games_finished;
+    uint64_t examples;
+    uint64_t expansions;
+    uint64_t evals;
+    uint64_t plies;
+    uint64_t white_wins, black_wins, draws;
+    uint64_t instant_wins;
+} TgSelfPlayStats;
+int tg_selfplay_stats(TgEngine* e, TgSelfPlayStats* out);
+/* copy out up to `cap` finished examples (headers + states + moves + visits) and remove them
+ * from the ring.  states: cap packed states; moves/visits: cap × TG_MAX_MOVES. */
+int tg_selfplay_drain(TgEngine* e, int cap, TgExampleHeader* headers, void* states, TgMove* moves,
+                      uint32_t* visits, int32_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAKGPU_H */

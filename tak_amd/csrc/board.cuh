@@ -1,0 +1,451 @@
+// board.cuh — Tak rules on a CDNA4 wavefront: one 64-lane wave owns one game, lane = square.
+//
+// Replaces (reference paths): tak/src/game.rs (Game::play / result), tak/src/move_gen.rs
+// (possible_moves), tak/src/board.rs (find_paths / full / flat_diff), tak/src/tile.rs.
+// Layout: the packed state of include/takgpu.h is a struct of per-square arrays, so the wave loads
+// a game with one coalesced 8-byte load per lane (stack bits) + one byte load (meta).  Per-colour /
+// per-type bitboards are never stored: `__ballot` builds them from the lanes in one instruction,
+// roads are flood-filled on the scalar unit with shifts, and spreads move stones between lanes with
+// ds_bpermute shuffles.  Everything here is bit-exact integer work (no floating point except the
+// fcd plane of the encoder, which reproduces the reference's f64 division).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/takgpu.h"
+
+namespace tg {
+
+enum : uint32_t { FLAT = 0, WALL = 1, CAP = 2 };
+enum : uint32_t { UP = 0, DOWN = 1, LEFT = 2, RIGHT = 3 };
+
+struct Geom {
+    int n, nsq, slots, bytes;
+    uint64_t all, row0, rowL, col0, colL;
+};
+
+__host__ __device__ inline Geom make_geom(int n) {
+    Geom g;
+    g.n = n;
+    g.nsq = n * n;
+    g.slots = n <= 5 ? 25 : 36;
+    g.bytes = n <= 5 ? TG_STATE5_BYTES : TG_STATE6_BYTES;
+    g.all = (g.nsq == 64) ? ~0ull : ((1ull << g.nsq) - 1);
+    g.row0 = (1ull << n) - 1;
+    g.rowL = g.row0 << (n * (n - 1));
+    g.col0 = 0;
+    for (int r = 0; r < n; r++) g.col0 |= 1ull << (r * n);
+    g.colL = g.col0 << (n - 1);
+    return g;
+}
+
+// reference tak/src/game.rs:10-20
+__host__ __device__ inline void starting_stones(int n, int& stones, int& caps) {
+    stones = n == 3 ? 10 : n == 4 ? 15 : n == 5 ? 21 : 30;
+    caps = n <= 4 ? 0 : 1;
+}
+__host__ __device__ inline int board_channels(int n) { return (n + 2 + 6) * 2; }
+__host__ __device__ inline int input_channels(int n) {
+    int s, c;
+    starting_stones(n, s, c);
+    return board_channels(n) + 2 + 2 * s + 2 * c;
+}
+
+// Wave-distributed game: per-lane square data + wave-uniform header.
+struct WState {
+    uint64_t stack;   // lane = square: colour bits bottom→top
+    uint32_t height;  // lane = square
+    uint32_t top;     // lane = square: piece type of the top stone
+    uint32_t to_move, ply, ws, wc, bs, bc, rev;
+    int32_t half_komi;
+};
+
+__device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ inline uint64_t shfl64(uint64_t v, int src) {
+    uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src);
+    uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ inline void ws_load(WState& s, const uint8_t* st, const Geom& g) {
+    int lane = lane_id();
+    bool on = lane < g.nsq;
+    const uint64_t* stk = (const uint64_t*)st;
+    const uint8_t* meta = st + 8 * g.slots;
+    s.stack = on ? stk[lane] : 0ull;
+    uint32_t m = on ? (uint32_t)meta[lane] : 0u;
+    s.height = m & 63u;
+    s.top = m >> 6;
+    const uint32_t* h = (const uint32_t*)(st + g.bytes - 16);
+    uint32_t h0 = uni(h[0]), h1 = uni(h[1]), h2 = uni(h[2]);
+    s.to_move = (h0 >> 8) & 0xff;
+    s.ply = h0 >> 16;
+    s.ws = h1 & 0xff;
+    s.wc = (h1 >> 8) & 0xff;
+    s.bs = (h1 >> 16) & 0xff;
+    s.bc = h1 >> 24;
+    s.half_komi = (int32_t)(int8_t)(h2 & 0xff);
+    s.rev = (h2 >> 8) & 0xff;
+}
+
+__device__ inline void ws_store(const WState& s, uint8_t* st, const Geom& g) {
+    int lane = lane_id();
+    uint64_t* stk = (uint64_t*)st;
+    uint8_t* meta = st + 8 * g.slots;
+    if (lane < g.slots) {
+        bool on = lane < g.nsq;
+        stk[lane] = on ? s.stack : 0ull;
+        meta[lane] = on ? (uint8_t)(s.height | ((s.height ? s.top : 0u) << 6)) : (uint8_t)0;
+    }
+    // zero the pad so equal games are equal bytes
+    int pad0 = 9 * g.slots, pad1 = g.bytes - 16;
+    for (int i = pad0 + lane; i < pad1; i += 64) st[i] = 0;
+    if (lane < 4) {
+        uint32_t v = 0;
+        if (lane == 0) v = (uint32_t)g.n | (s.to_move << 8) | (s.ply << 16);
+        if (lane == 1) v = s.ws | (s.wc << 8) | (s.bs << 16) | (s.bc << 24);
+        if (lane == 2) v = ((uint32_t)s.half_komi & 0xff) | ((s.rev & 0xff) << 8);
+        ((uint32_t*)(st + g.bytes - 16))[lane] = v;
+    }
+}
+
+__device__ inline void ws_start(WState& s, const Geom& g, int half_komi) {
+    int st, cp;
+    starting_stones(g.n, st, cp);
+    s.stack = 0; s.height = 0; s.top = 0;
+    s.to_move = 0; s.ply = 0; s.ws = s.bs = (uint32_t)st; s.wc = s.bc = (uint32_t)cp;
+    s.rev = 0; s.half_komi = half_komi;
+}
+
+__device__ inline uint32_t top_color(const WState& s) { return s.height ? (uint32_t)((s.stack >> (s.height - 1)) & 1ull) : 0u; }
+
+// Board::find_paths (board.rs:77-113) as a bitboard flood fill: does `b` connect `from` to `to`?
+__device__ inline bool bb_connects(uint64_t b, uint64_t from, uint64_t to, const Geom& g) {
+    uint64_t r = b & from;
+    if (!r || !(b & to)) return false;
+    for (;;) {
+        uint64_t nx = r | (((r << g.n) | (r >> g.n) | ((r << 1) & ~g.col0) | ((r >> 1) & ~g.colL)) & b);
+        if (nx == r) break;
+        r = nx;
+    }
+    return (r & to) != 0;
+}
+__device__ inline bool bb_road(uint64_t b, const Geom& g) {
+    return bb_connects(b, g.row0, g.rowL, g) || bb_connects(b, g.col0, g.colL, g);
+}
+
+// Game::result, game.rs:220-267.  Wave-uniform result (TgResult).
+__device__ inline uint32_t ws_result(const WState& s, const Geom& g) {
+    bool occ = s.height > 0;
+    uint32_t tc = top_color(s);
+    bool roadp = occ && s.top != WALL;
+    uint64_t wroad = __ballot(roadp && tc == 0);
+    uint64_t broad = __ballot(roadp && tc == 1);
+    uint64_t occ_bb = __ballot(occ);
+    uint64_t wflat = __ballot(occ && s.top == FLAT && tc == 0);
+    uint64_t bflat = __ballot(occ && s.top == FLAT && tc == 1);
+    uint32_t other = s.to_move ^ 1u;
+    // dragon clause: the player who just moved is checked first
+    if (bb_road(other ? broad : wroad, g)) return other ? TG_BLACK_ROAD : TG_WHITE_ROAD;
+    if (bb_road(s.to_move ? broad : wroad, g)) return s.to_move ? TG_BLACK_ROAD : TG_WHITE_ROAD;
+    if ((s.wc == 0 && s.ws == 0) || (s.bc == 0 && s.bs == 0) || occ_bb == g.all) {
+        int fd = __popcll(wflat) - __popcll(bflat);
+        int k = s.half_komi / 2;  // truncates toward zero like Rust's i8 division
+        if (fd > k) return TG_WHITE_FLAT;
+        if (fd < k) return TG_BLACK_FLAT;
+        return (s.half_komi % 2 == 0) ? TG_DRAW : TG_BLACK_FLAT;
+    }
+    if (s.rev >= 50) return TG_DRAW_REVERSIBLE;
+    return TG_ONGOING;
+}
+
+__device__ inline int flat_diff(const WState& s) {
+    bool occ = s.height > 0;
+    uint32_t tc = top_color(s);
+    uint64_t wflat = __ballot(occ && s.top == FLAT && tc == 0);
+    uint64_t bflat = __ballot(occ && s.top == FLAT && tc == 1);
+    return __popcll(wflat) - __popcll(bflat);
+}
+
+// Game::play, game.rs:121-218.  Wave-uniform TgPlayError; on error the state is unchanged
+// (Game::safe_play semantics).  All 64 lanes must call.
+__device__ inline uint32_t ws_play(WState& s, uint32_t mv, const Geom& g) {
+    const int lane = lane_id();
+    const int n = g.n;
+    uint32_t sq = mv & 63u, f = (mv >> 6) & 3u, pat = (mv >> 8) & 0xffu;
+    bool swapped = s.ply < 2;
+    uint32_t color = swapped ? (s.to_move ^ 1u) : s.to_move;
+    if ((int)sq >= g.nsq) return TG_PLAY_OUT_OF_BOUNDS;
+    uint32_t src_h = (uint32_t)__shfl((int)s.height, (int)sq);
+    uint32_t src_top = (uint32_t)__shfl((int)s.top, (int)sq);
+    uint64_t src_stack = shfl64(s.stack, (int)sq);
+    if (pat == 0) {  // execute_place, game.rs:147-169
+        uint32_t piece = f;
+        if (piece > CAP) return TG_PLAY_OUT_OF_BOUNDS;
+        uint32_t stones = s.to_move == 0 ? s.ws : s.bs;
+        uint32_t caps = s.to_move == 0 ? s.wc : s.bc;
+        if (src_h) return TG_PLAY_ALREADY_OCCUPIED;
+        if (piece == CAP && caps == 0) return TG_PLAY_NO_CAPSTONE;
+        if (piece != CAP && stones == 0) return TG_PLAY_NO_STONES;
+        if (swapped && piece != FLAT) return TG_PLAY_OPENING_NON_FLAT;
+        if (lane == (int)sq) { s.stack = color; s.height = 1; s.top = piece; }
+        if (piece != CAP) {
+            if ((s.to_move == 0) != swapped) s.ws -= 1; else s.bs -= 1;  // dec_stones :103-109
+        } else {
+            if (s.to_move == 0) s.wc -= 1; else s.bc -= 1;               // dec_caps :111-116
+        }
+        s.rev = 0;
+    } else {  // execute_spread, game.rs:171-209
+        if (src_h == 0) return TG_PLAY_EMPTY_SQUARE;
+        uint32_t src_tc = (uint32_t)((src_stack >> (src_h - 1)) & 1ull);
+        if (src_tc != color) return TG_PLAY_STACK_NOT_OWNED;
+        int k = 8 - __builtin_ctz(pat);  // Pattern::count_pieces
+        int m = __popc(pat);             // squares covered
+        if (k > n) return TG_PLAY_TAKE_CARRY_LIMIT;
+        if (k > (int)src_h) return TG_PLAY_TAKE_STACK_SIZE;
+        int sr = (int)sq / n, sc = (int)sq % n;
+        int room = f == UP ? n - 1 - sr : f == DOWN ? sr : f == LEFT ? sc : n - 1 - sc;
+        int lr = lane / n, lc = lane % n;
+        int i = 0;  // this lane is the i-th square of the spread (0 = not on it)
+        if (lane < g.nsq) {
+            if (f == UP && lc == sc && lr > sr) i = lr - sr;
+            else if (f == DOWN && lc == sc && lr < sr) i = sr - lr;
+            else if (f == LEFT && lr == sr && lc < sc) i = sc - lc;
+            else if (f == RIGHT && lr == sr && lc > sc) i = lc - sc;
+        }
+        if (i > m) i = 0;
+        // stones for step i: carry bits [start, start+len)
+        int start = 0, len = 0;
+        {
+            int cnt = 0, prev = 0;
+            for (int b = 0; b < 8; b++) {
+                if (pat & (0x80u >> b)) {
+                    cnt++;
+                    if (cnt == i) { start = prev; len = b + 1 - prev; }
+                    prev = b + 1;
+                }
+            }
+        }
+        bool last = (i == m);
+        uint32_t err = 0;
+        if (i > 0 && s.height > 0) {  // Tile::stack, tile.rs:28-45
+            if (s.top == CAP) err = TG_PLAY_STACK_CAP;
+            else if (s.top == WALL && !(last && len == 1 && src_top == CAP)) err = TG_PLAY_STACK_WALL;
+        }
+        uint64_t err_bb = __ballot(err != 0);
+        if (err_bb || m > room) {
+            // first failing step in walking order decides
+            int limit = m > room ? room : m;
+            for (int t = 1; t <= limit; t++) {
+                uint64_t bb = __ballot(i == t && err != 0);
+                if (bb) return (uint32_t)__shfl((int)err, __builtin_ctzll(bb));
+            }
+            return TG_PLAY_SPREAD_OUT_OF_BOUNDS;
+        }
+        uint64_t carry = (src_stack >> (src_h - (uint32_t)k)) & ((1ull << k) - 1ull);
+        if (i > 0) {
+            uint64_t sub = (carry >> start) & ((1ull << len) - 1ull);
+            s.stack |= sub << s.height;
+            s.height += (uint32_t)len;
+            s.top = last ? src_top : FLAT;  // only the last stone dropped keeps the carried top type
+        }
+        if (lane == (int)sq) {  // Tile::take, tile.rs:49-63
+            s.height = src_h - (uint32_t)k;
+            s.stack = src_stack & ((1ull << s.height) - 1ull);
+            s.top = FLAT;
+        }
+        s.rev += 1;
+    }
+    s.ply += 1;
+    s.to_move ^= 1u;
+    return TG_PLAY_OK;
+}
+
+// Enumerate the spreads of one (square, direction) in the reference's order (move_gen.rs:54-102):
+// pickup ascending; for each pickup the LIFO stack pops larger first drops first, which is ascending
+// numeric order of the MSB-first drop pattern.  `free_run` = squares in the direction that accept
+// any drop before the edge / a cap / a wall; `smash` = the blocker is a wall and the mover's top is
+// a cap (it may take exactly one stone: the cap).
+template <class F>
+__device__ inline int enum_spreads(int max_carry, int free_run, bool smash, F&& emit) {
+    int count = 0;
+    for (int k = 1; k <= max_carry; k++) {
+        int nv = 1 << (k - 1);
+        for (int v = 0; v < nv; v++) {
+            uint32_t bits = ((uint32_t)v << 1) | 1u;  // k bits, MSB = first carried stone
+            int parts = __popc(bits);
+            bool ok = parts <= free_run || (smash && parts == free_run + 1 && (k == 1 || (v & 1)));
+            if (ok) { emit(count, bits << (8 - k)); count++; }
+        }
+    }
+    return count;
+}
+
+__device__ inline int wave_inclusive_scan(int v) {
+    int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// Game::possible_moves, move_gen.rs:7-30, same order.  Calls emit(index, code) for every move and
+// returns the (wave-uniform) count.  All 64 lanes must call.  emit is called with index < cap only.
+template <class F>
+__device__ inline int ws_movegen(const WState& s, const Geom& g, int cap, F&& emit) {
+    const int lane = lane_id();
+    const int n = g.n;
+    bool occ = s.height > 0;
+    uint32_t tc = top_color(s);
+    bool swapped = s.ply < 2;
+    uint32_t color = swapped ? (s.to_move ^ 1u) : s.to_move;
+    uint64_t occ_bb = __ballot(occ);
+    uint64_t own_bb = __ballot(occ && tc == color);
+    uint64_t wall_bb = __ballot(occ && s.top == WALL);
+    uint64_t cap_bb = __ballot(occ && s.top == CAP);
+    uint32_t stones = s.to_move == 0 ? s.ws : s.bs;
+    uint32_t caps = s.to_move == 0 ? s.wc : s.bc;
+    int base = 0;
+    const int items = 4 * g.nsq;  // (square in col-major order) × (Up, Down, Left, Right)
+    for (int r0 = 0; r0 < items; r0 += 64) {
+        int j = r0 + lane;
+        bool valid = j < items;
+        int jj = valid ? j : 0;
+        int x = jj / (4 * n), y = (jj >> 2) % n, d = jj & 3;
+        int sq = y * n + x;
+        uint32_t h = (uint32_t)__shfl((int)s.height, sq);
+        uint32_t tp = (uint32_t)__shfl((int)s.top, sq);
+        int kind = 0;  // 0 nothing, 1 opening flat, 2 places, 3 spreads
+        int max_carry = 0, free_run = 0;
+        bool smash = false;
+        if (valid) {
+            bool sq_occ = (occ_bb >> sq) & 1ull;
+            if (swapped) {
+                if (d == 0 && !sq_occ) kind = 1;
+            } else if (!sq_occ) {
+                if (d == 0) kind = 2;
+            } else if ((own_bb >> sq) & 1ull) {
+                kind = 3;
+                max_carry = (int)h < n ? (int)h : n;
+                int room = d == UP ? n - 1 - y : d == DOWN ? y : d == LEFT ? x : n - 1 - x;
+                int delta = d == UP ? n : d == DOWN ? -n : d == LEFT ? -1 : 1;
+                int pos = sq;
+                for (int t = 0; t < room; t++) {
+                    pos += delta;
+                    if ((cap_bb >> pos) & 1ull) break;
+                    if ((wall_bb >> pos) & 1ull) { smash = (tp == CAP); break; }
+                    free_run++;
+                }
+            }
+        }
+        int cnt = 0;
+        if (kind == 1) cnt = 1;
+        else if (kind == 2) cnt = (stones > 0 ? 2 : 0) + (caps > 0 ? 1 : 0);
+        else if (kind == 3) cnt = enum_spreads(max_carry, free_run, smash, [](int, uint32_t) {});
+        int incl = wave_inclusive_scan(cnt);
+        int off = base + incl - cnt;
+        if (kind == 1) {
+            if (off < cap) emit(off, (uint32_t)sq | (FLAT << 6));
+        } else if (kind == 2) {
+            int o = off;
+            if (stones > 0) {
+                if (o < cap) emit(o, (uint32_t)sq | (FLAT << 6));
+                if (o + 1 < cap) emit(o + 1, (uint32_t)sq | (WALL << 6));
+                o += 2;
+            }
+            if (caps > 0 && o < cap) emit(o, (uint32_t)sq | (CAP << 6));
+        } else if (kind == 3) {
+            enum_spreads(max_carry, free_run, smash, [&](int idx, uint32_t pat) {
+                if (off + idx < cap) emit(off + idx, (uint32_t)sq | ((uint32_t)d << 6) | (pat << 8));
+            });
+        }
+        base += __shfl(incl, 63);
+    }
+    return base;
+}
+
+// game_repr (alpha-tak/src/repr/game.rs:19-51, board.rs:12-54, reserves.rs:4-28): value of channel
+// c at square data (stack, height, top).  `fcd` is the wave-uniform fcd plane value.
+__device__ inline float repr_value(int c, uint64_t stack, uint32_t height, uint32_t top, const WState& s, int n,
+                                   int stones0, int caps0, float fcd) {
+    const int bc = board_channels(n);
+    if (c < 6) {
+        if (!height) return 0.0f;
+        uint32_t tcol = (uint32_t)((stack >> (height - 1)) & 1ull);
+        int ch = 2 * (int)top + (tcol == s.to_move ? 0 : 1);
+        return c == ch ? 1.0f : 0.0f;
+    }
+    if (c < bc) {
+        int i = (c - 6) >> 1, who = (c - 6) & 1;  // i-th stone below the top
+        if ((int)height < i + 2) return 0.0f;
+        uint32_t col = (uint32_t)((stack >> (height - 2 - (uint32_t)i)) & 1ull);
+        return ((col == s.to_move ? 0 : 1) == who) ? 1.0f : 0.0f;
+    }
+    c -= bc;
+    bool w = s.to_move == 0;
+    int my_st = w ? s.ws : s.bs, en_st = w ? s.bs : s.ws, my_cp = w ? s.wc : s.bc, en_cp = w ? s.bc : s.wc;
+    if (c < stones0) return (my_st - 1 == c) ? 1.0f : 0.0f;
+    c -= stones0;
+    if (c < stones0) return (en_st - 1 == c) ? 1.0f : 0.0f;
+    c -= stones0;
+    if (c < caps0) return (my_cp - 1 == c) ? 1.0f : 0.0f;
+    c -= caps0;
+    if (c < caps0) return (en_cp - 1 == c) ? 1.0f : 0.0f;
+    c -= caps0;
+    if (c == 0) return w ? 1.0f : 0.0f;
+    return fcd;
+}
+
+__device__ inline float fcd_value(const WState& s, const Geom& g) {
+    int fcd = flat_diff(s) - s.half_komi / 2;
+    return (float)((double)fcd / (double)g.nsq);  // f64 division then narrowing, game.rs:35-37
+}
+
+// Write the encoded planes of one game, fully coalesced.  NCHW: out[c*nsq + sq] (the reference
+// tensor); NHWC: out[sq*C + c] (the layout the conv kernels consume).
+template <bool NHWC>
+__device__ inline void ws_encode(const WState& s, const Geom& g, float* out) {
+    const int lane = lane_id();
+    const int C = input_channels(g.n);
+    int st0, cp0;
+    starting_stones(g.n, st0, cp0);
+    float fcd = fcd_value(s, g);
+    const int total = C * g.nsq;
+    for (int e0 = 0; e0 < total; e0 += 64) {
+        int e = e0 + lane;
+        int ee = e < total ? e : 0;
+        int sq = NHWC ? ee / C : ee % g.nsq;
+        int c = NHWC ? ee % C : ee / g.nsq;
+        uint64_t stk = shfl64(s.stack, sq);
+        uint32_t h = (uint32_t)__shfl((int)s.height, sq);
+        uint32_t tp = (uint32_t)__shfl((int)s.top, sq);
+        float v = repr_value(c, stk, h, tp, s, g.n, st0, cp0, fcd);
+        if (e < total) out[e] = v;
+    }
+}
+
+// move_index, alpha-tak/src/search/move_map.rs:19-48.  lut5 = 25*4*32 entries (sq, dir, 5-bit
+// pattern) → index into the legacy 1575 table (−1 = the reference panics), built on the host by rule.
+__device__ inline int move_index_dev(uint32_t mv, int n, bool legacy5, const int16_t* __restrict__ lut5) {
+    uint32_t sq = mv & 63u, f = (mv >> 6) & 3u, pat = (mv >> 8) & 0xffu;
+    if (legacy5) {
+        int row = (int)sq / 5, col = (int)sq % 5;
+        if (pat == 0) return f > 2 ? -1 : (col * 5 + row) * 3 + (int)f;
+        if (pat & 7u) return -1;
+        return (int)lut5[((int)sq * 4 + (int)f) * 32 + (int)(pat >> 3)];
+    }
+    int row = (int)sq / n, col = (int)sq % n;
+    int channel;
+    if (pat == 0) channel = (int)f;
+    else {
+        int pattern_offset = (int)(pat >> (8 - n)) - 1;
+        int d = f == UP ? 0 : f == RIGHT ? 1 : f == DOWN ? 2 : 3;
+        channel = 3 + pattern_offset + ((1 << n) - 2) * d;
+    }
+    return channel * n * n + row * n + col;
+}
+
+}  // namespace tg

@@ -1,0 +1,80 @@
+// engine.h — internal definition of the opaque TgEngine handle (host side of libtakgpu.so)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/takgpu.h"
+#include "board.cuh"
+
+namespace tg {
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define TG_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            return tg::fail(TG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));            \
+    } while (0)
+
+// RAII device allocation
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t ensure(size_t nbytes) {
+        if (nbytes <= bytes) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc(&p, nbytes);
+        if (e == hipSuccess) bytes = nbytes;
+        return e;
+    }
+    template <class T>
+    T* as() const { return (T*)p; }
+};
+
+struct Net;     // net.hip
+struct Search;  // search.hip
+
+}  // namespace tg
+
+struct TgEngine {
+    TgConfig cfg;
+    tg::Geom g;
+    hipStream_t stream = nullptr;
+    int cin = 0;          // input channels
+    int policy_size = 0;  // P
+    bool legacy5 = false; // FC5 head → legacy 1575 LUT indices
+    tg::DevBuf lut5;      // int16[25*4*32]
+    // host-API scratch (sized for cfg.max_batch items)
+    tg::DevBuf s_states, s_moves, s_counts, s_status, s_planes, s_policy, s_eval, s_index;
+    tg::Net* net = nullptr;
+    tg::Search* search = nullptr;
+    ~TgEngine();
+};
+
+namespace tg {
+// net.hip
+int net_create(TgEngine* e);
+void net_destroy(Net* n);
+// search.hip
+void search_destroy(Search* s);
+int net_set_tensor(TgEngine* e, const char* name, const float* data, size_t count);
+int net_finalize(TgEngine* e);
+bool net_ready(const TgEngine* e);
+// forward on device: planes NHWC (n × nsq × C) → policy (n × P, softmax) and eval (n)
+int net_forward_dev(TgEngine* e, int n, const float* d_planes_nhwc, float* d_policy, float* d_eval);
+}  // namespace tg

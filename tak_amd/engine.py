@@ -1,0 +1,305 @@
+"""ctypes binding of libtakgpu.so (C ABI: include/takgpu.h)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtakgpu.so")
+
+TG_MAX_MOVES = 512
+HEAD_FC5, HEAD_CONV = 0, 1
+EVAL_RESNET, EVAL_DUMMY, EVAL_HASH = 0, 1, 2
+
+NODE_RECORD = np.dtype(
+    [("move", "<u2"), ("n_children", "<u2"), ("visits", "<u4"), ("virtual_visits", "<u4"), ("result", "<u4"),
+     ("prior_bits", "<u4"), ("q_bits", "<u4")]
+)
+EXAMPLE_HEADER = np.dtype([("game_id", "<i4"), ("n_moves", "<i4"), ("result", "<f4"), ("reserved", "<i4")])
+
+
+class TgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"takgpu error {code}: {msg}")
+        self.code = code
+
+
+class TgConfig(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in (
+        "abi_version", "device", "board_size", "res_blocks", "filters", "policy_head", "evaluator", "max_batch")]
+
+
+class TgSearchConfig(C.Structure):
+    _fields_ = [("games", C.c_int32), ("arena_nodes", C.c_int32), ("exploration_base", C.c_float),
+                ("exploration_init", C.c_float), ("seed", C.c_uint64)]
+
+
+class TgSelfPlayConfig(C.Structure):
+    _fields_ = [("rollouts", C.c_int32), ("noise_plies", C.c_int32), ("exploit_plies", C.c_int32),
+                ("noise_alpha", C.c_float), ("noise_ratio", C.c_float), ("komi", C.c_int32),
+                ("total_games", C.c_int32), ("max_examples", C.c_int32)]
+
+
+class TgSelfPlayStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in (
+        "games_finished", "examples", "expansions", "evals", "plies", "white_wins", "black_wins", "draws", "instant_wins")]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+# every symbol include/takgpu.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "tg_state_bytes", "tg_engine_create", "tg_engine_destroy", "tg_last_error", "tg_sync", "tg_stream",
+    "tg_input_channels", "tg_policy_size", "tg_movegen", "tg_play", "tg_result", "tg_encode", "tg_move_index",
+    "tg_perft", "tg_net_set_tensor", "tg_net_finalize", "tg_policy_eval", "tg_forward_mcts", "tg_policy_eval_dev",
+    "tg_search_create", "tg_search_reset", "tg_search_run", "tg_search_apply_dirichlet", "tg_search_apply_noise",
+    "tg_search_root", "tg_search_play", "tg_search_states", "tg_search_dump", "tg_search_counters",
+    "tg_selfplay_create", "tg_selfplay_step", "tg_selfplay_stats", "tg_selfplay_drain",
+]
+
+
+def build_library():
+    """Compile the HIP sources for gfx950 into tak_amd/libtakgpu.so (hipcc cross-compiles without a GPU)."""
+    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"], check=True)
+
+
+_lib = None
+
+
+def load_library():
+    """Load libtakgpu.so.  Raises (never falls back) if the library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} is missing: build it with tak_amd.build_library() / __graft_entry__.build()")
+        l = C.CDLL(LIB_PATH)
+        l.tg_state_bytes.restype = C.c_size_t
+        l.tg_last_error.restype = C.c_char_p
+        l.tg_stream.restype = C.c_void_p
+        l.tg_stream.argtypes = [C.c_void_p]
+        l.tg_engine_create.argtypes = [C.c_void_p, C.c_void_p]
+        l.tg_engine_destroy.argtypes = [C.c_void_p]
+        l.tg_engine_destroy.restype = None
+        for name in ABI_SYMBOLS:
+            getattr(l, name)
+        _lib = l
+    return _lib
+
+
+def state_bytes(n):
+    return 256 if n <= 5 else 384
+
+
+def input_channels(n):
+    return int(load_library().tg_input_channels(n))
+
+
+def policy_size(n, head):
+    return int(load_library().tg_policy_size(n, head))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _mask(active):
+    return np.ascontiguousarray(active, np.uint8) if active is not None else None
+
+
+class Engine:
+    """One engine per GPU (reference: one `NET` + the statics of alpha-tak/src/lib.rs:21-23)."""
+
+    def __init__(self, board_size=5, res_blocks=6, filters=64, policy_head=None, evaluator=EVAL_RESNET, max_batch=4096,
+                 device=0):
+        self.lib = load_library()
+        if policy_head is None:
+            policy_head = HEAD_FC5 if board_size == 5 else HEAD_CONV
+        self.n = board_size
+        self.head = policy_head
+        self.max_batch = max_batch
+        self.cfg = TgConfig(1, device, board_size, res_blocks, filters, policy_head, evaluator, max_batch)
+        self.h = C.c_void_p(None)
+        self._check(self.lib.tg_engine_create(C.byref(self.cfg), C.byref(self.h)))
+        self.sb = state_bytes(board_size)
+        self.cin = input_channels(board_size)
+        self.psize = policy_size(board_size, policy_head)
+        self.games = 0
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.tg_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise TgError(rc, self.lib.tg_last_error().decode())
+
+    def _states(self, states):
+        states = np.ascontiguousarray(states, np.uint8).reshape(-1, self.sb)
+        return states, states.shape[0]
+
+    def sync(self):
+        self._check(self.lib.tg_sync(self.h))
+
+    @property
+    def stream(self):
+        return self.lib.tg_stream(self.h)
+
+    # ---- Game::{possible_moves, play, result}, game_repr, move_index -------------------------------
+    def movegen(self, states):
+        states, k = self._states(states)
+        moves = np.zeros((k, TG_MAX_MOVES), np.uint16)
+        counts = np.zeros(k, np.int32)
+        self._check(self.lib.tg_movegen(self.h, k, _p(states), _p(moves), _p(counts)))
+        return moves, counts
+
+    def play(self, states, moves, check=False):
+        states, k = self._states(states)
+        states = states.copy()
+        moves = np.ascontiguousarray(moves, np.uint16).reshape(k)
+        status = np.zeros(k, np.uint8)
+        rc = self.lib.tg_play(self.h, k, _p(states), _p(moves), _p(status))
+        if rc != 0 and (check or rc != -8):
+            self._check(rc)
+        return states, status
+
+    def result(self, states):
+        states, k = self._states(states)
+        out = np.zeros(k, np.uint8)
+        self._check(self.lib.tg_result(self.h, k, _p(states), _p(out)))
+        return out
+
+    def encode(self, states):
+        states, k = self._states(states)
+        out = np.zeros((k, self.cin, self.n, self.n), np.float32)
+        self._check(self.lib.tg_encode(self.h, k, _p(states), _p(out)))
+        return out
+
+    def move_index(self, moves):
+        moves = np.ascontiguousarray(moves, np.uint16).ravel()
+        out = np.zeros(moves.size, np.int32)
+        self._check(self.lib.tg_move_index(self.h, moves.size, _p(moves), _p(out)))
+        return out
+
+    def perft(self, states, depth):
+        states, k = self._states(states)
+        out = np.zeros(k, np.uint64)
+        self._check(self.lib.tg_perft(self.h, k, _p(states), depth, _p(out)))
+        return out
+
+    # ---- Network<N> -------------------------------------------------------------------------------
+    def set_tensor(self, name, array):
+        a = np.ascontiguousarray(array, np.float32)
+        self._check(self.lib.tg_net_set_tensor(self.h, name.encode(), _p(a), C.c_size_t(a.size)))
+
+    def load_state_dict(self, tensors):
+        """tensors: {name: array} with the names of include/takgpu.h (tch layouts)."""
+        for k, v in tensors.items():
+            self.set_tensor(k, np.asarray(v, np.float32))
+        self._check(self.lib.tg_net_finalize(self.h))
+
+    def policy_eval(self, states):
+        """Network::policy_eval: states → (policy [k, P] softmax, eval [k] tanh)."""
+        states, k = self._states(states)
+        policy = np.zeros((k, self.psize), np.float32)
+        ev = np.zeros(k, np.float32)
+        self._check(self.lib.tg_policy_eval(self.h, k, _p(states), _p(policy), _p(ev)))
+        return policy, ev
+
+    def forward_mcts(self, planes):
+        planes = np.ascontiguousarray(planes, np.float32).reshape(-1, self.cin, self.n, self.n)
+        k = planes.shape[0]
+        policy = np.zeros((k, self.psize), np.float32)
+        ev = np.zeros(k, np.float32)
+        self._check(self.lib.tg_forward_mcts(self.h, k, _p(planes), _p(policy), _p(ev)))
+        return policy, ev
+
+    def policy_eval_dev(self, n, d_states, d_policy, d_eval):
+        self._check(self.lib.tg_policy_eval_dev(self.h, n, C.c_void_p(d_states), C.c_void_p(d_policy), C.c_void_p(d_eval)))
+
+    # ---- Node / search ----------------------------------------------------------------------------
+    def search_create(self, games, arena_nodes=1 << 16, base=500.0, init=4.0, seed=0):
+        cfg = TgSearchConfig(games, arena_nodes, base, init, seed)
+        self._check(self.lib.tg_search_create(self.h, C.byref(cfg)))
+        self.games = games
+
+    def search_reset(self, states):
+        states, k = self._states(states)
+        assert k == self.games
+        self._check(self.lib.tg_search_reset(self.h, _p(states)))
+
+    def search_run(self, iters, active=None):
+        self._check(self.lib.tg_search_run(self.h, iters, _p(_mask(active))))
+
+    def search_apply_dirichlet(self, alpha, ratio, active=None):
+        self._check(self.lib.tg_search_apply_dirichlet(self.h, C.c_float(alpha), C.c_float(ratio), _p(_mask(active))))
+
+    def search_apply_noise(self, noise, ratio, active=None):
+        noise = np.ascontiguousarray(noise, np.float32).reshape(self.games, TG_MAX_MOVES)
+        self._check(self.lib.tg_search_apply_noise(self.h, _p(noise), C.c_float(ratio), _p(_mask(active))))
+
+    def search_root(self):
+        g = self.games
+        moves = np.zeros((g, TG_MAX_MOVES), np.uint16)
+        visits = np.zeros((g, TG_MAX_MOVES), np.uint32)
+        prior = np.zeros((g, TG_MAX_MOVES), np.float32)
+        q = np.zeros((g, TG_MAX_MOVES), np.float32)
+        counts = np.zeros(g, np.int32)
+        rv = np.zeros(g, np.uint32)
+        rq = np.zeros(g, np.float32)
+        self._check(self.lib.tg_search_root(self.h, _p(moves), _p(visits), _p(prior), _p(q), _p(counts), _p(rv), _p(rq)))
+        return dict(moves=moves, visits=visits, prior=prior, q=q, counts=counts, root_visits=rv, root_q=rq)
+
+    def search_play(self, moves, active=None):
+        moves = np.ascontiguousarray(moves, np.uint16).reshape(self.games)
+        self._check(self.lib.tg_search_play(self.h, _p(moves), _p(_mask(active))))
+
+    def search_states(self):
+        out = np.zeros((self.games, self.sb), np.uint8)
+        self._check(self.lib.tg_search_states(self.h, _p(out)))
+        return out
+
+    def search_dump(self, game, capacity=1 << 20):
+        rec = np.zeros(capacity, NODE_RECORD)
+        nrec = C.c_size_t(0)
+        self._check(self.lib.tg_search_dump(self.h, game, _p(rec), C.c_size_t(capacity), C.byref(nrec)))
+        return rec[: nrec.value].copy()
+
+    def search_counters(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.lib.tg_search_counters(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    # ---- self_play_parallel ------------------------------------------------------------------------
+    def selfplay_create(self, games, arena_nodes=1 << 16, base=500.0, init=4.0, seed=0, rollouts=400, noise_plies=80,
+                        exploit_plies=40, noise_alpha=0.2, noise_ratio=0.3, komi=2, total_games=0, max_examples=1 << 16):
+        scfg = TgSearchConfig(games, arena_nodes, base, init, seed)
+        cfg = TgSelfPlayConfig(rollouts, noise_plies, exploit_plies, noise_alpha, noise_ratio, komi, total_games, max_examples)
+        self._check(self.lib.tg_selfplay_create(self.h, C.byref(scfg), C.byref(cfg)))
+        self.games = games
+
+    def selfplay_step(self, plies=1):
+        self._check(self.lib.tg_selfplay_step(self.h, plies))
+
+    def selfplay_stats(self):
+        s = TgSelfPlayStats()
+        self._check(self.lib.tg_selfplay_stats(self.h, C.byref(s)))
+        return s.as_dict()
+
+    def selfplay_drain(self, cap=4096):
+        hdr = np.zeros(cap, EXAMPLE_HEADER)
+        states = np.zeros((cap, self.sb), np.uint8)
+        moves = np.zeros((cap, TG_MAX_MOVES), np.uint16)
+        visits = np.zeros((cap, TG_MAX_MOVES), np.uint32)
+        k = C.c_int32(0)
+        self._check(self.lib.tg_selfplay_drain(self.h, cap, _p(hdr), _p(states), _p(moves), _p(visits), C.byref(k)))
+        k = k.value
+        return hdr[:k].copy(), states[:k].copy(), moves[:k].copy(), visits[:k].copy()

@@ -405,24 +405,26 @@ __device__ inline float fcd_value(const WState& s, const Geom& g) {
 }
 
 // Write the encoded planes of one game, fully coalesced.  NCHW: out[c*nsq + sq] (the reference
-// tensor); NHWC: out[sq*C + c] (the layout the conv kernels consume).
+// tensor); NHWC: out[sq*cstride + c] with channels C..cstride-1 zero (the layout the conv kernels
+// consume, rows padded to a multiple of 8 channels).
 template <bool NHWC>
-__device__ inline void ws_encode(const WState& s, const Geom& g, float* out) {
+__device__ inline void ws_encode(const WState& s, const Geom& g, float* out, int cstride) {
     const int lane = lane_id();
     const int C = input_channels(g.n);
+    if (!NHWC) cstride = C;
     int st0, cp0;
     starting_stones(g.n, st0, cp0);
     float fcd = fcd_value(s, g);
-    const int total = C * g.nsq;
+    const int total = cstride * g.nsq;
     for (int e0 = 0; e0 < total; e0 += 64) {
         int e = e0 + lane;
         int ee = e < total ? e : 0;
-        int sq = NHWC ? ee / C : ee % g.nsq;
-        int c = NHWC ? ee % C : ee / g.nsq;
+        int sq = NHWC ? ee / cstride : ee % g.nsq;
+        int c = NHWC ? ee % cstride : ee / g.nsq;
         uint64_t stk = shfl64(s.stack, sq);
         uint32_t h = (uint32_t)__shfl((int)s.height, sq);
         uint32_t tp = (uint32_t)__shfl((int)s.top, sq);
-        float v = repr_value(c, stk, h, tp, s, g.n, st0, cp0, fcd);
+        float v = c < C ? repr_value(c, stk, h, tp, s, g.n, st0, cp0, fcd) : 0.0f;
         if (e < total) out[e] = v;
     }
 }

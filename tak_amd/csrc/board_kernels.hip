@@ -47,13 +47,13 @@ __global__ __launch_bounds__(256) void k_result(const uint8_t* __restrict__ stat
 
 template <bool NHWC>
 __global__ __launch_bounds__(256) void k_encode(const uint8_t* __restrict__ states, int count, int n,
-                                                float* __restrict__ planes) {
+                                                float* __restrict__ planes, int cstride) {
     int gi = wave_global_id();
     if (gi >= count) return;
     Geom g = make_geom(n);
     WState s;
     ws_load(s, states + (size_t)gi * g.bytes, g);
-    ws_encode<NHWC>(s, g, planes + (size_t)gi * input_channels(n) * g.nsq);
+    ws_encode<NHWC>(s, g, planes + (size_t)gi * cstride * g.nsq, cstride);
 }
 
 __global__ void k_move_index(const uint16_t* __restrict__ moves, int count, int n, int legacy5,
@@ -119,8 +119,12 @@ void launch_result(hipStream_t st, const uint8_t* states, int count, int n, uint
 }
 void launch_encode(hipStream_t st, const uint8_t* states, int count, int n, float* planes, bool nhwc) {
     if (count <= 0) return;
-    if (nhwc) hipLaunchKernelGGL(k_encode<true>, wave_grid(count), dim3(256), 0, st, states, count, n, planes);
-    else hipLaunchKernelGGL(k_encode<false>, wave_grid(count), dim3(256), 0, st, states, count, n, planes);
+    int c = input_channels(n);
+    if (nhwc) hipLaunchKernelGGL(k_encode<true>, wave_grid(count), dim3(256), 0, st, states, count, n, planes, c);
+    else hipLaunchKernelGGL(k_encode<false>, wave_grid(count), dim3(256), 0, st, states, count, n, planes, c);
+}
+void launch_encode_nhwc(hipStream_t st, const uint8_t* states, int count, int n, float* planes, int cstride) {
+    if (count > 0) hipLaunchKernelGGL(k_encode<true>, wave_grid(count), dim3(256), 0, st, states, count, n, planes, cstride);
 }
 void launch_move_index(hipStream_t st, const uint16_t* moves, int count, int n, bool legacy5, const int16_t* lut5, int32_t* index) {
     if (count > 0) hipLaunchKernelGGL(k_move_index, dim3((count + 255) / 256), dim3(256), 0, st, moves, count, n, legacy5 ? 1 : 0, lut5, index);

@@ -10,9 +10,20 @@ void launch_movegen(hipStream_t st, const uint8_t* states, int count, int n, uin
 void launch_play(hipStream_t st, uint8_t* states, int count, int n, const uint16_t* moves, uint8_t* status);
 void launch_result(hipStream_t st, const uint8_t* states, int count, int n, uint8_t* results);
 void launch_encode(hipStream_t st, const uint8_t* states, int count, int n, float* planes, bool nhwc);
+void launch_encode_nhwc(hipStream_t st, const uint8_t* states, int count, int n, float* planes, int cstride);
 void launch_move_index(hipStream_t st, const uint16_t* moves, int count, int n, bool legacy5, const int16_t* lut5, int32_t* index);
 void launch_perft_count(hipStream_t st, const uint8_t* states, int count, int n, int32_t* nchild, uint8_t* terminal);
 void launch_perft_expand(hipStream_t st, const uint8_t* states, int count, int n, const int64_t* offsets, const int32_t* root_of,
                          uint8_t* next_states, int32_t* next_root);
+
+// net_kernels.hip
+hipError_t launch_conv3x3(hipStream_t st, const float* in, const float* Wp, const float* bias, const float* res, float* out,
+                          int M, int n, int Cpad, int CoutP, int out_stride, int cout_valid, bool relu);
+hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp, const float* bias, float* out, int M, int K,
+                       int NP, int out_stride, int n_valid);
+hipError_t launch_value_head(hipStream_t st, const float* act, const float* wv, float bv, int B, int len, float* eval);
+hipError_t launch_softmax(hipStream_t st, const float* logits, int row_stride, bool conv_head, int nsq, int ch_stride, int P,
+                          int B, float* policy);
+hipError_t launch_nchw_to_nhwc(hipStream_t st, const float* src, int B, int C, int nsq, int Cpad, float* dst);
 
 }  // namespace tg

@@ -1,19 +1,288 @@
-// net.hip — placeholder, replaced by the real network kernels
+// net.hip — host side of the network: tensor intake in tch/libtorch layout, BatchNorm folding,
+// re-layout for the MFMA kernels, and the forward schedule (one kernel per conv layer, heads,
+// softmax) on the engine stream.  Replaces Network<N> of reference alpha-tak/src/model/network.rs:26-35
+// and the concrete Net5 / Net6 (model/net5.rs, net6.rs, res_block.rs) without any tch type.
+#include <cmath>
+#include <cstring>
+
 #include "engine.h"
+#include "kernels.h"
+
 namespace tg {
-struct Net {};
-int net_create(TgEngine*) { return TG_OK; }
+
+struct ConvLayer {
+    DevBuf w, b;      // Wp [K/8][CoutP][8], bias [CoutP]
+    int cin_pad = 0;  // channels per input row (multiple of 8)
+    int cout = 0, cout_pad = 0;
+};
+
+struct Net {
+    std::map<std::string, std::vector<float>> tensors;  // as given (tch layouts)
+    bool ready = false;
+    int F = 0, R = 0, cin = 0, cin_pad = 0;
+    ConvLayer conv0;
+    std::vector<ConvLayer> res1, res2;
+    ConvLayer policy_conv;            // TG_HEAD_CONV
+    DevBuf policy_w, policy_b;        // TG_HEAD_FC5: Wp [K/8][NP][8]
+    int policy_np = 0;                // padded FC outputs
+    DevBuf value_w;                   // [nsq*F] in NHWC order
+    float value_b = 0.0f;
+    // activations (max_batch positions)
+    DevBuf x, y, logits, planes_nhwc, planes_nchw;
+};
+
 void net_destroy(Net* n) { delete n; }
-int net_set_tensor(TgEngine*, const char*, const float*, size_t) { return fail(TG_ERR_STATE, "network not built yet"); }
-int net_finalize(TgEngine*) { return fail(TG_ERR_STATE, "network not built yet"); }
-bool net_ready(const TgEngine*) { return false; }
-int net_forward_dev(TgEngine*, int, const float*, float*, float*) { return fail(TG_ERR_STATE, "network not built yet"); }
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+int net_create(TgEngine* e) {
+    Net* n = new Net();
+    e->net = n;
+    n->F = e->cfg.filters;
+    n->R = e->cfg.res_blocks;
+    n->cin = e->cin;
+    n->cin_pad = round_up(e->cin, 8);
+    return TG_OK;
 }
+
+int net_set_tensor(TgEngine* e, const char* name, const float* data, size_t count) {
+    if (!e || !e->net) return fail(TG_ERR_STATE, "engine has no network (evaluator is not TG_EVAL_RESNET)");
+    if (!name || (!data && count)) return fail(TG_ERR_INVALID_ARG, "tg_net_set_tensor: null argument");
+    e->net->tensors[name] = std::vector<float>(data, data + count);
+    e->net->ready = false;
+    return TG_OK;
+}
+
+bool net_ready(const TgEngine* e) { return e && e->net && e->net->ready; }
+
+namespace {
+
+struct Folded {
+    std::vector<float> w, b;  // OIHW weights scaled per output channel, bias
+};
+
+const std::vector<float>* find(Net* n, const std::string& name, size_t want, std::string& err) {
+    auto it = n->tensors.find(name);
+    if (it == n->tensors.end()) { err = "missing tensor " + name; return nullptr; }
+    if (it->second.size() != want) {
+        err = "tensor " + name + " has " + std::to_string(it->second.size()) + " elements, expected " + std::to_string(want);
+        return nullptr;
+    }
+    return &it->second;
+}
+
+// conv (O,I,3,3)+bias followed by BatchNorm in eval mode (running stats, eps = 1e-5, tch default):
+// y = (conv(x) + b - mean) * gamma / sqrt(var + eps) + beta  →  w' = w*s, b' = (b - mean)*s + beta
+bool fold_conv_bn(Net* n, const std::string& conv, const std::string& bn, int O, int I, Folded& out, std::string& err) {
+    auto w = find(n, conv + ".weight", (size_t)O * I * 9, err);
+    auto b = w ? find(n, conv + ".bias", O, err) : nullptr;
+    if (!w || !b) return false;
+    out.w = *w;
+    out.b = *b;
+    if (bn.empty()) return true;
+    auto g = find(n, bn + ".weight", O, err);
+    auto be = g ? find(n, bn + ".bias", O, err) : nullptr;
+    auto mu = be ? find(n, bn + ".running_mean", O, err) : nullptr;
+    auto var = mu ? find(n, bn + ".running_var", O, err) : nullptr;
+    if (!var) return false;
+    for (int o = 0; o < O; o++) {
+        float s = (*g)[o] / std::sqrt((*var)[o] + 1e-5f);
+        for (int k = 0; k < I * 9; k++) out.w[(size_t)o * I * 9 + k] *= s;
+        out.b[o] = ((*b)[o] - (*mu)[o]) * s + (*be)[o];
+    }
+    return true;
+}
+
+// OIHW → Wp[(tap*Ipad + c)/8][CoutP][(tap*Ipad + c)%8], tap = ky*3 + kx, zero padded
+hipError_t upload_conv(const Folded& f, int O, int I, int Ipad, ConvLayer& L) {
+    int OP = round_up(O, 64);
+    size_t K = (size_t)9 * Ipad;
+    std::vector<float> wp(K * OP, 0.0f), bp(OP, 0.0f);
+    for (int o = 0; o < O; o++) {
+        bp[o] = f.b[o];
+        for (int c = 0; c < I; c++)
+            for (int tap = 0; tap < 9; tap++) {
+                size_t k = (size_t)tap * Ipad + c;
+                wp[((k >> 3) * OP + o) * 8 + (k & 7)] = f.w[((size_t)o * I + c) * 9 + tap];
+            }
+    }
+    L.cin_pad = Ipad; L.cout = O; L.cout_pad = OP;
+    hipError_t e = L.w.ensure(wp.size() * 4);
+    if (e != hipSuccess) return e;
+    e = L.b.ensure(bp.size() * 4);
+    if (e != hipSuccess) return e;
+    e = hipMemcpy(L.w.p, wp.data(), wp.size() * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(L.b.p, bp.data(), bp.size() * 4, hipMemcpyHostToDevice);
+}
+
+}  // namespace
+
+int net_finalize(TgEngine* e) {
+    if (!e || !e->net) return fail(TG_ERR_STATE, "engine has no network (evaluator is not TG_EVAL_RESNET)");
+    TG_HIP(hipSetDevice(e->cfg.device));
+    Net* n = e->net;
+    const int F = n->F, R = n->R, nsq = e->g.nsq;
+    std::string err;
+    Folded f;
+    if (!fold_conv_bn(n, "conv0", "bn0", F, n->cin, f, err)) return fail(TG_ERR_WEIGHTS, err);
+    TG_HIP(upload_conv(f, F, n->cin, n->cin_pad, n->conv0));
+    n->res1.clear(); n->res2.clear();
+    n->res1.resize(R); n->res2.resize(R);
+    for (int i = 0; i < R; i++) {
+        std::string p = "res" + std::to_string(i);
+        if (!fold_conv_bn(n, p + ".conv1", p + ".bn1", F, F, f, err)) return fail(TG_ERR_WEIGHTS, err);
+        TG_HIP(upload_conv(f, F, F, F, n->res1[i]));
+        if (!fold_conv_bn(n, p + ".conv2", p + ".bn2", F, F, f, err)) return fail(TG_ERR_WEIGHTS, err);
+        TG_HIP(upload_conv(f, F, F, F, n->res2[i]));
+    }
+    const int P = e->policy_size;
+    if (e->cfg.policy_head == TG_HEAD_CONV) {
+        int ch = P / nsq;
+        if (!fold_conv_bn(n, "policy", "", ch, F, f, err)) return fail(TG_ERR_WEIGHTS, err);
+        TG_HIP(upload_conv(f, ch, F, F, n->policy_conv));
+    } else {
+        // Linear [P, F*nsq] over the NCHW flattening c*nsq + sq (net5.rs:86 view) → K order sq*F + c
+        size_t K = (size_t)F * nsq;
+        auto w = find(n, "policy.weight", (size_t)P * K, err);
+        auto b = w ? find(n, "policy.bias", P, err) : nullptr;
+        if (!b) return fail(TG_ERR_WEIGHTS, err);
+        int NP = round_up(P, 64);
+        std::vector<float> wp(K * NP, 0.0f), bp(NP, 0.0f);
+        for (int o = 0; o < P; o++) {
+            bp[o] = (*b)[o];
+            for (int c = 0; c < F; c++)
+                for (int sq = 0; sq < nsq; sq++) {
+                    size_t k = (size_t)sq * F + c;
+                    wp[((k >> 3) * NP + o) * 8 + (k & 7)] = (*w)[(size_t)o * K + (size_t)c * nsq + sq];
+                }
+        }
+        n->policy_np = NP;
+        TG_HIP(n->policy_w.ensure(wp.size() * 4));
+        TG_HIP(n->policy_b.ensure(bp.size() * 4));
+        TG_HIP(hipMemcpy(n->policy_w.p, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
+        TG_HIP(hipMemcpy(n->policy_b.p, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+    }
+    {
+        size_t K = (size_t)F * nsq;
+        auto w = find(n, "value.weight", K, err);
+        auto b = w ? find(n, "value.bias", 1, err) : nullptr;
+        if (!b) return fail(TG_ERR_WEIGHTS, err);
+        std::vector<float> wv(K);
+        for (int c = 0; c < F; c++)
+            for (int sq = 0; sq < nsq; sq++) wv[(size_t)sq * F + c] = (*w)[(size_t)c * nsq + sq];
+        n->value_b = (*b)[0];
+        TG_HIP(n->value_w.ensure(K * 4));
+        TG_HIP(hipMemcpy(n->value_w.p, wv.data(), K * 4, hipMemcpyHostToDevice));
+    }
+    size_t mb = (size_t)e->cfg.max_batch;
+    TG_HIP(n->x.ensure(mb * nsq * F * 4));
+    TG_HIP(n->y.ensure(mb * nsq * F * 4));
+    size_t logit_row = e->cfg.policy_head == TG_HEAD_CONV ? (size_t)nsq * n->policy_conv.cout_pad : (size_t)n->policy_np;
+    TG_HIP(n->logits.ensure(mb * logit_row * 4));
+    TG_HIP(n->planes_nhwc.ensure(mb * nsq * n->cin_pad * 4));
+    n->ready = true;
+    return TG_OK;
+}
+
+// planes NHWC [nb][nsq][cin_pad] (device) → policy [nb][P] (softmax, reference order), eval [nb]
+int net_forward_dev(TgEngine* e, int nb, const float* d_planes, float* d_policy, float* d_eval) {
+    if (!net_ready(e)) return fail(TG_ERR_STATE, "network weights not finalized (tg_net_finalize)");
+    if (nb <= 0) return TG_OK;
+    if (nb > e->cfg.max_batch) return fail(TG_ERR_INVALID_ARG, "batch larger than max_batch");
+    Net* n = e->net;
+    hipStream_t st = e->stream;
+    const int F = n->F, nsq = e->g.nsq, N = e->g.n;
+    const int M = nb * nsq;
+    float* x = n->x.as<float>();
+    float* y = n->y.as<float>();
+    TG_HIP(launch_conv3x3(st, d_planes, n->conv0.w.as<float>(), n->conv0.b.as<float>(), nullptr, x, M, N, n->cin_pad,
+                          n->conv0.cout_pad, F, F, true));
+    for (int i = 0; i < n->R; i++) {
+        TG_HIP(launch_conv3x3(st, x, n->res1[i].w.as<float>(), n->res1[i].b.as<float>(), nullptr, y, M, N, F,
+                              n->res1[i].cout_pad, F, F, true));
+        TG_HIP(launch_conv3x3(st, y, n->res2[i].w.as<float>(), n->res2[i].b.as<float>(), x, x, M, N, F,
+                              n->res2[i].cout_pad, F, F, true));
+    }
+    float* logits = n->logits.as<float>();
+    if (e->cfg.policy_head == TG_HEAD_CONV) {
+        const ConvLayer& L = n->policy_conv;
+        TG_HIP(launch_conv3x3(st, x, L.w.as<float>(), L.b.as<float>(), nullptr, logits, M, N, F, L.cout_pad, L.cout_pad, L.cout, false));
+        TG_HIP(launch_softmax(st, logits, nsq * L.cout_pad, true, nsq, L.cout_pad, e->policy_size, nb, d_policy));
+    } else {
+        TG_HIP(launch_gemm(st, x, nsq * F, n->policy_w.as<float>(), n->policy_b.as<float>(), logits, nb, nsq * F, n->policy_np,
+                           n->policy_np, e->policy_size));
+        TG_HIP(launch_softmax(st, logits, n->policy_np, false, nsq, 0, e->policy_size, nb, d_policy));
+    }
+    TG_HIP(launch_value_head(st, x, n->value_w.as<float>(), n->value_b, nb, nsq * F, d_eval));
+    return TG_OK;
+}
+
+}  // namespace tg
+
 using namespace tg;
+
 extern "C" {
+
 int tg_net_set_tensor(TgEngine* e, const char* name, const float* data, size_t count) { return net_set_tensor(e, name, data, count); }
 int tg_net_finalize(TgEngine* e) { return net_finalize(e); }
-int tg_policy_eval(TgEngine*, int, const void*, float*, float*) { return fail(TG_ERR_STATE, "network not built yet"); }
-int tg_forward_mcts(TgEngine*, int, const float*, float*, float*) { return fail(TG_ERR_STATE, "network not built yet"); }
-int tg_policy_eval_dev(TgEngine*, int, const void*, float*, float*) { return fail(TG_ERR_STATE, "network not built yet"); }
+
+// Network::policy_eval (net5.rs:120-130): encode on the device straight into NHWC, forward, copy out
+int tg_policy_eval_dev(TgEngine* e, int n, const void* d_states, float* d_policy, float* d_eval) {
+    if (!net_ready(e)) return fail(TG_ERR_STATE, "network weights not finalized (tg_net_finalize)");
+    if (n < 0 || n > e->cfg.max_batch) return fail(TG_ERR_INVALID_ARG, "tg_policy_eval_dev: n out of range");
+    if (n == 0) return TG_OK;
+    TG_HIP(hipSetDevice(e->cfg.device));
+    Net* net = e->net;
+    launch_encode_nhwc(e->stream, (const uint8_t*)d_states, n, e->g.n, net->planes_nhwc.as<float>(), net->cin_pad);
+    TG_HIP(hipGetLastError());
+    return net_forward_dev(e, n, net->planes_nhwc.as<float>(), d_policy, d_eval);
 }
+
+int tg_policy_eval(TgEngine* e, int n, const void* states, float* policy, float* eval) {
+    if (!e) return fail(TG_ERR_INVALID_ARG, "null engine");
+    if (n < 0 || (n > 0 && (!states || !policy || !eval))) return fail(TG_ERR_INVALID_ARG, "tg_policy_eval: bad arguments");
+    if (n == 0) return TG_OK;  // net5.rs:121-123
+    if (!net_ready(e)) return fail(TG_ERR_STATE, "network weights not finalized (tg_net_finalize)");
+    TG_HIP(hipSetDevice(e->cfg.device));
+    const size_t sb = e->g.bytes, P = (size_t)e->policy_size;
+    TG_HIP(e->s_policy.ensure((size_t)e->cfg.max_batch * P * 4));
+    TG_HIP(e->s_eval.ensure((size_t)e->cfg.max_batch * 4));
+    for (int off = 0; off < n; off += e->cfg.max_batch) {
+        int k = std::min(e->cfg.max_batch, n - off);
+        TG_HIP(hipMemcpyAsync(e->s_states.p, (const uint8_t*)states + (size_t)off * sb, (size_t)k * sb, hipMemcpyHostToDevice, e->stream));
+        int rc = tg_policy_eval_dev(e, k, e->s_states.p, e->s_policy.as<float>(), e->s_eval.as<float>());
+        if (rc) return rc;
+        TG_HIP(hipMemcpyAsync(policy + (size_t)off * P, e->s_policy.p, (size_t)k * P * 4, hipMemcpyDeviceToHost, e->stream));
+        TG_HIP(hipMemcpyAsync(eval + off, e->s_eval.p, (size_t)k * 4, hipMemcpyDeviceToHost, e->stream));
+        TG_HIP(hipStreamSynchronize(e->stream));
+    }
+    return TG_OK;
+}
+
+// Network::forward_mcts (net5.rs:106-111) on caller-encoded NCHW planes
+int tg_forward_mcts(TgEngine* e, int n, const float* planes, float* policy, float* eval) {
+    if (!e) return fail(TG_ERR_INVALID_ARG, "null engine");
+    if (n < 0 || (n > 0 && (!planes || !policy || !eval))) return fail(TG_ERR_INVALID_ARG, "tg_forward_mcts: bad arguments");
+    if (n == 0) return TG_OK;
+    if (!net_ready(e)) return fail(TG_ERR_STATE, "network weights not finalized (tg_net_finalize)");
+    TG_HIP(hipSetDevice(e->cfg.device));
+    Net* net = e->net;
+    const size_t per = (size_t)e->cin * e->g.nsq, P = (size_t)e->policy_size;
+    TG_HIP(net->planes_nchw.ensure((size_t)e->cfg.max_batch * per * 4));
+    TG_HIP(e->s_policy.ensure((size_t)e->cfg.max_batch * P * 4));
+    TG_HIP(e->s_eval.ensure((size_t)e->cfg.max_batch * 4));
+    for (int off = 0; off < n; off += e->cfg.max_batch) {
+        int k = std::min(e->cfg.max_batch, n - off);
+        TG_HIP(hipMemcpyAsync(net->planes_nchw.p, planes + (size_t)off * per, (size_t)k * per * 4, hipMemcpyHostToDevice, e->stream));
+        TG_HIP(launch_nchw_to_nhwc(e->stream, net->planes_nchw.as<float>(), k, e->cin, e->g.nsq, net->cin_pad, net->planes_nhwc.as<float>()));
+        int rc = net_forward_dev(e, k, net->planes_nhwc.as<float>(), e->s_policy.as<float>(), e->s_eval.as<float>());
+        if (rc) return rc;
+        TG_HIP(hipMemcpyAsync(policy + (size_t)off * P, e->s_policy.p, (size_t)k * P * 4, hipMemcpyDeviceToHost, e->stream));
+        TG_HIP(hipMemcpyAsync(eval + off, e->s_eval.p, (size_t)k * 4, hipMemcpyDeviceToHost, e->stream));
+        TG_HIP(hipStreamSynchronize(e->stream));
+    }
+    return TG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,348 @@
+// net_kernels.hip — policy/value resnet forward on CDNA4 matrix cores, exact f32.
+//
+// Replaces the libtorch ops behind reference alpha-tak/src/model/{net5,net6,res_block}.rs
+// (conv2d 3×3 pad 1 + batch_norm(eval) + relu + residual add, linear, softmax, tanh).
+//
+// Layout: activations are NHWC — row m = (position b, square sq), F contiguous channels — so a
+// 3×3 convolution is an implicit GEMM  out[m][o] = Σ_{tap,c} X[nbr(m,tap)][c] · W[tap,c][o]  with
+// M = B·N² rows, K = 9·C.  Halos never cross positions, so a workgroup stages the whole positions
+// its row tile touches into LDS once (plus one all-zero row that out-of-board taps point at) and
+// every tap is just a different LDS row offset: im2col lives in address arithmetic only.
+// MFMA: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate — bit-exact fmaf chains, the parity path;
+// 157 TF peak).  Each lane feeds 4 consecutive k of its row/column from one 16-byte load, so the
+// K order inside a group of 8 is (k, k+4) pairs; weights are pre-permuted to [K/8][Cout][8] on
+// the host so the B fragment is one coalesced 16-byte global load per lane (L2-resident: a whole
+// layer is ≤ 590 KB).  BatchNorm (eval) is folded into weights/bias at load time; bias, residual
+// and ReLU are fused into the accumulator epilogue.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace tg {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int LDS_PAD = 4;  // floats appended to every LDS row: consecutive rows shift by 4 banks
+
+// Workgroup = 4 waves as 2 (rows) × 2 (cols); each wave owns RT×CT tiles of 32×32.
+template <int RT, int CT>
+__global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, const float* __restrict__ Wp,
+                                                 const float* __restrict__ bias, const float* __restrict__ res,
+                                                 float* __restrict__ out, int M, int n, int Cpad, int CoutP,
+                                                 int out_stride, int cout_valid, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TM = 64 * RT;
+    const int tid = threadIdx.x;
+    const int nsq = n * n;
+    const int LS = Cpad + LDS_PAD;
+    const int m0 = blockIdx.x * TM;
+    const int mlast = min(m0 + TM, M) - 1;
+    const int pos0 = m0 / nsq;
+    const int npos = mlast / nsq - pos0 + 1;
+    const int rows = npos * nsq;
+
+    // ---- stage the touched positions (contiguous in global) into padded LDS rows ----
+    {
+        const int vpr = Cpad >> 2;  // float4 per row
+        const float4* src = (const float4*)(in + (size_t)pos0 * nsq * Cpad);
+        const int total = rows * vpr;
+        for (int idx = tid; idx < total; idx += 256) {
+            int r = idx / vpr, v = idx - r * vpr;
+            float4 x = src[idx];
+            *(float4*)&lds[r * LS + v * 4] = x;
+        }
+        for (int idx = tid; idx < LS; idx += 256) lds[rows * LS + idx] = 0.0f;  // the zero row
+    }
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wr = wave & 1, wc = wave >> 1;
+    const int i = lane & 31, h = lane >> 5;
+    const int zero_off = rows * LS + 4 * h;
+
+    int base_off[RT], py[RT], px[RT];
+    bool valid[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+        int m = m0 + (wr * RT + rt) * 32 + i;
+        valid[rt] = m < M;
+        int mm = valid[rt] ? m : m0;
+        int p = mm / nsq;
+        int sq = mm - p * nsq;
+        py[rt] = sq / n;
+        px[rt] = sq - py[rt] * n;
+        base_off[rt] = ((p - pos0) * nsq + sq) * LS + 4 * h;
+    }
+
+    f32x16 acc[RT][CT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[rt][ct][r] = 0.0f;
+
+    const int col0 = blockIdx.y * (64 * CT) + wc * (32 * CT);
+    const int chunks = Cpad >> 3;
+    // B fragment base: Wp[kchunk][col][8], this lane: column col0 + ct*32 + i, k sub-offset 4h
+    const float* wlane = Wp + ((size_t)(col0 + i) * 8 + 4 * h);
+    const size_t wchunk_stride = (size_t)CoutP * 8;
+
+    for (int tap = 0; tap < 9; tap++) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        int aoff[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            int yy = py[rt] + dy, xx = px[rt] + dx;
+            bool ok = valid[rt] && yy >= 0 && yy < n && xx >= 0 && xx < n;
+            aoff[rt] = ok ? base_off[rt] + (dy * n + dx) * LS : zero_off;
+        }
+        const float* wtap = wlane + (size_t)tap * chunks * wchunk_stride;
+        for (int c8 = 0; c8 < chunks; c8++) {
+            f32x4 a[RT], b[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) b[ct] = *(const f32x4*)(wtap + (size_t)c8 * wchunk_stride + (size_t)ct * 32 * 8);
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) a[rt] = *(const f32x4*)&lds[aoff[rt] + c8 * 8];
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ct++)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt][t], b[ct][t], acc[rt][ct], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: bias (+ residual) (+ ReLU); C/D map: col = lane&31, row = (r&3) + 8(r>>2) + 4(lane>>5) ----
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            const int col = col0 + ct * 32 + i;
+            const float bv = bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                int m = m0 + (wr * RT + rt) * 32 + row;
+                if (m < M && col < cout_valid) {
+                    float v = acc[rt][ct][r] + bv;
+                    size_t o = (size_t)m * out_stride + col;
+                    if (res) v += res[o];
+                    if (relu) v = fmaxf(v, 0.0f);
+                    out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+// Plain GEMM out[M][N] = A[M][K]·W[K][N] + bias for the 5×5 policy FC (net5.rs:56-61,108): the same
+// fragments, A staged through LDS in K-chunks of 32.
+template <int RT, int CT>
+__global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda, const float* __restrict__ Wp,
+                                              const float* __restrict__ bias, float* __restrict__ out, int M, int K,
+                                              int NP, int out_stride, int n_valid) {
+    constexpr int TM = 64 * RT;
+    constexpr int KC = 32;
+    constexpr int LS = KC + LDS_PAD;
+    __shared__ __attribute__((aligned(16))) float lds[2][TM * LS];
+    const int tid = threadIdx.x;
+    const int m0 = blockIdx.x * TM;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wr = wave & 1, wc = wave >> 1;
+    const int i = lane & 31, h = lane >> 5;
+    const int col0 = blockIdx.y * (64 * CT) + wc * (32 * CT);
+    const float* wlane = Wp + ((size_t)(col0 + i) * 8 + 4 * h);
+    const size_t wchunk_stride = (size_t)NP * 8;
+
+    f32x16 acc[RT][CT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[rt][ct][r] = 0.0f;
+
+    auto stage = [&](int buf, int k0) {
+        // TM rows × 8 float4
+        for (int idx = tid; idx < TM * (KC / 4); idx += 256) {
+            int r = idx >> 3, v = idx & 7;
+            int m = m0 + r;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < M) x = *(const float4*)(A + (size_t)m * lda + k0 + v * 4);
+            *(float4*)&lds[buf][r * LS + v * 4] = x;
+        }
+    };
+
+    const int nchunk = K / KC;
+    stage(0, 0);
+    __syncthreads();
+    for (int kc = 0; kc < nchunk; kc++) {
+        const int buf = kc & 1;
+        if (kc + 1 < nchunk) stage(buf ^ 1, (kc + 1) * KC);
+#pragma unroll
+        for (int c8 = 0; c8 < KC / 8; c8++) {
+            f32x4 a[RT], b[CT];
+            const size_t kchunk = (size_t)kc * (KC / 8) + c8;
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) b[ct] = *(const f32x4*)(wlane + kchunk * wchunk_stride + (size_t)ct * 32 * 8);
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) a[rt] = *(const f32x4*)&lds[buf][((wr * RT + rt) * 32 + i) * LS + c8 * 8 + 4 * h];
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ct++)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt][t], b[ct][t], acc[rt][ct], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            const int col = col0 + ct * 32 + i;
+            const float bv = bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                int m = m0 + (wr * RT + rt) * 32 + row;
+                if (m < M && col < n_valid) out[(size_t)m * out_stride + col] = acc[rt][ct][r] + bv;
+            }
+        }
+}
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+    return v;
+}
+
+// value head: Linear(F·N² → 1) + tanh (net5.rs:62,109 / net6.rs:57,104-107).  One wave per position;
+// wv is permuted to the NHWC order of the activations.
+__global__ __launch_bounds__(256) void k_value_head(const float* __restrict__ act, const float* __restrict__ wv, float bv,
+                                                    int B, int len, float* __restrict__ eval) {
+    int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    int lane = threadIdx.x & 63;
+    const float4* a = (const float4*)(act + (size_t)b * len);
+    const float4* w = (const float4*)wv;
+    float s = 0.0f;
+    for (int k = lane; k < (len >> 2); k += 64) {
+        float4 x = a[k], y = w[k];
+        s = fmaf(x.x, y.x, s);
+        s = fmaf(x.y, y.y, s);
+        s = fmaf(x.z, y.z, s);
+        s = fmaf(x.w, y.w, s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) eval[b] = tanhf(s + bv);
+}
+
+// softmax over ALL P outputs (no legal-move mask; net5.rs:108, net6.rs:100-103).  One 256-thread block
+// per position.  logits are stored [b][row_stride] with element (sq, ch) at sq*ch_stride + ch when
+// conv_head (NHWC conv output) or simply [b][p] for the FC head; the probabilities are written in the
+// reference's order p = ch·N² + sq.
+__global__ __launch_bounds__(256) void k_softmax(const float* __restrict__ logits, int row_stride, int conv_head, int nsq,
+                                                 int ch_stride, int P, float* __restrict__ policy) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* x = logits + (size_t)b * row_stride;
+    auto at = [&](int p) -> float {
+        if (!conv_head) return x[p];
+        int ch = p / nsq, sq = p - ch * nsq;
+        return x[sq * ch_stride + ch];
+    };
+    float mx = -INFINITY;
+    for (int p = tid; p < P; p += 256) mx = fmaxf(mx, at(p));
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.0f;
+    for (int p = tid; p < P; p += 256) s += expf(at(p) - mx);
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    float inv = 1.0f / s;
+    float* o = policy + (size_t)b * P;
+    for (int p = tid; p < P; p += 256) o[p] = expf(at(p) - mx) * inv;
+}
+
+// NCHW planes (the reference tensor layout) → NHWC rows padded to Cpad channels
+__global__ void k_nchw_to_nhwc(const float* __restrict__ src, int B, int C, int nsq, int Cpad, float* __restrict__ dst) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)B * nsq * Cpad;
+    if (idx >= total) return;
+    int c = (int)(idx % Cpad);
+    size_t r = idx / Cpad;
+    int sq = (int)(r % nsq);
+    size_t b = r / nsq;
+    dst[idx] = c < C ? src[(b * C + c) * nsq + sq] : 0.0f;
+}
+
+// ---- launchers --------------------------------------------------------------------------------
+size_t conv_lds_bytes(int rt, int n, int Cpad) {
+    int TM = 64 * rt, nsq = n * n;
+    int max_pos = (TM - 1) / nsq + 2;
+    return (size_t)(max_pos * nsq + 1) * (Cpad + LDS_PAD) * sizeof(float);
+}
+
+template <int RT, int CT>
+static hipError_t launch_conv_t(hipStream_t st, const float* in, const float* Wp, const float* bias, const float* res,
+                                float* out, int M, int n, int Cpad, int CoutP, int out_stride, int cout_valid, bool relu) {
+    size_t lds = conv_lds_bytes(RT, n, Cpad);
+    static size_t configured = 0;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_conv3x3<RT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    dim3 grid((M + 64 * RT - 1) / (64 * RT), CoutP / (64 * CT));
+    hipLaunchKernelGGL((k_conv3x3<RT, CT>), grid, dim3(256), lds, st, in, Wp, bias, res, out, M, n, Cpad, CoutP, out_stride,
+                       cout_valid, relu ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv3x3(hipStream_t st, const float* in, const float* Wp, const float* bias, const float* res, float* out,
+                          int M, int n, int Cpad, int CoutP, int out_stride, int cout_valid, bool relu) {
+    if (CoutP % 128 == 0) return launch_conv_t<2, 2>(st, in, Wp, bias, res, out, M, n, Cpad, CoutP, out_stride, cout_valid, relu);
+    return launch_conv_t<2, 1>(st, in, Wp, bias, res, out, M, n, Cpad, CoutP, out_stride, cout_valid, relu);
+}
+
+hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp, const float* bias, float* out, int M, int K,
+                       int NP, int out_stride, int n_valid) {
+    dim3 grid((M + 127) / 128, NP / 64);
+    hipLaunchKernelGGL((k_gemm<2, 1>), grid, dim3(256), 0, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid);
+    return hipGetLastError();
+}
+
+hipError_t launch_value_head(hipStream_t st, const float* act, const float* wv, float bv, int B, int len, float* eval) {
+    hipLaunchKernelGGL(k_value_head, dim3((B + 3) / 4), dim3(256), 0, st, act, wv, bv, B, len, eval);
+    return hipGetLastError();
+}
+
+hipError_t launch_softmax(hipStream_t st, const float* logits, int row_stride, bool conv_head, int nsq, int ch_stride, int P,
+                          int B, float* policy) {
+    hipLaunchKernelGGL(k_softmax, dim3(B), dim3(256), 0, st, logits, row_stride, conv_head ? 1 : 0, nsq, ch_stride, P, policy);
+    return hipGetLastError();
+}
+
+hipError_t launch_nchw_to_nhwc(hipStream_t st, const float* src, int B, int C, int nsq, int Cpad, float* dst) {
+    size_t total = (size_t)B * nsq * Cpad;
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, B, C, nsq, Cpad, dst);
+    return hipGetLastError();
+}
+
+}  // namespace tg

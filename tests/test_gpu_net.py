@@ -1,0 +1,82 @@
+"""GPU parity of the network forward (through the C ABI) against PyTorch-CPU fp32 (the same ATen ops
+tch-rs calls).  Tolerance from BASELINE.json's north_star: |Δ| ≤ 1e-4 on policy and eval, fp32."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import torch_ref
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "net*.npz")))
+
+
+def _engine(n, blocks, filters, head, max_batch=256):
+    import tak_amd
+
+    return tak_amd.Engine(n, res_blocks=blocks, filters=filters, policy_head=tak_amd.HEAD_FC5 if head == "fc5" else tak_amd.HEAD_CONV,
+                          evaluator=tak_amd.EVAL_RESNET, max_batch=max_batch)
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_golden_fixture(path, orc):
+    z = np.load(path)
+    n, blocks, filters, head_i, seed = [int(v) for v in z["meta"]]
+    head = "fc5" if head_i == 0 else "conv"
+    net = torch_ref.make_net(n, blocks, filters, head, seed=seed)
+    # the regenerated weights reproduce the committed outputs on CPU (same PyTorch build)
+    p_cpu, v_cpu = torch_ref.forward(net, orc.encode(n, z["states"]))
+    assert np.abs(p_cpu - z["policy"]).max() < 1e-6 and np.abs(v_cpu - z["eval"]).max() < 1e-6
+    e = _engine(n, blocks, filters, head)
+    e.load_state_dict(torch_ref.abi_tensors(net))
+    p, v = e.policy_eval(z["states"])
+    assert np.abs(p - z["policy"]).max() <= TOL
+    assert np.abs(v - z["eval"]).max() <= TOL
+    assert np.abs(p.sum(1) - 1).max() < 1e-5
+    # forward_mcts on caller-encoded planes gives the same numbers
+    p2, v2 = e.forward_mcts(orc.encode(n, z["states"]))
+    assert np.array_equal(p, p2) and np.array_equal(v, v2)
+    e.close()
+
+
+@pytest.mark.parametrize("n,blocks,filters,head,batch", [
+    (5, 6, 64, "fc5", 300),     # BASELINE config C2 topology
+    (6, 10, 128, "conv", 130),  # config C3 topology
+    (5, 10, 128, "fc5", 77),    # config C5 topology
+    (5, 2, 64, "conv", 64),     # conv head on 5x5
+    (3, 1, 32, "conv", 50),     # DummyNet-sized board (search/tests.rs)
+])
+def test_config_topologies_vs_torch(orc, n, blocks, filters, head, batch):
+    net = torch_ref.make_net(n, blocks, filters, head, seed=n * 100 + blocks)
+    sts = orc.random_positions(n, batch, seed=5, max_plies=80 if n >= 5 else 12, half_komi=4)
+    p_ref, v_ref = torch_ref.forward(net, orc.encode(n, sts))
+    e = _engine(n, blocks, filters, head, max_batch=128)  # forces chunking for batch > 128
+    e.load_state_dict(torch_ref.abi_tensors(net))
+    p, v = e.policy_eval(sts)
+    assert np.abs(p - p_ref).max() <= TOL, np.abs(p - p_ref).max()
+    assert np.abs(v - v_ref).max() <= TOL, np.abs(v - v_ref).max()
+    # relative check on the policy too (probabilities are ~1e-3, so 1e-4 absolute alone is lax)
+    assert (np.abs(p - p_ref) / p_ref).max() < 5e-4
+    # per-position results do not depend on the batch they are evaluated in
+    p1, v1 = e.policy_eval(sts[3:4])
+    assert np.array_equal(p1[0], p[3]) and v1[0] == v[3]
+    e.close()
+
+
+def test_weight_errors():
+    import tak_amd
+
+    e = _engine(5, 1, 32, "fc5")
+    with pytest.raises(tak_amd.TgError) as ei:
+        e.policy_eval(np.zeros((1, 256), np.uint8))
+    assert ei.value.code == -7  # not finalized
+    net = torch_ref.make_net(5, 1, 32, "fc5")
+    t = torch_ref.abi_tensors(net)
+    del t["res0.bn2.running_var"]
+    with pytest.raises(tak_amd.TgError) as ei:
+        e.load_state_dict(t)
+    assert ei.value.code == -4 and "res0.bn2.running_var" in str(ei.value)
+    assert e.policy_eval(np.zeros((0, 256), np.uint8))[0].shape == (0, 1575)  # empty batch is fine (net5.rs:121)
+    e.close()

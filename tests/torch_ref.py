@@ -1,0 +1,90 @@
+"""Plain PyTorch fp32 statement of the reference's networks (alpha-tak/src/model/{net5,net6,res_block}.rs),
+used as the arithmetic oracle for the HIP network kernels: libtorch's conv2d / batch_norm(eval) / relu /
+linear / softmax / tanh are the same ATen ops tch-rs calls.  Test infrastructure only."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def input_channels(n):
+    stones, caps = {3: (10, 0), 4: (15, 0), 5: (21, 1), 6: (30, 1)}[n]
+    return (n + 2 + 6) * 2 + 2 + 2 * stones + 2 * caps
+
+
+class ResBlock(nn.Module):  # res_block.rs:13-24
+    def __init__(self, f):
+        super().__init__()
+        self.conv1 = nn.Conv2d(f, f, 3, padding=1)
+        self.conv2 = nn.Conv2d(f, f, 3, padding=1)
+        self.bn1 = nn.BatchNorm2d(f)
+        self.bn2 = nn.BatchNorm2d(f)
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        return F.relu(y + x)
+
+
+class TakNet(nn.Module):
+    """head 'fc5' = Net5 (net5.rs:19-131), head 'conv' = Net6 (net6.rs:19-139); blocks/filters runtime."""
+
+    def __init__(self, n, res_blocks, filters, head):
+        super().__init__()
+        self.n, self.head, self.f = n, head, filters
+        self.conv0 = nn.Conv2d(input_channels(n), filters, 3, padding=1)
+        self.bn0 = nn.BatchNorm2d(filters)
+        self.res = nn.ModuleList([ResBlock(filters) for _ in range(res_blocks)])
+        if head == "fc5":
+            assert n == 5
+            self.policy = nn.Linear(filters * 25, 1575)
+        else:
+            self.policy = nn.Conv2d(filters, 3 + 4 * (2 ** n - 2), 3, padding=1)
+        self.value = nn.Linear(filters * n * n, 1)
+
+    def forward(self, x):  # forward_mcts (eval mode BN)
+        s = F.relu(self.bn0(self.conv0(x)))
+        for blk in self.res:
+            s = blk(s)
+        if self.head == "fc5":
+            p = self.policy(s.reshape(s.shape[0], -1))
+        else:
+            p = self.policy(s).reshape(s.shape[0], -1)
+        p = torch.softmax(p, dim=1)
+        v = torch.tanh(self.value(s.reshape(s.shape[0], -1)))
+        return p, v[:, 0]
+
+
+def make_net(n, res_blocks, filters, head, seed=0, randomize_bn=True):
+    torch.manual_seed(seed)
+    net = TakNet(n, res_blocks, filters, head)
+    if randomize_bn:  # exercise the BN fold: non-trivial affine + running statistics
+        g = torch.Generator().manual_seed(seed + 1)
+        for m in net.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.weight.data = torch.rand(m.num_features, generator=g) * 1.0 + 0.5
+                m.bias.data = torch.randn(m.num_features, generator=g) * 0.1
+                m.running_mean = torch.randn(m.num_features, generator=g) * 0.1
+                m.running_var = torch.rand(m.num_features, generator=g) * 1.0 + 0.5
+    return net.eval()
+
+
+def abi_tensors(net):
+    """state_dict → {ABI tensor name: float32 array} (names of include/takgpu.h)."""
+    out = {}
+    for k, v in net.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        parts = k.split(".")
+        if parts[0] == "res":
+            name = f"res{parts[1]}." + ".".join(parts[2:])
+        else:
+            name = k
+        out[name] = v.detach().cpu().numpy().astype(np.float32)
+    return out
+
+
+@torch.no_grad()
+def forward(net, planes):
+    p, v = net(torch.from_numpy(np.ascontiguousarray(planes, np.float32)))
+    return p.numpy(), v.numpy()

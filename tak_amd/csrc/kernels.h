@@ -26,4 +26,22 @@ hipError_t launch_softmax(hipStream_t st, const float* logits, int row_stride, b
                           int B, float* policy);
 hipError_t launch_nchw_to_nhwc(hipStream_t st, const float* src, int B, int C, int nsq, int Cpad, float* dst);
 
+// search_kernels.hip
+struct SearchDev;
+struct SelfPlayDev;
+void launch_select(hipStream_t st, const SearchDev& S, const uint8_t* active);
+void launch_backup(hipStream_t st, const SearchDev& S);
+void launch_dirichlet(hipStream_t st, const SearchDev& S, const uint8_t* active, float alpha, float ratio);
+void launch_apply_noise(hipStream_t st, const SearchDev& S, const uint8_t* active, const float* noise, float ratio);
+void launch_reroot(hipStream_t st, const SearchDev& S, const int32_t* op);
+void launch_root_stats(hipStream_t st, const SearchDev& S, uint16_t* moves, uint32_t* visits, float* prior, float* q, int32_t* counts,
+                       uint32_t* root_visits, float* root_q);
+void launch_play_move(hipStream_t st, const SearchDev& S, const uint16_t* moves, const uint8_t* active, int32_t* op);
+void launch_sp_opening(hipStream_t st, const SearchDev& S);
+void launch_sp_instant_win(hipStream_t st, const SearchDev& S, const SelfPlayDev& P);
+void launch_sp_finish(hipStream_t st, const SearchDev& S, const SelfPlayDev& P, int32_t* op);
+void launch_sp_noise_mask(hipStream_t st, const SearchDev& S, const SelfPlayDev& P);
+void launch_sp_pick(hipStream_t st, const SearchDev& S, const SelfPlayDev& P, int32_t* op);
+void launch_sp_count_ply(hipStream_t st, const SelfPlayDev& P);
+
 }  // namespace tg

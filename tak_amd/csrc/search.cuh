@@ -1,0 +1,105 @@
+// search.cuh — device-resident MCTS data layout shared by search_kernels.hip and search.hip.
+//
+// Replaces the heap tree of reference alpha-tak/src/search/node.rs:3-39 (Node { policy,
+// expected_reward, result, visits, virtual_visits, children: Box<[(Move, Node)]> }).
+// One arena pair per game; a node is two records so that PUCT selection streams only the hot one:
+//   NodeHot  (16 B)  prior, q (= expected_reward), visits, virtual visits   — read per child per level
+//   NodeCold ( 8 B)  first-child index, move code, n_children | result<<12   — read for the chosen child
+// The children of a node are contiguous (same order as Game::possible_moves), so a wave scanning them
+// issues fully coalesced 16-byte-per-lane loads.  Node 0 of the active arena is the root; on a move the
+// chosen child's subtree is compacted breadth-first into the game's other arena (tree reuse,
+// search/play.rs:26-43) so memory stays bounded without a free list.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tg {
+
+struct NodeHot {
+    float prior, q;
+    uint32_t visits, virt;
+};
+struct NodeCold {
+    uint32_t child;   // index of the first child in the same arena (0 = no children)
+    uint16_t mv;      // move that leads here (TgMove)
+    uint16_t nres;    // n_children (12 bits) | TgResult << 12
+};
+static_assert(sizeof(NodeHot) == 16 && sizeof(NodeCold) == 8, "node records");
+
+constexpr int MAX_DEPTH = 256;       // longest selection path kept per game
+constexpr int EX_MOVES = 512;        // = TG_MAX_MOVES
+
+enum : uint32_t {
+    ERRF_ARENA = 1u,     // node arena full
+    ERRF_NAN = 2u,       // NaN upper confidence bound (reference panics, mcts.rs:110)
+    ERRF_DEPTH = 4u,     // selection path longer than MAX_DEPTH
+    ERRF_CTAB = 8u,      // visit count beyond the exploration-rate table
+    ERRF_MOVE = 16u,     // move not among the root's children / unmapped policy index
+    ERRF_EXAMPLES = 32u, // a game produced more examples than its staging area holds
+    ERRF_QUEUE = 64u,    // re-root queue overflow
+    ERRF_PICK = 128u     // WeightedIndex over all-zero visits (reference panics, play.rs:62)
+};
+
+// one training example as staged / emitted on the device
+struct ExampleRec {
+    int32_t slot;        // global slot id
+    int32_t generation;  // index of the game played in that slot
+    int32_t n_moves;
+    float result;
+};
+
+struct SearchDev {
+    // trees
+    NodeHot* hot;        // [G][2][cap]
+    NodeCold* cold;      // [G][2][cap]
+    uint8_t* sel;        // [G] active arena
+    uint32_t* alloc;     // [G] next free node in the active arena
+    // games
+    uint8_t* root_state; // [G][state bytes]
+    uint8_t* alive;      // [G]
+    uint32_t* generation;// [G]
+    // per-iteration leaf hand-off
+    int32_t* path_len;   // [G]
+    uint32_t* path;      // [G][MAX_DEPTH]
+    uint8_t* leaf_kind;  // [G] 0 skipped, 1 needs evaluation, 2 terminal (already backed up)
+    uint64_t* leaf_hash; // [G] (TG_EVAL_HASH)
+    float* planes;       // [G][nsq][cin_pad] NHWC network input
+    float* policy;       // [G][P]
+    float* eval;         // [G]
+    // constants
+    const float* ctab;   // exploration_rate(n) for integer n (host logf, mcts.rs:10-12)
+    const int16_t* lut5;
+    uint32_t* err;       // error flag word
+    unsigned long long* counters;  // [0] expansions [1] evals
+    int G, cap, n, cin_pad, P, ctab_size, legacy5, evaluator;
+    uint32_t slot_base;
+    uint64_t seed;
+};
+
+struct SelfPlayDev {
+    // staging of the current game's examples per slot
+    ExampleRec* st_hdr;   // [G][ex_per_game]
+    uint8_t* st_state;    // [G][ex_per_game][bytes]
+    uint16_t* st_moves;   // [G][ex_per_game][EX_MOVES]
+    uint32_t* st_visits;  // [G][ex_per_game][EX_MOVES]
+    int32_t* st_count;    // [G]
+    // output ring
+    ExampleRec* out_hdr;  // [max_examples]
+    uint8_t* out_state;
+    uint16_t* out_moves;
+    uint32_t* out_visits;
+    // phase hand-off
+    uint8_t* fin;         // [G] TgResult of a game that just ended (0 = still running)
+    uint8_t* recycle;     // [G]
+    uint32_t* out_off;    // [G] first ring slot for this game's examples
+    int32_t* chosen;      // [G] child ordinal picked this ply (-1 none)
+    uint8_t* mask;        // [G] scratch mask (noise phase)
+    unsigned long long* stats;  // games_finished, examples, plies, white, black, draws, instant_wins
+    int ex_per_game, max_examples;
+    int rollouts, noise_plies, exploit_plies, komi, total_games;
+    float noise_alpha, noise_ratio;
+};
+
+enum { ST_FINISHED = 0, ST_EXAMPLES = 1, ST_PLIES = 2, ST_WHITE = 3, ST_BLACK = 4, ST_DRAWS = 5, ST_INSTANT = 6, ST_COUNT = 8 };
+
+}  // namespace tg

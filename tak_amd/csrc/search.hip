@@ -1,21 +1,497 @@
-// search.hip — placeholder, replaced by the real MCTS kernels
+// search.hip — host side of the search / self-play entry points of include/takgpu.h: device
+// allocation, the per-iteration schedule (select → network → backup, no host synchronisation inside a
+// call), the per-ply schedule of self_play_parallel, result read-back and the tree dump.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
 #include "engine.h"
-namespace tg { struct Search {}; void search_destroy(Search* s) { delete s; } }
-using namespace tg;
-#define NOTYET return fail(TG_ERR_STATE, "search not built yet")
-extern "C" {
-int tg_search_create(TgEngine*, const TgSearchConfig*) { NOTYET; }
-int tg_search_reset(TgEngine*, const void*) { NOTYET; }
-int tg_search_run(TgEngine*, int, const uint8_t*) { NOTYET; }
-int tg_search_apply_dirichlet(TgEngine*, float, float, const uint8_t*) { NOTYET; }
-int tg_search_apply_noise(TgEngine*, const float*, float, const uint8_t*) { NOTYET; }
-int tg_search_root(TgEngine*, TgMove*, uint32_t*, float*, float*, int32_t*, uint32_t*, float*) { NOTYET; }
-int tg_search_play(TgEngine*, const TgMove*, const uint8_t*) { NOTYET; }
-int tg_search_states(TgEngine*, void*) { NOTYET; }
-int tg_search_dump(TgEngine*, int, TgNodeRecord*, size_t, size_t*) { NOTYET; }
-int tg_search_counters(TgEngine*, uint64_t*, uint64_t*) { NOTYET; }
-int tg_selfplay_create(TgEngine*, const TgSearchConfig*, const TgSelfPlayConfig*) { NOTYET; }
-int tg_selfplay_step(TgEngine*, int) { NOTYET; }
-int tg_selfplay_stats(TgEngine*, TgSelfPlayStats*) { NOTYET; }
-int tg_selfplay_drain(TgEngine*, int, TgExampleHeader*, void*, TgMove*, uint32_t*, int32_t*) { NOTYET; }
+#include "kernels.h"
+#include "search.cuh"
+
+namespace tg {
+
+struct Search {
+    TgSearchConfig cfg;
+    SearchDev d;
+    DevBuf hot, cold, sel, alloc, root_state, alive, generation, path_len, path, leaf_kind, leaf_hash, planes, policy, eval,
+        ctab, err, counters, op, active, noise;
+    DevBuf r_moves, r_visits, r_prior, r_q, r_counts, r_rv, r_rq, s_moves;
+    // self-play
+    bool selfplay = false;
+    TgSelfPlayConfig spcfg;
+    SelfPlayDev p;
+    DevBuf st_hdr, st_state, st_moves, st_visits, st_count, out_hdr, out_state, out_moves, out_visits, fin, recycle, out_off, chosen,
+        mask, stats;
+    unsigned long long drained = 0;
+};
+
+void search_destroy(Search* s) { delete s; }
+
+static int describe_errors(uint32_t bits) {
+    std::string msg;
+    int code = TG_ERR_STATE;
+    auto add = [&](uint32_t b, const char* m, int c) {
+        if (bits & b) { if (!msg.empty()) msg += "; "; msg += m; code = c; }
+    };
+    add(ERRF_DEPTH, "selection path deeper than MAX_DEPTH", TG_ERR_ARENA_OVERFLOW);
+    add(ERRF_CTAB, "visit count beyond the exploration table", TG_ERR_ARENA_OVERFLOW);
+    add(ERRF_EXAMPLES, "a game produced more examples than its staging area holds", TG_ERR_ARENA_OVERFLOW);
+    add(ERRF_QUEUE, "re-root queue overflow", TG_ERR_ARENA_OVERFLOW);
+    add(ERRF_PICK, "pick_move on a root without visits", TG_ERR_STATE);
+    add(ERRF_MOVE, "move is not a child of the root / has no policy index", TG_ERR_ILLEGAL_MOVE);
+    add(ERRF_NAN, "NaN upper confidence bound (reference: \"tried comparing nan\")", TG_ERR_NAN);
+    add(ERRF_ARENA, "MCTS node arena full (raise TgSearchConfig.arena_nodes)", TG_ERR_ARENA_OVERFLOW);
+    return fail(code, msg);
 }
+
+int search_poll_errors(TgEngine* e) {
+    if (!e || !e->search) return TG_OK;
+    uint32_t bits = 0;
+    TG_HIP(hipMemcpy(&bits, e->search->err.p, 4, hipMemcpyDeviceToHost));
+    if (!bits) return TG_OK;
+    return describe_errors(bits);
+}
+
+static int need_search(TgEngine* e) {
+    if (!e) return fail(TG_ERR_INVALID_ARG, "null engine");
+    if (!e->search) return fail(TG_ERR_STATE, "tg_search_create / tg_selfplay_create has not been called");
+    TG_HIP(hipSetDevice(e->cfg.device));
+    return TG_OK;
+}
+
+static int upload_mask(TgEngine* e, const uint8_t* active, const uint8_t** d_out) {
+    *d_out = nullptr;
+    if (!active) return TG_OK;
+    Search* s = e->search;
+    TG_HIP(hipMemcpyAsync(s->active.p, active, (size_t)s->d.G, hipMemcpyHostToDevice, e->stream));
+    *d_out = s->active.as<uint8_t>();
+    return TG_OK;
+}
+
+static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
+    if (!e) return fail(TG_ERR_INVALID_ARG, "null engine");
+    if (!cfg || cfg->games <= 0 || cfg->games > e->cfg.max_batch) return fail(TG_ERR_INVALID_ARG, "games must be in 1..max_batch");
+    if (cfg->arena_nodes < 1024) return fail(TG_ERR_INVALID_ARG, "arena_nodes must be at least 1024");
+    if (e->cfg.evaluator == TG_EVAL_RESNET && !net_ready(e)) return fail(TG_ERR_STATE, "network weights not finalized (tg_net_finalize)");
+    TG_HIP(hipSetDevice(e->cfg.device));
+    if (e->search) {
+        TG_HIP(hipStreamSynchronize(e->stream));
+        search_destroy(e->search);
+        e->search = nullptr;
+    }
+    std::unique_ptr<Search> sp(new Search());
+    Search* s = sp.get();
+    s->cfg = *cfg;
+    const size_t G = (size_t)cfg->games, cap = (size_t)cfg->arena_nodes;
+    const int cin_pad = (e->cin + 7) / 8 * 8;
+    TG_HIP(s->hot.ensure(G * 2 * cap * sizeof(NodeHot)));
+    TG_HIP(s->cold.ensure(G * 2 * cap * sizeof(NodeCold)));
+    TG_HIP(s->sel.ensure(G));
+    TG_HIP(s->alloc.ensure(G * 4));
+    TG_HIP(s->root_state.ensure(G * e->g.bytes));
+    TG_HIP(s->alive.ensure(G));
+    TG_HIP(s->generation.ensure(G * 4));
+    TG_HIP(s->path_len.ensure(G * 4));
+    TG_HIP(s->path.ensure(G * MAX_DEPTH * 4));
+    TG_HIP(s->leaf_kind.ensure(G));
+    TG_HIP(s->leaf_hash.ensure(G * 8));
+    TG_HIP(s->op.ensure(G * 4));
+    TG_HIP(s->active.ensure(G));
+    TG_HIP(s->noise.ensure(G * EX_MOVES * 4));
+    TG_HIP(s->err.ensure(4));
+    TG_HIP(s->counters.ensure(16));
+    TG_HIP(s->r_moves.ensure(G * EX_MOVES * 2));
+    TG_HIP(s->r_visits.ensure(G * EX_MOVES * 4));
+    TG_HIP(s->r_prior.ensure(G * EX_MOVES * 4));
+    TG_HIP(s->r_q.ensure(G * EX_MOVES * 4));
+    TG_HIP(s->r_counts.ensure(G * 4));
+    TG_HIP(s->r_rv.ensure(G * 4));
+    TG_HIP(s->r_rq.ensure(G * 4));
+    TG_HIP(s->s_moves.ensure(G * 2));
+    if (e->cfg.evaluator == TG_EVAL_RESNET) {
+        TG_HIP(s->planes.ensure(G * e->g.nsq * cin_pad * 4));
+        TG_HIP(s->policy.ensure(G * (size_t)e->policy_size * 4));
+        TG_HIP(s->eval.ensure(G * 4));
+        TG_HIP(hipMemset(s->planes.p, 0, s->planes.bytes));
+    }
+    // exploration_rate(n) = ln((1 + n + base) / base) + init for integer visit counts (mcts.rs:10-12),
+    // evaluated once on the host in f32 so that every GPU and the CPU agree on the last bit
+    const int ctab_size = 1 << 20;
+    std::vector<float> ctab(ctab_size);
+    for (int i = 0; i < ctab_size; i++) {
+        float nf = (float)i;
+        ctab[i] = logf((1.0f + nf + cfg->exploration_base) / cfg->exploration_base) + cfg->exploration_init;
+    }
+    TG_HIP(s->ctab.ensure((size_t)ctab_size * 4));
+    TG_HIP(hipMemcpy(s->ctab.p, ctab.data(), (size_t)ctab_size * 4, hipMemcpyHostToDevice));
+    TG_HIP(hipMemset(s->err.p, 0, 4));
+    TG_HIP(hipMemset(s->counters.p, 0, 16));
+    TG_HIP(hipMemset(s->generation.p, 0, G * 4));
+    TG_HIP(hipMemset(s->alive.p, 0, G));
+    SearchDev& d = s->d;
+    d.hot = s->hot.as<NodeHot>(); d.cold = s->cold.as<NodeCold>(); d.sel = s->sel.as<uint8_t>(); d.alloc = s->alloc.as<uint32_t>();
+    d.root_state = s->root_state.as<uint8_t>(); d.alive = s->alive.as<uint8_t>(); d.generation = s->generation.as<uint32_t>();
+    d.path_len = s->path_len.as<int32_t>(); d.path = s->path.as<uint32_t>(); d.leaf_kind = s->leaf_kind.as<uint8_t>();
+    d.leaf_hash = s->leaf_hash.as<uint64_t>(); d.planes = s->planes.as<float>(); d.policy = s->policy.as<float>();
+    d.eval = s->eval.as<float>(); d.ctab = s->ctab.as<float>(); d.lut5 = e->lut5.as<int16_t>(); d.err = s->err.as<uint32_t>();
+    d.counters = s->counters.as<unsigned long long>();
+    d.G = cfg->games; d.cap = cfg->arena_nodes; d.n = e->g.n; d.cin_pad = cin_pad; d.P = e->policy_size; d.ctab_size = ctab_size;
+    d.legacy5 = e->legacy5 ? 1 : 0; d.evaluator = e->cfg.evaluator; d.slot_base = 0; d.seed = cfg->seed;
+    e->search = sp.release();
+    return TG_OK;
+}
+
+// every tree = Node::default(), every game alive with the given root state
+static int search_reset_trees(TgEngine* e) {
+    Search* s = e->search;
+    const size_t G = (size_t)s->d.G;
+    std::vector<int32_t> op(G, -2);
+    TG_HIP(hipMemsetAsync(s->sel.p, 0, G, e->stream));
+    TG_HIP(hipMemcpyAsync(s->op.p, op.data(), G * 4, hipMemcpyHostToDevice, e->stream));
+    launch_reroot(e->stream, s->d, s->op.as<int32_t>());
+    TG_HIP(hipGetLastError());
+    TG_HIP(hipStreamSynchronize(e->stream));
+    return TG_OK;
+}
+
+// one lock-step iteration: the body of train/src/self_play.rs:181-210
+static int search_iterate(TgEngine* e, const uint8_t* d_active) {
+    Search* s = e->search;
+    launch_select(e->stream, s->d, d_active);
+    TG_HIP(hipGetLastError());
+    if (e->cfg.evaluator == TG_EVAL_RESNET) {
+        int rc = net_forward_dev(e, s->d.G, s->d.planes, s->d.policy, s->d.eval);
+        if (rc) return rc;
+    }
+    launch_backup(e->stream, s->d);
+    TG_HIP(hipGetLastError());
+    return TG_OK;
+}
+
+static int sync_and_check(TgEngine* e) {
+    TG_HIP(hipStreamSynchronize(e->stream));
+    return search_poll_errors(e);
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+extern "C" {
+
+int tg_search_create(TgEngine* e, const TgSearchConfig* cfg) {
+    int rc = search_alloc(e, cfg);
+    if (rc) return rc;
+    return TG_OK;
+}
+
+int tg_search_reset(TgEngine* e, const void* states) {
+    int rc = need_search(e);
+    if (rc) return rc;
+    if (!states) return fail(TG_ERR_INVALID_ARG, "tg_search_reset: null states");
+    Search* s = e->search;
+    const size_t G = (size_t)s->d.G;
+    TG_HIP(hipMemcpyAsync(s->root_state.p, states, G * e->g.bytes, hipMemcpyHostToDevice, e->stream));
+    TG_HIP(hipMemsetAsync(s->alive.p, 1, G, e->stream));
+    TG_HIP(hipMemsetAsync(s->err.p, 0, 4, e->stream));
+    return search_reset_trees(e);
+}
+
+int tg_search_run(TgEngine* e, int iters, const uint8_t* active) {
+    int rc = need_search(e);
+    if (rc) return rc;
+    if (iters < 0) return fail(TG_ERR_INVALID_ARG, "tg_search_run: negative iters");
+    const uint8_t* d_active;
+    rc = upload_mask(e, active, &d_active);
+    if (rc) return rc;
+    for (int i = 0; i < iters; i++) {
+        rc = search_iterate(e, d_active);
+        if (rc) return rc;
+    }
+    if (active) TG_HIP(hipStreamSynchronize(e->stream));  // the staged mask must outlive the launches
+    return TG_OK;
+}
+
+int tg_search_apply_dirichlet(TgEngine* e, float alpha, float ratio, const uint8_t* active) {
+    int rc = need_search(e);
+    if (rc) return rc;
+    const uint8_t* d_active;
+    rc = upload_mask(e, active, &d_active);
+    if (rc) return rc;
+    launch_dirichlet(e->stream, e->search->d, d_active, alpha, ratio);
+    TG_HIP(hipGetLastError());
+    return sync_and_check(e);
+}
+
+int tg_search_apply_noise(TgEngine* e, const float* noise, float ratio, const uint8_t* active) {
+    int rc = need_search(e);
+    if (rc) return rc;
+    if (!noise) return fail(TG_ERR_INVALID_ARG, "tg_search_apply_noise: null noise");
+    Search* s = e->search;
+    const uint8_t* d_active;
+    rc = upload_mask(e, active, &d_active);
+    if (rc) return rc;
+    TG_HIP(hipMemcpyAsync(s->noise.p, noise, (size_t)s->d.G * EX_MOVES * 4, hipMemcpyHostToDevice, e->stream));
+    launch_apply_noise(e->stream, s->d, d_active, s->noise.as<float>(), ratio);
+    TG_HIP(hipGetLastError());
+    return sync_and_check(e);
+}
+
+int tg_search_root(TgEngine* e, TgMove* moves, uint32_t* visits, float* prior, float* q, int32_t* counts, uint32_t* root_visits,
+                   float* root_q) {
+    int rc = need_search(e);
+    if (rc) return rc;
+    Search* s = e->search;
+    const size_t G = (size_t)s->d.G;
+    launch_root_stats(e->stream, s->d, s->r_moves.as<uint16_t>(), s->r_visits.as<uint32_t>(), s->r_prior.as<float>(), s->r_q.as<float>(),
+                      s->r_counts.as<int32_t>(), s->r_rv.as<uint32_t>(), s->r_rq.as<float>());
+    TG_HIP(hipGetLastError());
+    rc = sync_and_check(e);
+    if (rc) return rc;
+    if (moves) TG_HIP(hipMemcpy(moves, s->r_moves.p, G * EX_MOVES * 2, hipMemcpyDeviceToHost));
+    if (visits) TG_HIP(hipMemcpy(visits, s->r_visits.p, G * EX_MOVES * 4, hipMemcpyDeviceToHost));
+    if (prior) TG_HIP(hipMemcpy(prior, s->r_prior.p, G * EX_MOVES * 4, hipMemcpyDeviceToHost));
+    if (q) TG_HIP(hipMemcpy(q, s->r_q.p, G * EX_MOVES * 4, hipMemcpyDeviceToHost));
+    if (counts) TG_HIP(hipMemcpy(counts, s->r_counts.p, G * 4, hipMemcpyDeviceToHost));
+    if (root_visits) TG_HIP(hipMemcpy(root_visits, s->r_rv.p, G * 4, hipMemcpyDeviceToHost));
+    if (root_q) TG_HIP(hipMemcpy(root_q, s->r_rq.p, G * 4, hipMemcpyDeviceToHost));
+    return TG_OK;
+}
+
+int tg_search_play(TgEngine* e, const TgMove* moves, const uint8_t* active) {
+    int rc = need_search(e);
+    if (rc) return rc;
+    if (!moves) return fail(TG_ERR_INVALID_ARG, "tg_search_play: null moves");
+    Search* s = e->search;
+    const uint8_t* d_active;
+    rc = upload_mask(e, active, &d_active);
+    if (rc) return rc;
+    TG_HIP(hipMemcpyAsync(s->s_moves.p, moves, (size_t)s->d.G * 2, hipMemcpyHostToDevice, e->stream));
+    launch_play_move(e->stream, s->d, s->s_moves.as<uint16_t>(), d_active, s->op.as<int32_t>());
+    launch_reroot(e->stream, s->d, s->op.as<int32_t>());
+    TG_HIP(hipGetLastError());
+    return sync_and_check(e);
+}
+
+int tg_search_states(TgEngine* e, void* states) {
+    int rc = need_search(e);
+    if (rc) return rc;
+    if (!states) return fail(TG_ERR_INVALID_ARG, "tg_search_states: null states");
+    rc = sync_and_check(e);
+    if (rc) return rc;
+    TG_HIP(hipMemcpy(states, e->search->root_state.p, (size_t)e->search->d.G * e->g.bytes, hipMemcpyDeviceToHost));
+    return TG_OK;
+}
+
+int tg_search_dump(TgEngine* e, int game, TgNodeRecord* records, size_t capacity, size_t* n_records) {
+    int rc = need_search(e);
+    if (rc) return rc;
+    Search* s = e->search;
+    if (game < 0 || game >= s->d.G || !n_records) return fail(TG_ERR_INVALID_ARG, "tg_search_dump: bad arguments");
+    rc = sync_and_check(e);
+    if (rc) return rc;
+    uint8_t sel = 0;
+    uint32_t alloc = 0;
+    TG_HIP(hipMemcpy(&sel, s->sel.as<uint8_t>() + game, 1, hipMemcpyDeviceToHost));
+    TG_HIP(hipMemcpy(&alloc, s->alloc.as<uint32_t>() + game, 4, hipMemcpyDeviceToHost));
+    const size_t base = ((size_t)game * 2 + sel) * (size_t)s->d.cap;
+    std::vector<NodeHot> hot(alloc);
+    std::vector<NodeCold> cold(alloc);
+    TG_HIP(hipMemcpy(hot.data(), s->hot.as<NodeHot>() + base, (size_t)alloc * sizeof(NodeHot), hipMemcpyDeviceToHost));
+    TG_HIP(hipMemcpy(cold.data(), s->cold.as<NodeCold>() + base, (size_t)alloc * sizeof(NodeCold), hipMemcpyDeviceToHost));
+    // depth-first in child order; uninitialised children become leaf records with n_children = 0xFFFF
+    std::vector<TgNodeRecord> out;
+    struct Frame { uint32_t node; uint32_t next; };
+    std::vector<Frame> stack;
+    auto emit = [&](uint32_t nd, bool is_root) {
+        TgNodeRecord r;
+        r.move = is_root ? 0 : cold[nd].mv;
+        r.n_children = (uint16_t)(cold[nd].nres & 0xfff);
+        r.visits = hot[nd].visits;
+        r.virtual_visits = hot[nd].virt;
+        r.result = cold[nd].nres >> 12;
+        std::memcpy(&r.prior_bits, &hot[nd].prior, 4);
+        std::memcpy(&r.q_bits, &hot[nd].q, 4);
+        out.push_back(r);
+    };
+    emit(0, true);
+    stack.push_back({0u, 0u});
+    while (!stack.empty()) {
+        Frame& f = stack.back();
+        uint32_t nch = cold[f.node].nres & 0xfff;
+        if (f.next >= nch) { stack.pop_back(); continue; }
+        uint32_t c = cold[f.node].child + f.next;
+        f.next++;
+        if (c >= alloc) return fail(TG_ERR_STATE, "tg_search_dump: corrupt tree (child index out of the arena)");
+        if (hot[c].visits != 0 || hot[c].virt != 0) {
+            emit(c, false);
+            stack.push_back({c, 0u});
+        } else {
+            TgNodeRecord r;
+            r.move = cold[c].mv;
+            r.n_children = 0xFFFF;
+            r.visits = 0; r.virtual_visits = 0; r.result = 0;
+            std::memcpy(&r.prior_bits, &hot[c].prior, 4);
+            std::memcpy(&r.q_bits, &hot[c].q, 4);
+            out.push_back(r);
+        }
+    }
+    *n_records = out.size();
+    if (out.size() > capacity || (!records && !out.empty())) return fail(TG_ERR_INVALID_ARG, "tg_search_dump: capacity too small");
+    std::memcpy(records, out.data(), out.size() * sizeof(TgNodeRecord));
+    return TG_OK;
+}
+
+int tg_search_counters(TgEngine* e, uint64_t* expansions, uint64_t* evals) {
+    int rc = need_search(e);
+    if (rc) return rc;
+    rc = sync_and_check(e);
+    if (rc) return rc;
+    unsigned long long c[2];
+    TG_HIP(hipMemcpy(c, e->search->counters.p, 16, hipMemcpyDeviceToHost));
+    if (expansions) *expansions = c[0];
+    if (evals) *evals = c[1];
+    return TG_OK;
+}
+
+// ---- self-play -----------------------------------------------------------------------------------
+
+int tg_selfplay_create(TgEngine* e, const TgSearchConfig* scfg, const TgSelfPlayConfig* cfg) {
+    if (!cfg) return fail(TG_ERR_INVALID_ARG, "null self-play config");
+    if (cfg->rollouts < 1 || cfg->max_examples < 1) return fail(TG_ERR_INVALID_ARG, "rollouts and max_examples must be positive");
+    int rc = search_alloc(e, scfg);
+    if (rc) return rc;
+    Search* s = e->search;
+    s->selfplay = true;
+    s->spcfg = *cfg;
+    const size_t G = (size_t)s->d.G, sb = (size_t)e->g.bytes;
+    const int epg = 512;
+    const size_t ME = (size_t)cfg->max_examples;
+    TG_HIP(s->st_hdr.ensure(G * epg * sizeof(ExampleRec)));
+    TG_HIP(s->st_state.ensure(G * epg * sb));
+    TG_HIP(s->st_moves.ensure(G * epg * EX_MOVES * 2));
+    TG_HIP(s->st_visits.ensure(G * epg * EX_MOVES * 4));
+    TG_HIP(s->st_count.ensure(G * 4));
+    TG_HIP(s->out_hdr.ensure(ME * sizeof(ExampleRec)));
+    TG_HIP(s->out_state.ensure(ME * sb));
+    TG_HIP(s->out_moves.ensure(ME * EX_MOVES * 2));
+    TG_HIP(s->out_visits.ensure(ME * EX_MOVES * 4));
+    TG_HIP(s->fin.ensure(G));
+    TG_HIP(s->recycle.ensure(G));
+    TG_HIP(s->out_off.ensure(G * 4));
+    TG_HIP(s->chosen.ensure(G * 4));
+    TG_HIP(s->mask.ensure(G));
+    TG_HIP(s->stats.ensure(ST_COUNT * 8));
+    TG_HIP(hipMemset(s->st_count.p, 0, G * 4));
+    TG_HIP(hipMemset(s->stats.p, 0, ST_COUNT * 8));
+    TG_HIP(hipMemset(s->fin.p, 0, G));
+    SelfPlayDev& p = s->p;
+    p.st_hdr = s->st_hdr.as<ExampleRec>(); p.st_state = s->st_state.as<uint8_t>(); p.st_moves = s->st_moves.as<uint16_t>();
+    p.st_visits = s->st_visits.as<uint32_t>(); p.st_count = s->st_count.as<int32_t>();
+    p.out_hdr = s->out_hdr.as<ExampleRec>(); p.out_state = s->out_state.as<uint8_t>(); p.out_moves = s->out_moves.as<uint16_t>();
+    p.out_visits = s->out_visits.as<uint32_t>();
+    p.fin = s->fin.as<uint8_t>(); p.recycle = s->recycle.as<uint8_t>(); p.out_off = s->out_off.as<uint32_t>();
+    p.chosen = s->chosen.as<int32_t>(); p.mask = s->mask.as<uint8_t>(); p.stats = s->stats.as<unsigned long long>();
+    p.ex_per_game = epg; p.max_examples = cfg->max_examples;
+    p.rollouts = cfg->rollouts; p.noise_plies = cfg->noise_plies; p.exploit_plies = cfg->exploit_plies; p.komi = cfg->komi;
+    p.total_games = cfg->total_games; p.noise_alpha = cfg->noise_alpha; p.noise_ratio = cfg->noise_ratio;
+    // games[i] = Game::with_komi(komi), nodes[i] = Node::default()  (self_play.rs:102-103)
+    std::vector<uint8_t> start(sb, 0);
+    {
+        int stones, caps;
+        starting_stones(e->g.n, stones, caps);
+        TgHeader* h = (TgHeader*)(start.data() + sb - sizeof(TgHeader));
+        h->n = (uint8_t)e->g.n; h->to_move = 0; h->ply = 0;
+        h->white_stones = h->black_stones = (uint8_t)stones;
+        h->white_caps = h->black_caps = (uint8_t)caps;
+        h->half_komi = (int8_t)(cfg->komi * 2); h->reversible_plies = 0;
+    }
+    std::vector<uint8_t> all(G * sb);
+    for (size_t g = 0; g < G; g++) std::memcpy(&all[g * sb], start.data(), sb);
+    TG_HIP(hipMemcpy(s->root_state.p, all.data(), all.size(), hipMemcpyHostToDevice));
+    TG_HIP(hipMemset(s->alive.p, 1, G));
+    return search_reset_trees(e);
+}
+
+int tg_selfplay_step(TgEngine* e, int plies) {
+    int rc = need_search(e);
+    if (rc) return rc;
+    Search* s = e->search;
+    if (!s->selfplay) return fail(TG_ERR_STATE, "tg_selfplay_create has not been called");
+    hipStream_t st = e->stream;
+    const size_t G = (size_t)s->d.G;
+    int32_t* op = s->op.as<int32_t>();
+    for (int ply = 0; ply < plies; ply++) {
+        launch_sp_opening(st, s->d);                                   // (a) :110-116
+        launch_sp_instant_win(st, s->d, s->p);                         // (b) :119-171
+        TG_HIP(hipMemsetAsync(op, 0xFF, G * 4, st));
+        launch_sp_finish(st, s->d, s->p, op);
+        launch_reroot(st, s->d, op);
+        launch_sp_noise_mask(st, s->d, s->p);                          // (c) :174-180
+        rc = search_iterate(e, s->p.mask);
+        if (rc) return rc;
+        launch_dirichlet(st, s->d, s->p.mask, s->p.noise_alpha, s->p.noise_ratio);
+        for (int r = 0; r < s->p.rollouts; r++) {                      // (d) :181-210
+            rc = search_iterate(e, nullptr);
+            if (rc) return rc;
+        }
+        launch_sp_pick(st, s->d, s->p, op);                            // (e) :212-258
+        launch_sp_finish(st, s->d, s->p, op);
+        launch_reroot(st, s->d, op);
+        launch_sp_count_ply(st, s->p);
+        TG_HIP(hipGetLastError());
+    }
+    return TG_OK;
+}
+
+int tg_selfplay_stats(TgEngine* e, TgSelfPlayStats* out) {
+    int rc = need_search(e);
+    if (rc) return rc;
+    Search* s = e->search;
+    if (!s->selfplay || !out) return fail(TG_ERR_STATE, "tg_selfplay_create has not been called");
+    rc = sync_and_check(e);
+    if (rc) return rc;
+    unsigned long long st[ST_COUNT], c[2];
+    TG_HIP(hipMemcpy(st, s->stats.p, sizeof st, hipMemcpyDeviceToHost));
+    TG_HIP(hipMemcpy(c, s->counters.p, 16, hipMemcpyDeviceToHost));
+    out->games_finished = st[ST_FINISHED]; out->examples = st[ST_EXAMPLES]; out->plies = st[ST_PLIES];
+    out->white_wins = st[ST_WHITE]; out->black_wins = st[ST_BLACK]; out->draws = st[ST_DRAWS]; out->instant_wins = st[ST_INSTANT];
+    out->expansions = c[0]; out->evals = c[1];
+    return TG_OK;
+}
+
+int tg_selfplay_drain(TgEngine* e, int cap, TgExampleHeader* headers, void* states, TgMove* moves, uint32_t* visits, int32_t* n_out) {
+    int rc = need_search(e);
+    if (rc) return rc;
+    Search* s = e->search;
+    if (!s->selfplay) return fail(TG_ERR_STATE, "tg_selfplay_create has not been called");
+    if (cap < 0 || !n_out || (cap > 0 && (!headers || !states || !moves || !visits))) return fail(TG_ERR_INVALID_ARG, "tg_selfplay_drain: bad arguments");
+    rc = sync_and_check(e);
+    if (rc) return rc;
+    unsigned long long total = 0;
+    TG_HIP(hipMemcpy(&total, s->stats.as<unsigned long long>() + ST_EXAMPLES, 8, hipMemcpyDeviceToHost));
+    const unsigned long long ME = (unsigned long long)s->p.max_examples;
+    if (total - s->drained > ME) s->drained = total - ME;  // older ones were overwritten in the ring
+    const size_t sb = (size_t)e->g.bytes;
+    int k = 0;
+    std::vector<ExampleRec> hdr(1);
+    for (; k < cap && s->drained < total; k++, s->drained++) {
+        size_t o = (size_t)(s->drained % ME);
+        TG_HIP(hipMemcpy(hdr.data(), s->out_hdr.as<ExampleRec>() + o, sizeof(ExampleRec), hipMemcpyDeviceToHost));
+        headers[k].game_id = hdr[0].slot | (hdr[0].generation << 20);
+        headers[k].n_moves = hdr[0].n_moves;
+        headers[k].result = hdr[0].result;
+        headers[k].reserved = 0;
+        TG_HIP(hipMemcpy((uint8_t*)states + (size_t)k * sb, s->out_state.as<uint8_t>() + o * sb, sb, hipMemcpyDeviceToHost));
+        size_t nm = (size_t)std::min(hdr[0].n_moves, (int32_t)EX_MOVES);
+        std::memset(moves + (size_t)k * EX_MOVES, 0, EX_MOVES * 2);
+        std::memset(visits + (size_t)k * EX_MOVES, 0, EX_MOVES * 4);
+        TG_HIP(hipMemcpy(moves + (size_t)k * EX_MOVES, s->out_moves.as<uint16_t>() + o * EX_MOVES, nm * 2, hipMemcpyDeviceToHost));
+        TG_HIP(hipMemcpy(visits + (size_t)k * EX_MOVES, s->out_visits.as<uint32_t>() + o * EX_MOVES, nm * 4, hipMemcpyDeviceToHost));
+    }
+    *n_out = k;
+    return TG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,717 @@
+// search_kernels.hip — GPU-resident MCTS (one wavefront per game) and the self-play driver kernels.
+//
+// Replaces reference alpha-tak/src/search/mcts.rs (virtual_rollout :26-65, select :94-118,
+// devirtualize_path :67-91, update_concrete :120-124), search/noise.rs, search/play.rs and the
+// per-ply phases of train/src/self_play.rs:108-259.  The float arithmetic of PUCT and of the value
+// backup is written in the reference's operation order and compiled with -ffp-contract=off, the
+// exploration rate comes from a host-computed table over the (integer) visit count, and both argmaxes
+// keep the LAST maximum like Iterator::max_by / max_by_key, so that search traces are reproducible bit
+// for bit against a scalar CPU statement of the same algorithm.
+#include "board.cuh"
+#include "kernels.h"
+#include "rng.cuh"
+#include "search.cuh"
+
+namespace tg {
+
+constexpr int WPB = 4;  // waves (games) per 256-thread block
+
+__device__ inline int game_of_wave() { return (int)(blockIdx.x * WPB + (threadIdx.x >> 6)); }
+__device__ inline void flag(const SearchDev& S, uint32_t bit) { atomicOr(S.err, bit); }
+__device__ inline void wave_sync_mem() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+
+__device__ inline uint64_t ws_hash(const WState& s, const Geom& g) {
+    // same function of the packed bytes as the CPU statement: stack words, meta bytes, 10 header bytes
+    uint64_t h = 0x243F6A8885A308D3ull;
+    for (int i = 0; i < g.nsq; i++) h = mix64(h ^ shfl64(s.stack, i)) + (uint64_t)i;
+    for (int i = 0; i < g.nsq; i++) {
+        uint32_t hh = (uint32_t)__shfl((int)s.height, i), tp = (uint32_t)__shfl((int)s.top, i);
+        uint64_t meta = hh | ((hh ? tp : 0u) << 6);
+        h = mix64(h ^ (meta << 8) ^ (uint64_t)(i + 1));
+    }
+    uint64_t a = (uint64_t)g.n | ((uint64_t)s.to_move << 8) | ((uint64_t)(s.ply & 0xffff) << 16) | ((uint64_t)s.ws << 32) |
+                 ((uint64_t)s.wc << 40) | ((uint64_t)s.bs << 48) | ((uint64_t)s.bc << 56);
+    uint64_t b = ((uint64_t)s.half_komi & 0xff) | ((uint64_t)(s.rev & 0xff) << 8);
+    h = mix64(h ^ a);
+    h = mix64(h ^ b);
+    return h;
+}
+
+// update_concrete, mcts.rs:120-124
+__device__ inline void update_concrete(NodeHot& h, float reward) {
+    float cumulative = h.q * (float)h.visits;
+    h.visits += 1;
+    h.q = (cumulative + reward) / (float)h.visits;
+}
+
+// ------------------------------------------------------------------------------------------------
+// virtual_rollout (+ select): descend, expand the first uninitialised node, mark the path with a
+// virtual visit (or back a concrete result up when the rollout ends on a terminal node), and leave
+// the leaf encoded in the network input batch.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __restrict__ active) {
+    __shared__ uint32_t path_lds[WPB][MAX_DEPTH];
+    const int g = game_of_wave();
+    if (g >= S.G) return;
+    const int lane = lane_id();
+    if (!S.alive[g] || (active && !active[g])) {
+        if (lane == 0) S.leaf_kind[g] = 0;
+        return;
+    }
+    const Geom geo = make_geom(S.n);
+    WState s;
+    ws_load(s, S.root_state + (size_t)g * geo.bytes, geo);
+    const size_t base = ((size_t)g * 2 + S.sel[g]) * (size_t)S.cap;
+    NodeHot* hot = S.hot + base;
+    NodeCold* cold = S.cold + base;
+    uint32_t* path = path_lds[threadIdx.x >> 6];
+    const uint32_t root_color = s.to_move;
+    uint32_t node = 0;
+    int depth = 0;
+    uint32_t res = TG_ONGOING;
+    bool terminal = false;
+
+    for (;;) {
+        NodeHot nh = hot[node];
+        uint32_t vis = uni(nh.visits), vv = uni(nh.virt);
+        if (vis == 0 && vv == 0) {
+            // uninitialised node: initialise it and stop (mcts.rs:41-53)
+            res = ws_result(s, geo);
+            uint32_t count = 0, cb = 0;
+            if (res == TG_ONGOING) {
+                uint32_t a = uni(S.alloc[g]);
+                int room = S.cap - (int)a;
+                NodeCold* blk = cold + a;
+                count = (uint32_t)ws_movegen(s, geo, room, [&](int idx, uint32_t code) {
+                    NodeCold c;
+                    c.child = 0; c.mv = (uint16_t)code; c.nres = 0;
+                    blk[idx] = c;
+                });
+                if ((int)count > room || count > 0xfffu) {
+                    flag(S, ERRF_ARENA);
+                    if (lane == 0) S.leaf_kind[g] = 0;
+                    return;
+                }
+                float temp_policy = 1.0f / (float)count;
+                for (uint32_t i = lane; i < count; i += 64) {
+                    NodeHot c;
+                    c.prior = temp_policy; c.q = 0.0f; c.visits = 0; c.virt = 0;
+                    hot[a + i] = c;
+                }
+                cb = a;
+                if (lane == 0) S.alloc[g] = a + count;
+            }
+            if (lane == 0) {
+                cold[node].child = cb;
+                cold[node].nres = (uint16_t)(count | (res << 12));
+            }
+            terminal = res != TG_ONGOING;
+            break;
+        }
+        NodeCold nc = cold[node];
+        uint32_t nres = uni(nc.nres);
+        res = nres >> 12;
+        if (res != TG_ONGOING) { terminal = true; break; }  // known terminal node: same result again (mcts.rs:35-38)
+        // ---- select, mcts.rs:94-118 ----
+        const uint32_t nchild = nres & 0xfffu, cbase = uni(nc.child);
+        const uint32_t nsum = vis + vv;
+        const float visit_count = (float)nsum;
+        uint32_t ti = nsum;
+        if ((int)ti >= S.ctab_size) { flag(S, ERRF_CTAB); ti = (uint32_t)S.ctab_size - 1; }
+        const float c_rate = S.ctab[ti];
+        const float root_n = sqrtf(visit_count);
+        float best = -INFINITY;
+        int best_i = -1;
+        bool nan = false;
+        for (uint32_t i = lane; i < nchild; i += 64) {
+            NodeHot ch = hot[cbase + i];
+            float cn = (float)(ch.visits + ch.virt);
+            float qv = (ch.visits | ch.virt) ? (ch.q * (float)ch.visits - (float)ch.virt) / cn : 0.0f;
+            float u = qv + c_rate * ch.prior * (root_n / (1.0f + cn));
+            if (u != u) nan = true;
+            if (u >= best) { best = u; best_i = (int)i; }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            float ob = __shfl_xor(best, d);
+            int oi = __shfl_xor(best_i, d);
+            if (ob > best || (ob == best && oi > best_i)) { best = ob; best_i = oi; }
+        }
+        if (__ballot(nan)) flag(S, ERRF_NAN);
+        if (best_i < 0) {  // cannot happen for a consistent tree; never index out of the arena
+            flag(S, ERRF_NAN);
+            if (lane == 0) S.leaf_kind[g] = 0;
+            return;
+        }
+        const uint32_t chosen = cbase + (uint32_t)best_i;
+        const uint32_t mv = uni((uint32_t)cold[chosen].mv);
+        ws_play(s, mv, geo);
+        if (depth >= MAX_DEPTH) {
+            flag(S, ERRF_DEPTH);
+            if (lane == 0) S.leaf_kind[g] = 0;
+            return;
+        }
+        if (lane == 0) path[depth] = chosen;
+        depth++;
+        node = chosen;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    // ---- unwind (mcts.rs:55-62): lane d handles the node at depth d ----
+    const bool winner = res >= TG_WHITE_ROAD && res <= TG_BLACK_FLAT;
+    const uint32_t wcolor = (res == TG_WHITE_ROAD || res == TG_WHITE_FLAT) ? 0u : 1u;
+    for (int d = lane; d <= depth; d += 64) {
+        uint32_t nd = d == 0 ? 0u : path[d - 1];
+        NodeHot h = hot[nd];
+        if (terminal) {
+            uint32_t curr = root_color ^ (uint32_t)(d & 1);
+            float reward = winner ? (wcolor == curr ? -1.0f : 1.0f) : 0.0f;
+            update_concrete(h, reward);
+        } else {
+            h.virt += 1;
+        }
+        hot[nd] = h;
+    }
+    uint32_t* gpath = S.path + (size_t)g * MAX_DEPTH;
+    for (int d = lane; d < depth; d += 64) gpath[d] = path[d];
+    if (!terminal) {
+        if (S.evaluator == TG_EVAL_RESNET) ws_encode<true>(s, geo, S.planes + (size_t)g * geo.nsq * S.cin_pad, S.cin_pad);
+        else if (S.evaluator == TG_EVAL_HASH) {
+            uint64_t h = ws_hash(s, geo);
+            if (lane == 0) S.leaf_hash[g] = h;
+        }
+    }
+    if (lane == 0) {
+        S.path_len[g] = depth;
+        S.leaf_kind[g] = terminal ? 2 : 1;
+        atomicAdd(&S.counters[0], 1ull);
+        if (!terminal) atomicAdd(&S.counters[1], 1ull);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// devirtualize_path, mcts.rs:67-91: real priors for the leaf's children, value backed up with
+// alternating sign, virtual visits removed.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_backup(SearchDev S) {
+    const int g = game_of_wave();
+    if (g >= S.G) return;
+    if (S.leaf_kind[g] != 1) return;
+    const int lane = lane_id();
+    const size_t base = ((size_t)g * 2 + S.sel[g]) * (size_t)S.cap;
+    NodeHot* hot = S.hot + base;
+    NodeCold* cold = S.cold + base;
+    const uint32_t* path = S.path + (size_t)g * MAX_DEPTH;
+    const int L = S.path_len[g];
+    const uint32_t leaf = L ? path[L - 1] : 0u;
+    NodeCold lc = cold[leaf];
+    const uint32_t nchild = uni((uint32_t)lc.nres) & 0xfffu, cb = uni(lc.child);
+    float e;
+    uint64_t hsh = 0;
+    if (S.evaluator == TG_EVAL_RESNET) e = S.eval[g];
+    else if (S.evaluator == TG_EVAL_HASH) { hsh = S.leaf_hash[g]; e = hash_eval(hsh); }
+    else e = 0.0f;
+    const float* pol = S.policy + (size_t)g * S.P;
+    bool bad = false;
+    for (uint32_t i = lane; i < nchild; i += 64) {
+        uint32_t mv = cold[cb + i].mv;
+        int idx = move_index_dev(mv, S.n, S.legacy5 != 0, S.lut5);
+        float p;
+        if (idx < 0 || idx >= S.P) { bad = true; p = 0.0f; }
+        else if (S.evaluator == TG_EVAL_RESNET) p = pol[idx];
+        else if (S.evaluator == TG_EVAL_HASH) p = hash_policy(hsh, (uint32_t)idx);
+        else p = 1.0f;
+        hot[cb + i].prior = p;
+    }
+    if (__ballot(bad)) flag(S, ERRF_MOVE);
+    for (int d = lane; d <= L; d += 64) {
+        uint32_t nd = d == 0 ? 0u : path[d - 1];
+        NodeHot h = hot[nd];
+        h.virt -= 1;
+        float ev = ((L - d) & 1) ? e : -e;  // the leaf sees -eval, its parent +eval, …
+        update_concrete(h, ev);
+        // the prior of this node may just have been rewritten above only if it is a child of the leaf,
+        // which it is not (it lies on the path), so writing the whole record back is safe
+        hot[nd].q = h.q;
+        hot[nd].visits = h.visits;
+        hot[nd].virt = h.virt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// apply_dirichlet, noise.rs:6-16
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_dirichlet(SearchDev S, const uint8_t* __restrict__ active, float alpha, float ratio) {
+    __shared__ double gam[EX_MOVES];
+    __shared__ double sum_s;
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (!S.alive[g] || (active && !active[g])) return;
+    const Geom geo = make_geom(S.n);
+    const size_t base = ((size_t)g * 2 + S.sel[g]) * (size_t)S.cap;
+    NodeHot* hot = S.hot + base;
+    NodeCold rc = S.cold[base];
+    const uint32_t nchild = (uint32_t)rc.nres & 0xfffu, cb = rc.child;
+    if (nchild == 0 || hot[0].visits == 0) return;  // reference asserts visits > 0
+    const uint32_t* hdr = (const uint32_t*)(S.root_state + (size_t)g * geo.bytes + geo.bytes - 16);
+    const uint32_t ply = hdr[0] >> 16;
+    const uint32_t gen = S.generation[g];
+    for (uint32_t i = lane; i < nchild && i < EX_MOVES; i += 64)
+        gam[i] = gamma_sample((double)alpha, S.seed, S.slot_base + (uint32_t)g, gen, ply, i);
+    __syncthreads();
+    if (lane == 0) {
+        double sum = 0.0;
+        for (uint32_t i = 0; i < nchild; i++) sum += gam[i];  // index order: matches the sequential statement
+        sum_s = sum;
+    }
+    __syncthreads();
+    const double sum = sum_s;
+    for (uint32_t i = lane; i < nchild; i += 64) {
+        float noise = sum > 0.0 ? (float)(gam[i] / sum) : (float)(1.0 / (double)nchild);
+        float p = hot[cb + i].prior;
+        hot[cb + i].prior = noise * ratio + p * (1.0f - ratio);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_apply_noise(SearchDev S, const uint8_t* __restrict__ active, const float* __restrict__ noise, float ratio) {
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (!S.alive[g] || (active && !active[g])) return;
+    const size_t base = ((size_t)g * 2 + S.sel[g]) * (size_t)S.cap;
+    NodeHot* hot = S.hot + base;
+    NodeCold rc = S.cold[base];
+    const uint32_t nchild = (uint32_t)rc.nres & 0xfffu, cb = rc.child;
+    for (uint32_t i = lane; i < nchild && i < EX_MOVES; i += 64) {
+        float p = hot[cb + i].prior;
+        hot[cb + i].prior = noise[(size_t)g * EX_MOVES + i] * ratio + p * (1.0f - ratio);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tree reuse: Node::play, play.rs:26-43.  op[g]: -2 = reset the tree (Node::default()), -1 = nothing,
+// ≥ 0 = make that child the root.  The kept subtree is copied breadth-first into the other arena; each
+// block of children is written exactly once with its final child pointers.
+// ------------------------------------------------------------------------------------------------
+struct QDesc { uint32_t old_start, new_start, count; };
+constexpr int QCAP = 4096;
+
+__global__ __launch_bounds__(64) void k_reroot(SearchDev S, const int32_t* __restrict__ op) {
+    __shared__ QDesc q[QCAP];
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int o = op[g];
+    if (o == -1) return;
+    const uint32_t cur = S.sel[g];
+    const size_t base_old = ((size_t)g * 2 + cur) * (size_t)S.cap;
+    if (o == -2) {
+        if (lane == 0) {
+            NodeHot h; h.prior = 0.0f; h.q = 0.0f; h.visits = 0; h.virt = 0;
+            NodeCold c; c.child = 0; c.mv = 0; c.nres = 0;
+            S.hot[base_old] = h;
+            S.cold[base_old] = c;
+            S.alloc[g] = 1;
+        }
+        return;
+    }
+    const size_t base_new = ((size_t)g * 2 + (cur ^ 1u)) * (size_t)S.cap;
+    const NodeHot* hot_o = S.hot + base_old;
+    const NodeCold* cold_o = S.cold + base_old;
+    NodeHot* hot_n = S.hot + base_new;
+    NodeCold* cold_n = S.cold + base_new;
+    NodeCold rc = cold_o[0];
+    const uint32_t rn = (uint32_t)rc.nres & 0xfffu;
+    if ((uint32_t)o >= rn) { flag(S, ERRF_MOVE); return; }
+    const uint32_t oc = rc.child + (uint32_t)o;
+    NodeCold cc = cold_o[oc];
+    uint32_t new_alloc = 1;
+    int head = 0, tail = 0;
+    const uint32_t cn = (uint32_t)cc.nres & 0xfffu;
+    if (lane == 0) {
+        hot_n[0] = hot_o[oc];
+        NodeCold c = cc;
+        c.child = cn ? 1u : 0u;
+        cold_n[0] = c;
+        if (cn) { q[0].old_start = cc.child; q[0].new_start = 1; q[0].count = cn; }
+    }
+    if (cn) { tail = 1; new_alloc = 1 + cn; }
+    __syncthreads();
+    bool overflow = false;
+    while (head != tail) {
+        QDesc d = q[head % QCAP];
+        head++;
+        for (uint32_t k0 = 0; k0 < d.count; k0 += 64) {
+            uint32_t k = k0 + lane;
+            bool on = k < d.count;
+            NodeCold c;
+            c.child = 0; c.mv = 0; c.nres = 0;
+            if (on) c = cold_o[d.old_start + k];
+            uint32_t nch = on ? ((uint32_t)c.nres & 0xfffu) : 0u;
+            int incl = wave_inclusive_scan((int)nch);
+            uint32_t my_new = new_alloc + (uint32_t)(incl - (int)nch);
+            uint64_t bb = __ballot(nch > 0);
+            if (nch > 0) {
+                int rank = __popcll(bb & ((1ull << lane) - 1ull));
+                if (tail + rank - head >= QCAP) overflow = true;
+                else {
+                    QDesc nd;
+                    nd.old_start = c.child; nd.new_start = my_new; nd.count = nch;
+                    q[(tail + rank) % QCAP] = nd;
+                }
+            }
+            if (on) {
+                hot_n[d.new_start + k] = hot_o[d.old_start + k];
+                c.child = nch ? my_new : 0u;
+                cold_n[d.new_start + k] = c;
+            }
+            new_alloc += (uint32_t)__shfl(incl, 63);
+            tail += __popcll(bb);
+        }
+        __syncthreads();
+        if (__ballot(overflow)) { flag(S, ERRF_QUEUE); break; }
+    }
+    if (lane == 0) {
+        S.sel[g] = (uint8_t)(cur ^ 1u);
+        S.alloc[g] = new_alloc;
+    }
+}
+
+// root children → host-visible arrays (Node::improved_policy, play.rs:13-21, plus priors / q)
+__global__ __launch_bounds__(64) void k_root_stats(SearchDev S, uint16_t* moves, uint32_t* visits, float* prior, float* q,
+                                                   int32_t* counts, uint32_t* root_visits, float* root_q) {
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    const size_t base = ((size_t)g * 2 + S.sel[g]) * (size_t)S.cap;
+    NodeCold rc = S.cold[base];
+    NodeHot rh = S.hot[base];
+    const uint32_t nchild = (uint32_t)rc.nres & 0xfffu, cb = rc.child;
+    if (lane == 0) { counts[g] = (int32_t)nchild; root_visits[g] = rh.visits; root_q[g] = rh.q; }
+    for (uint32_t i = lane; i < nchild && i < EX_MOVES; i += 64) {
+        NodeHot h = S.hot[base + cb + i];
+        size_t o = (size_t)g * EX_MOVES + i;
+        moves[o] = S.cold[base + cb + i].mv;
+        visits[o] = h.visits;
+        prior[o] = h.prior;
+        q[o] = h.q;
+    }
+}
+
+// tg_search_play: find the child for a caller-chosen move, play it on the root state
+__global__ __launch_bounds__(256) void k_play_move(SearchDev S, const uint16_t* __restrict__ moves, const uint8_t* __restrict__ active,
+                                                   int32_t* __restrict__ op) {
+    const int g = game_of_wave();
+    if (g >= S.G) return;
+    const int lane = lane_id();
+    if (!S.alive[g] || (active && !active[g])) { if (lane == 0) op[g] = -1; return; }
+    const Geom geo = make_geom(S.n);
+    const size_t base = ((size_t)g * 2 + S.sel[g]) * (size_t)S.cap;
+    NodeCold rc = S.cold[base];
+    const uint32_t nchild = uni((uint32_t)rc.nres) & 0xfffu, cb = uni(rc.child);
+    const uint32_t mv = uni((uint32_t)moves[g]);
+    int found = -1;
+    for (uint32_t i0 = 0; i0 < nchild && found < 0; i0 += 64) {
+        uint32_t i = i0 + lane;
+        bool hit = i < nchild && S.cold[base + cb + i].mv == mv;
+        uint64_t bb = __ballot(hit);
+        if (bb) found = (int)i0 + __builtin_ctzll(bb);
+    }
+    if (found < 0) {  // "tried to play an invalid move" / "node must be initialized" (play.rs:10,35)
+        flag(S, ERRF_MOVE);
+        if (lane == 0) op[g] = -1;
+        return;
+    }
+    WState s;
+    uint8_t* st = S.root_state + (size_t)g * geo.bytes;
+    ws_load(s, st, geo);
+    ws_play(s, mv, geo);
+    ws_store(s, st, geo);
+    if (lane == 0) op[g] = found;
+}
+
+// ------------------------------------------------------------------------------------------------
+// self_play_parallel phases (train/src/self_play.rs:108-259)
+// ------------------------------------------------------------------------------------------------
+
+// (a) opening, :110-116.  "a1", then one of the two far corners (reference hard-codes the 6×6 names
+// a6 / f6; generalised to (0, N-1) / (N-1, N-1)).
+__global__ __launch_bounds__(256) void k_sp_opening(SearchDev S) {
+    const int g = game_of_wave();
+    if (g >= S.G) return;
+    if (!S.alive[g]) return;
+    const Geom geo = make_geom(S.n);
+    WState s;
+    uint8_t* st = S.root_state + (size_t)g * geo.bytes;
+    ws_load(s, st, geo);
+    if (s.ply != 0) return;
+    ws_play(s, 0u /* a1 flat */, geo);
+    U4 r = rng_draw(S.seed, S.slot_base + (uint32_t)g, S.generation[g], 0, RNG_OPENING, 0, 0);
+    uint32_t col = (r.v[0] & 1u) ? 0u : (uint32_t)(geo.n - 1);
+    ws_play(s, (uint32_t)((geo.n - 1) * geo.n) + col, geo);
+    ws_store(s, st, geo);
+}
+
+__device__ inline void stage_example(const SearchDev& S, const SelfPlayDev& P, int g, const WState& s, const Geom& geo,
+                                     uint32_t nmoves, int& slot_out) {
+    // reserves the next staging slot of game g and writes header + state; returns the slot (or -1)
+    int k = P.st_count[g];
+    if (k >= P.ex_per_game) { flag(S, ERRF_EXAMPLES); slot_out = -1; return; }
+    size_t e = (size_t)g * P.ex_per_game + k;
+    ws_store(s, P.st_state + e * geo.bytes, geo);
+    if (lane_id() == 0) {
+        ExampleRec h;
+        h.slot = (int32_t)(S.slot_base + (uint32_t)g);
+        h.generation = (int32_t)S.generation[g];
+        h.n_moves = (int32_t)nmoves;
+        h.result = 0.0f;
+        P.st_hdr[e] = h;
+        P.st_count[g] = k + 1;
+    }
+    slot_out = k;
+}
+
+// (b) instant-win scan, :119-171
+__global__ __launch_bounds__(256) void k_sp_instant_win(SearchDev S, SelfPlayDev P) {
+    __shared__ uint16_t mv_lds[WPB][EX_MOVES];
+    __shared__ uint8_t win_lds[WPB][EX_MOVES];
+    const int g = game_of_wave();
+    if (g >= S.G) return;
+    const int lane = lane_id();
+    if (lane == 0) P.fin[g] = 0;
+    if (!S.alive[g]) return;
+    const Geom geo = make_geom(S.n);
+    WState s;
+    ws_load(s, S.root_state + (size_t)g * geo.bytes, geo);
+    uint16_t* mv = mv_lds[threadIdx.x >> 6];
+    uint8_t* wl = win_lds[threadIdx.x >> 6];
+    int count = ws_movegen(s, geo, EX_MOVES, [&](int idx, uint32_t code) { mv[idx] = (uint16_t)code; });
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (count > EX_MOVES) { flag(S, ERRF_EXAMPLES); return; }
+    bool win = false;
+    for (int k = 0; k < count; k++) {
+        WState t = s;
+        ws_play(t, (uint32_t)mv[k], geo);
+        uint32_t r = ws_result(t, geo);
+        bool w = (r >= TG_WHITE_ROAD && r <= TG_BLACK_FLAT) && (((r == TG_WHITE_ROAD || r == TG_WHITE_FLAT) ? 0u : 1u) == s.to_move);
+        if (lane == 0) wl[k] = w ? 1 : 0;
+        win |= w;
+    }
+    if (!win) return;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int slot;
+    stage_example(S, P, g, s, geo, (uint32_t)count, slot);
+    if (slot >= 0) {
+        size_t e = (size_t)g * P.ex_per_game + slot;
+        for (int k = lane; k < count; k += 64) {
+            P.st_moves[e * EX_MOVES + k] = mv[k];
+            P.st_visits[e * EX_MOVES + k] = wl[k] ? 1000u : 1u;  // fake visits, :129-134
+        }
+    }
+    if (lane == 0) {
+        P.fin[g] = (uint8_t)(s.to_move == 0 ? TG_WHITE_FLAT : TG_BLACK_FLAT);  // Winner { color: to_move, road: false }, :147
+        atomicAdd(&P.stats[ST_INSTANT], 1ull);
+    }
+}
+
+// ordered bookkeeping of the games that ended in this phase (slot order = the reference's loop order):
+// completed counter, recycle-or-retire decision (:151,237), contiguous output ranges for their examples.
+__global__ __launch_bounds__(1024) void k_sp_finish_scan(SearchDev S, SelfPlayDev P) {
+    __shared__ uint32_t s_fin[1024], s_ex[1024];
+    const int tid = threadIdx.x;
+    const int per = (S.G + 1023) / 1024;
+    const int g0 = tid * per, g1 = min(g0 + per, S.G);
+    uint32_t nf = 0, ne = 0;
+    for (int g = g0; g < g1; g++)
+        if (P.fin[g]) { nf++; ne += (uint32_t)P.st_count[g]; }
+    s_fin[tid] = nf;
+    s_ex[tid] = ne;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {  // Hillis–Steele inclusive scan
+        uint32_t a = tid >= d ? s_fin[tid - d] : 0u, b = tid >= d ? s_ex[tid - d] : 0u;
+        __syncthreads();
+        s_fin[tid] += a;
+        s_ex[tid] += b;
+        __syncthreads();
+    }
+    const unsigned long long done0 = P.stats[ST_FINISHED], ex0 = P.stats[ST_EXAMPLES];
+    uint32_t rf = s_fin[tid] - nf, re = s_ex[tid] - ne;
+    for (int g = g0; g < g1; g++) {
+        if (!P.fin[g]) continue;
+        unsigned long long completed = done0 + rf + 1;
+        P.recycle[g] = (P.total_games == 0 || completed + (unsigned long long)S.G < (unsigned long long)P.total_games) ? 1 : 0;
+        P.out_off[g] = (uint32_t)((ex0 + re) % (unsigned long long)P.max_examples);
+        rf++;
+        re += (uint32_t)P.st_count[g];
+    }
+    __syncthreads();
+    if (tid == 1023) {
+        P.stats[ST_FINISHED] = done0 + s_fin[1023];
+        P.stats[ST_EXAMPLES] = ex0 + s_ex[1023];
+    }
+}
+
+// complete the finished games' examples (:158-169, :245-256), reset tree and game (or retire the slot)
+__global__ __launch_bounds__(256) void k_sp_finish_apply(SearchDev S, SelfPlayDev P, int32_t* __restrict__ op) {
+    const int g = game_of_wave();
+    if (g >= S.G) return;
+    const int lane = lane_id();
+    const uint32_t r = P.fin[g];
+    if (!r) return;
+    const Geom geo = make_geom(S.n);
+    const float white_result = (r == TG_WHITE_ROAD || r == TG_WHITE_FLAT) ? 1.0f : (r == TG_BLACK_ROAD || r == TG_BLACK_FLAT) ? -1.0f : 0.0f;
+    const int cnt = P.st_count[g];
+    const uint32_t off = P.out_off[g];
+    for (int k = 0; k < cnt; k++) {
+        size_t e = (size_t)g * P.ex_per_game + k;
+        size_t o = (size_t)((off + (uint32_t)k) % (uint32_t)P.max_examples);
+        ExampleRec h = P.st_hdr[e];
+        const uint8_t* st = P.st_state + e * geo.bytes;
+        uint32_t to_move = st[geo.bytes - 16 + 1];
+        h.result = to_move == 0 ? white_result : -white_result;
+        if (lane == 0) P.out_hdr[o] = h;
+        for (int b = lane; b < geo.bytes / 4; b += 64) ((uint32_t*)(P.out_state + o * geo.bytes))[b] = ((const uint32_t*)st)[b];
+        for (int m = lane; m < h.n_moves; m += 64) {
+            P.out_moves[o * EX_MOVES + m] = P.st_moves[e * EX_MOVES + m];
+            P.out_visits[o * EX_MOVES + m] = P.st_visits[e * EX_MOVES + m];
+        }
+    }
+    WState s;
+    ws_start(s, geo, P.komi * 2);
+    ws_store(s, S.root_state + (size_t)g * geo.bytes, geo);
+    if (lane == 0) {
+        P.st_count[g] = 0;
+        S.generation[g] += 1;
+        if (!P.recycle[g]) S.alive[g] = 0;
+        op[g] = -2;  // *node = Node::default()
+        atomicAdd(&P.stats[white_result > 0 ? ST_WHITE : white_result < 0 ? ST_BLACK : ST_DRAWS], 1ull);
+    }
+}
+
+__global__ void k_sp_noise_mask(SearchDev S, SelfPlayDev P) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= S.G) return;
+    const Geom geo = make_geom(S.n);
+    const uint32_t* hdr = (const uint32_t*)(S.root_state + (size_t)g * geo.bytes + geo.bytes - 16);
+    P.mask[g] = (S.alive[g] && (int)(hdr[0] >> 16) < P.noise_plies) ? 1 : 0;
+}
+
+// (e) pick_move (play.rs:49-67), example (:222-225), play (:227-228), result (:230)
+__global__ __launch_bounds__(256) void k_sp_pick(SearchDev S, SelfPlayDev P, int32_t* __restrict__ op) {
+    const int g = game_of_wave();
+    if (g >= S.G) return;
+    const int lane = lane_id();
+    if (lane == 0) { P.fin[g] = 0; op[g] = -1; }
+    if (!S.alive[g]) return;
+    const Geom geo = make_geom(S.n);
+    const size_t base = ((size_t)g * 2 + S.sel[g]) * (size_t)S.cap;
+    const NodeHot* hot = S.hot + base;
+    const NodeCold* cold = S.cold + base;
+    NodeCold rc = cold[0];
+    const uint32_t nchild = uni((uint32_t)rc.nres) & 0xfffu, cb = uni(rc.child);
+    WState s;
+    uint8_t* st = S.root_state + (size_t)g * geo.bytes;
+    ws_load(s, st, geo);
+    if (nchild == 0) { flag(S, ERRF_PICK); return; }
+    int pick = -1;
+    if ((int)s.ply >= P.exploit_plies) {
+        // max_by_key: most visits, last on ties
+        uint32_t bv = 0;
+        int bi = -1;
+        for (uint32_t i = lane; i < nchild; i += 64) {
+            uint32_t v = hot[cb + i].visits;
+            if (bi < 0 || v >= bv) { bv = v; bi = (int)i; }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            uint32_t ov = (uint32_t)__shfl_xor((int)bv, d);
+            int oi = __shfl_xor(bi, d);
+            if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi > bi))) { bv = ov; bi = oi; }
+        }
+        pick = bi;
+    } else {
+        // WeightedIndex over visits with one RNG_PICK draw
+        unsigned long long total = 0;
+        for (uint32_t i = lane; i < nchild; i += 64) total += hot[cb + i].visits;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(total >> 32), d) << 32) |
+                                   (uint32_t)__shfl_xor((int)(uint32_t)total, d);
+            total += o;
+        }
+        if (total == 0) { flag(S, ERRF_PICK); return; }
+        U4 r = rng_draw(S.seed, S.slot_base + (uint32_t)g, S.generation[g], s.ply, RNG_PICK, 0, 0);
+        unsigned long long x = ((unsigned long long)r.v[0] << 32) | r.v[1];
+        unsigned long long target = __umul64hi(x, total);
+        unsigned long long carry = 0;
+        for (uint32_t i0 = 0; i0 < nchild && pick < 0; i0 += 64) {
+            uint32_t i = i0 + lane;
+            int v = i < nchild ? (int)hot[cb + i].visits : 0;
+            int incl = wave_inclusive_scan(v);
+            uint64_t bb = __ballot(i < nchild && carry + (unsigned long long)incl > target);
+            if (bb) pick = (int)i0 + __builtin_ctzll(bb);
+            carry += (unsigned long long)__shfl(incl, 63);
+        }
+        if (pick < 0) pick = (int)nchild - 1;
+    }
+    // example = (game before the move, visit counts of every child)
+    int slot;
+    stage_example(S, P, g, s, geo, nchild, slot);
+    if (slot >= 0) {
+        size_t e = (size_t)g * P.ex_per_game + slot;
+        for (uint32_t i = lane; i < nchild && i < EX_MOVES; i += 64) {
+            P.st_moves[e * EX_MOVES + i] = cold[cb + i].mv;
+            P.st_visits[e * EX_MOVES + i] = hot[cb + i].visits;
+        }
+    }
+    const uint32_t mv = uni((uint32_t)cold[cb + (uint32_t)pick].mv);
+    ws_play(s, mv, geo);
+    ws_store(s, st, geo);
+    const uint32_t res = ws_result(s, geo);
+    if (lane == 0) {
+        P.fin[g] = (uint8_t)res;
+        op[g] = pick;
+        P.chosen[g] = pick;
+    }
+}
+
+__global__ void k_sp_count_ply(SelfPlayDev P) { P.stats[ST_PLIES] += 1; }
+
+// ---- launchers --------------------------------------------------------------------------------
+static inline dim3 wgrid(int G) { return dim3((G + WPB - 1) / WPB); }
+
+void launch_select(hipStream_t st, const SearchDev& S, const uint8_t* active) {
+    hipLaunchKernelGGL(k_select, wgrid(S.G), dim3(256), 0, st, S, active);
+}
+void launch_backup(hipStream_t st, const SearchDev& S) { hipLaunchKernelGGL(k_backup, wgrid(S.G), dim3(256), 0, st, S); }
+void launch_dirichlet(hipStream_t st, const SearchDev& S, const uint8_t* active, float alpha, float ratio) {
+    hipLaunchKernelGGL(k_dirichlet, dim3(S.G), dim3(64), 0, st, S, active, alpha, ratio);
+}
+void launch_apply_noise(hipStream_t st, const SearchDev& S, const uint8_t* active, const float* noise, float ratio) {
+    hipLaunchKernelGGL(k_apply_noise, dim3(S.G), dim3(64), 0, st, S, active, noise, ratio);
+}
+void launch_reroot(hipStream_t st, const SearchDev& S, const int32_t* op) { hipLaunchKernelGGL(k_reroot, dim3(S.G), dim3(64), 0, st, S, op); }
+void launch_root_stats(hipStream_t st, const SearchDev& S, uint16_t* moves, uint32_t* visits, float* prior, float* q, int32_t* counts,
+                       uint32_t* root_visits, float* root_q) {
+    hipLaunchKernelGGL(k_root_stats, dim3(S.G), dim3(64), 0, st, S, moves, visits, prior, q, counts, root_visits, root_q);
+}
+void launch_play_move(hipStream_t st, const SearchDev& S, const uint16_t* moves, const uint8_t* active, int32_t* op) {
+    hipLaunchKernelGGL(k_play_move, wgrid(S.G), dim3(256), 0, st, S, moves, active, op);
+}
+void launch_sp_opening(hipStream_t st, const SearchDev& S) { hipLaunchKernelGGL(k_sp_opening, wgrid(S.G), dim3(256), 0, st, S); }
+void launch_sp_instant_win(hipStream_t st, const SearchDev& S, const SelfPlayDev& P) {
+    hipLaunchKernelGGL(k_sp_instant_win, wgrid(S.G), dim3(256), 0, st, S, P);
+}
+void launch_sp_finish(hipStream_t st, const SearchDev& S, const SelfPlayDev& P, int32_t* op) {
+    hipLaunchKernelGGL(k_sp_finish_scan, dim3(1), dim3(1024), 0, st, S, P);
+    hipLaunchKernelGGL(k_sp_finish_apply, wgrid(S.G), dim3(256), 0, st, S, P, op);
+}
+void launch_sp_noise_mask(hipStream_t st, const SearchDev& S, const SelfPlayDev& P) {
+    hipLaunchKernelGGL(k_sp_noise_mask, dim3((S.G + 255) / 256), dim3(256), 0, st, S, P);
+}
+void launch_sp_pick(hipStream_t st, const SearchDev& S, const SelfPlayDev& P, int32_t* op) {
+    hipLaunchKernelGGL(k_sp_pick, wgrid(S.G), dim3(256), 0, st, S, P, op);
+}
+void launch_sp_count_ply(hipStream_t st, const SelfPlayDev& P) { hipLaunchKernelGGL(k_sp_count_ply, dim3(1), dim3(1), 0, st, P); }
+
+}  // namespace tg

@@ -1,0 +1,220 @@
+"""GPU-resident MCTS and self-play driver (through the C ABI) against the CPU oracle: whole trees,
+bit for bit (visit counts, f32 priors and values compared as raw bits), with the deterministic test
+evaluators and with the real network."""
+import numpy as np
+import pytest
+
+import torch_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(n, evaluator, games, head=None, **kw):
+    import tak_amd
+
+    if head is None:
+        head = tak_amd.HEAD_FC5 if n == 5 else tak_amd.HEAD_CONV
+    e = tak_amd.Engine(n, evaluator=evaluator, max_batch=max(games, 64), policy_head=head, **kw)
+    return e
+
+
+def _roots(orc, n, count, seed, max_plies):
+    sts = orc.random_positions(n, count * 3, seed=seed, max_plies=max_plies, half_komi=4)
+    sts = sts[orc.result(n, sts) == 0][:count]
+    assert len(sts) == count
+    return sts
+
+
+def _assert_same_trees(e, s, games):
+    for g in range(games):
+        a, b = e.search_dump(g), s.dump(g)
+        assert len(a) == len(b), (g, len(a), len(b))
+        for f in a.dtype.names:
+            assert np.array_equal(a[f], b[f]), (g, f)
+
+
+def _best(root, g):
+    c = root["counts"][g]
+    v = root["visits"][g, :c]
+    return root["moves"][g, c - 1 - int(np.argmax(v[::-1]))]
+
+
+def test_dummynet_behaviour_3x3(orc):
+    # alpha-tak/src/search/tests.rs:37-72 on the GPU (DummyNet: policy 1.0, eval 0)
+    import tak_amd
+
+    e = _mk(3, tak_amd.EVAL_DUMMY, 2)
+    e.search_create(2, arena_nodes=1 << 15)
+    st = np.stack([orc.from_ptn(3, ["a3", "c3", "c2", "a2"]), orc.from_ptn(3, ["a3", "c3", "c2"])])
+    e.search_reset(st)
+    e.search_run(1000)
+    r = e.search_root()
+    mv0 = _best(r, 0)
+    st2, status = orc.play(3, st[0], [mv0])
+    assert status[0] == 0 and orc.result(3, st2)[0] == 1  # win in one: Winner { White, road }
+    # same trees as the oracle, bit for bit
+    s = orc.Search(3, evaluator=orc.EVAL_DUMMY)
+    s.reset(st)
+    s.run(1000)
+    _assert_same_trees(e, s, 2)
+    # prevent win in two: play black's choice, search again, white cannot win immediately
+    mv1 = _best(r, 1)
+    e.search_play([mv0, mv1])
+    s.play([mv0, mv1])
+    assert np.array_equal(e.search_states(), s.states())
+    act = np.array([0, 1], np.uint8)
+    e.search_run(1000, act)
+    s.run(1000, act)
+    _assert_same_trees(e, s, 2)
+    r = e.search_root()
+    st3, status = orc.play(3, e.search_states()[1], [_best(r, 1)])
+    assert status[0] == 0 and orc.result(3, st3)[0] == 0
+    e.close()
+
+
+@pytest.mark.parametrize("n,games,iters", [(5, 24, 300), (6, 12, 200), (4, 16, 300)])
+def test_tree_parity_hash_evaluator(orc, n, games, iters):
+    import tak_amd
+
+    e = _mk(n, tak_amd.EVAL_HASH, games)
+    e.search_create(games, arena_nodes=1 << 16, seed=99)
+    head = orc.HEAD_FC5 if n == 5 else orc.HEAD_CONV
+    s = orc.Search(n, head=head, evaluator=orc.EVAL_HASH, seed=99)
+    sts = _roots(orc, n, games, seed=n, max_plies=40 if n >= 5 else 16)
+    e.search_reset(sts)
+    s.reset(sts)
+    e.search_run(iters)
+    s.run(iters)
+    _assert_same_trees(e, s, games)
+    assert e.search_counters() == s.counters()
+    # Dirichlet noise from the counter-based RNG, then more search, then tree reuse — three rounds
+    for rnd in range(3):
+        e.search_apply_dirichlet(0.2, 0.3)
+        s.apply_dirichlet(0.2, 0.3)
+        e.search_run(60)
+        s.run(60)
+        _assert_same_trees(e, s, games)
+        r = e.search_root()
+        ro = s.root()
+        for k in ("moves", "visits", "counts", "root_visits"):
+            assert np.array_equal(r[k], ro[k])
+        assert np.array_equal(r["prior"].view(np.uint32), ro["prior"].view(np.uint32))
+        assert np.array_equal(r["q"].view(np.uint32), ro["q"].view(np.uint32))
+        mv = np.array([_best(r, g) for g in range(games)], np.uint16)
+        # stop advancing games that the move would end
+        nxt, _ = orc.play(n, e.search_states(), mv)
+        act = (orc.result(n, nxt) == 0).astype(np.uint8)
+        e.search_play(mv, act)
+        s.play(mv, act)
+        assert np.array_equal(e.search_states(), s.states())
+        _assert_same_trees(e, s, games)
+        e.search_run(50, act)
+        s.run(50, act)
+        _assert_same_trees(e, s, games)
+    e.close()
+
+
+def test_caller_noise_and_errors(orc):
+    import tak_amd
+
+    e = _mk(5, tak_amd.EVAL_HASH, 4)
+    e.search_create(4, arena_nodes=1 << 14)
+    s = orc.Search(5, head=orc.HEAD_FC5, evaluator=orc.EVAL_HASH)
+    sts = _roots(orc, 5, 4, seed=2, max_plies=20)
+    e.search_reset(sts)
+    s.reset(sts)
+    e.search_run(10)
+    s.run(10)
+    noise = np.random.default_rng(0).random((4, 512)).astype(np.float32)
+    e.search_apply_noise(noise, 0.25)
+    s.apply_noise(noise, 0.25)
+    _assert_same_trees(e, s, 4)
+    with pytest.raises(tak_amd.TgError) as ei:
+        e.search_play(np.full(4, 0xFFFF, np.uint16))  # not a child of any root
+    assert ei.value.code == -8
+    e.close()
+
+
+def test_arena_overflow_is_reported(orc):
+    import tak_amd
+
+    e = _mk(5, tak_amd.EVAL_DUMMY, 2)
+    e.search_create(2, arena_nodes=1024)
+    e.search_reset(_roots(orc, 5, 2, seed=4, max_plies=30))
+    e.search_run(400)
+    with pytest.raises(tak_amd.TgError) as ei:
+        e.search_root()
+    assert ei.value.code == -5
+    e.close()
+
+
+@pytest.mark.parametrize("n,blocks,filters,head", [(5, 2, 32, "fc5"), (6, 1, 32, "conv")])
+def test_tree_parity_with_real_network(orc, n, blocks, filters, head):
+    # the oracle's MCTS evaluates its leaves through tg_policy_eval; the GPU search feeds the same
+    # kernels from its own leaf batch — identical trees require identical per-position network outputs
+    import tak_amd
+
+    games = 12
+    net = torch_ref.make_net(n, blocks, filters, head, seed=3)
+    tensors = torch_ref.abi_tensors(net)
+    e = _mk(n, tak_amd.EVAL_RESNET, games, res_blocks=blocks, filters=filters)
+    e.load_state_dict(tensors)
+    ev = _mk(n, tak_amd.EVAL_RESNET, games, res_blocks=blocks, filters=filters)
+    ev.load_state_dict(tensors)
+    e.search_create(games, arena_nodes=1 << 15)
+    s = orc.Search(n, head=orc.HEAD_FC5 if head == "fc5" else orc.HEAD_CONV, py_eval=lambda st: ev.policy_eval(st))
+    sts = _roots(orc, n, games, seed=8, max_plies=30)
+    e.search_reset(sts)
+    s.reset(sts)
+    e.search_run(150)
+    s.run(150)
+    _assert_same_trees(e, s, games)
+    e.close()
+    ev.close()
+
+
+def test_dirichlet_spec_matches_oracle(orc):
+    import tak_amd
+
+    e = _mk(5, tak_amd.EVAL_DUMMY, 3)
+    e.search_create(3, arena_nodes=1 << 12, seed=1234)
+    sts = _roots(orc, 5, 3, seed=6, max_plies=25)
+    e.search_reset(sts)
+    e.search_run(1)  # expand the roots: priors become the DummyNet's 1.0
+    e.search_apply_dirichlet(0.2, 0.5)
+    r = e.search_root()
+    for g in range(3):
+        c = r["counts"][g]
+        ply = int(sts[g][256 - 16 + 2]) | (int(sts[g][256 - 16 + 3]) << 8)
+        noise = orc.dirichlet(c, 0.2, 1234, g, 0, ply)
+        want = noise * np.float32(0.5) + np.float32(1.0) * (np.float32(1.0) - np.float32(0.5))
+        assert np.array_equal(r["prior"][g, :c].view(np.uint32), want.astype(np.float32).view(np.uint32))
+        assert abs(float(noise.sum()) - 1.0) < 1e-5
+    e.close()
+
+
+@pytest.mark.parametrize("n,games,rollouts,total", [(4, 8, 24, 20), (5, 6, 16, 9)])
+def test_selfplay_driver_matches_oracle(orc, n, games, rollouts, total):
+    # self_play_parallel end to end: openings, instant wins, noise, rollouts, sampling / argmax,
+    # tree reuse, game recycling and example emission — every example identical, in the same order
+    import tak_amd
+
+    kw = dict(rollouts=rollouts, noise_plies=6, exploit_plies=4, noise_alpha=0.2, noise_ratio=0.3, komi=2, total_games=total)
+    e = _mk(n, tak_amd.EVAL_HASH, games)
+    e.selfplay_create(games, arena_nodes=1 << 15, seed=5, max_examples=1 << 14, **kw)
+    head = orc.HEAD_FC5 if n == 5 else orc.HEAD_CONV
+    sp = orc.SelfPlay(n, games, head=head, evaluator=orc.EVAL_HASH, seed=5, **kw)
+    for step in range(400):
+        e.selfplay_step(1)
+        sp.step(1)
+        a, b = e.selfplay_stats(), sp.stats()
+        assert a == b, (step, a, b)
+        if not sp.states()[1].any():
+            break
+    assert b["games_finished"] >= total - games + 1 and b["examples"] > 0
+    gh, gs, gm, gv = e.selfplay_drain(1 << 14)
+    oh, os_, om, ov = sp.drain(1 << 14)
+    assert len(gh) == len(oh) == b["examples"]
+    assert np.array_equal(gh, oh)
+    assert np.array_equal(gs, os_) and np.array_equal(gm, om) and np.array_equal(gv, ov)
+    e.close()

@@ -244,6 +244,10 @@ int tg_search_root(TgEngine* e, TgMove* moves, uint32_t* visits, float* prior, f
     if (rc) return rc;
     Search* s = e->search;
     const size_t G = (size_t)s->d.G;
+    TG_HIP(hipMemsetAsync(s->r_moves.p, 0, G * EX_MOVES * 2, e->stream));
+    TG_HIP(hipMemsetAsync(s->r_visits.p, 0, G * EX_MOVES * 4, e->stream));
+    TG_HIP(hipMemsetAsync(s->r_prior.p, 0, G * EX_MOVES * 4, e->stream));
+    TG_HIP(hipMemsetAsync(s->r_q.p, 0, G * EX_MOVES * 4, e->stream));
     launch_root_stats(e->stream, s->d, s->r_moves.as<uint16_t>(), s->r_visits.as<uint32_t>(), s->r_prior.as<float>(), s->r_q.as<float>(),
                       s->r_counts.as<int32_t>(), s->r_rv.as<uint32_t>(), s->r_rq.as<float>());
     TG_HIP(hipGetLastError());

@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X-native Tak self-play engine.
+
+Metric (BASELINE.json): MCTS node-expansions / second, 5×5 Tak, 400 sims/move, 4096 concurrent games
+per GPU, 6-block × 64-filter resnet with the FC-1575 policy head (config C2), random-init weights,
+synthetic self-play (no dataset exists for this path).  One "step" = one ply of self_play_parallel for
+every game on the GPU: opening / instant-win scan / root evaluation + Dirichlet noise / 400 lock-step
+rollouts (virtual_rollout → one batched network forward → devirtualize_path) / move choice, example
+emission, tree reuse and game recycling.  Everything runs on the GPU with states resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+Self-play shards by game with no data-path collective: rank r owns games
+[r·4096, (r+1)·4096) with their own RNG streams; RCCL is used only for the barrier / max-over-ranks
+timing.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact f32
+
+
+def make_weights(n, blocks, filters, head, seed=0):
+    """Random-init weights of the named topology (PyTorch default init, fresh BatchNorm), tch layout."""
+    import torch_ref
+
+    net = torch_ref.make_net(n, blocks, filters, head, seed=seed, randomize_bn=False)
+    return net, torch_ref.abi_tensors(net)
+
+
+def cpu_baseline(args, net, seconds_budget=20.0):
+    """The CPU port (oracle/: scalar MCTS + AoS rules, PyTorch-CPU fp32 network) on the host cores, on a
+    bounded sample of the same workload: `cpu_games` of the 4096 games, one full ply (1 + rollouts
+    lock-step iterations)."""
+    import torch
+
+    import torch_ref
+    from oracle import oracle as orc
+
+    n = args.board
+    head = orc.HEAD_FC5 if args.head == "fc5" else orc.HEAD_CONV
+
+    def py_eval(states):
+        return torch_ref.forward(net, orc.encode(n, states))
+
+    sp = orc.SelfPlay(n, args.cpu_games, head=head, py_eval=py_eval, seed=args.seed, rollouts=args.rollouts)
+    t0 = time.perf_counter()
+    plies = 0
+    while True:
+        sp.step(1)
+        plies += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds_budget or plies >= 2:
+            break
+    st = sp.stats()
+    return {
+        "value": st["expansions"] / dt,
+        "unit": "node-expansions/s",
+        "cores": int(torch.get_num_threads()),
+        "kind": "port",
+        "sample": f"{args.cpu_games} of the {args.games} games, {plies} ply(ies) = {st['expansions']} expansions "
+                  f"in {dt:.1f} s; oracle scalar MCTS (1 thread) + PyTorch-CPU fp32 {args.blocks}x{args.filters} net "
+                  f"({torch.get_num_threads()} threads)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
+    ap.add_argument("--rollouts", type=int, default=400, help="sims per move")
+    ap.add_argument("--board", type=int, default=5)
+    ap.add_argument("--blocks", type=int, default=6)
+    ap.add_argument("--filters", type=int, default=64)
+    ap.add_argument("--head", default="fc5", choices=["fc5", "conv"])
+    ap.add_argument("--arena", type=int, default=1 << 17, help="MCTS nodes per game arena")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cpu-games", type=int, default=48)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-every", type=int, default=8, help="time the tower convs of every k-th forward (0 = off)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}", file=sys.stderr)
+            sys.exit(2)
+
+    import torch
+
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible — the engine has no CPU fallback", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import tak_amd
+
+    net, tensors = make_weights(args.board, args.blocks, args.filters, args.head, seed=args.seed)
+    eng = tak_amd.Engine(args.board, res_blocks=args.blocks, filters=args.filters,
+                         policy_head=tak_amd.HEAD_FC5 if args.head == "fc5" else tak_amd.HEAD_CONV,
+                         evaluator=tak_amd.EVAL_RESNET, max_batch=args.games, device=local_rank)
+    eng.load_state_dict(tensors)
+    steps_total = args.steps + args.warmup
+    eng.selfplay_create(args.games, arena_nodes=args.arena, seed=args.seed, rollouts=args.rollouts,
+                        max_examples=max(1 << 14, args.games * (steps_total + 2)), slot_base=rank * args.games)
+
+    def barrier():
+        eng.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        eng.selfplay_step(1)
+    barrier()
+    s0 = eng.selfplay_stats()
+    if args.profile_every:
+        eng.profile_enable(args.profile_every)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.selfplay_step(1)
+    eng.sync()
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    prof = eng.profile_read() if args.profile_every else None
+    if args.profile_every:
+        eng.profile_enable(0)
+    s1 = eng.selfplay_stats()
+    expansions = s1["expansions"] - s0["expansions"]
+    evals = s1["evals"] - s0["evals"]
+
+    dt = dt_local
+    total_exp = expansions
+    if dist is not None:
+        t = torch.tensor([dt_local], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        c = torch.tensor([expansions], dtype=torch.float64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        total_exp = int(c.item())
+
+    if rank == 0:
+        out = {
+            "metric": "MCTS node-expansions/sec (5x5 Tak, 400 sims/move, 4096 games/GPU)",
+            "value": total_exp / dt,
+            "unit": "node-expansions/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1000.0 * dt / max(args.steps, 1),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.board}x{args.board} Tak self-play, {args.games} concurrent games/GPU, {args.rollouts} sims/move, "
+                            f"{args.blocks}-block x {args.filters}-filter resnet ({args.head} policy head), random-init weights, 1 step = 1 ply of all games",
+                "games_per_gpu": args.games, "sims_per_move": args.rollouts, "board": args.board,
+                "parallelism": f"games sharded x{world}, no data-path collective",
+                "expansions_timed": total_exp, "network_evals_rank0": evals,
+            },
+        }
+        if prof and prof["conv_launches"]:
+            avg_ms = prof["conv_ms"] / prof["conv_launches"]
+            achieved = prof["conv_flops"] / (avg_ms * 1e-3) / 1e12
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_conv.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {
+                "bound": "mfma", "kernel": "k_conv3x3<2,1> (3x3 conv F->F, f32 MFMA 32x32x2)",
+                "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+                "traffic": traffic, "avg_launch_ms": avg_ms, "launches_timed": prof["conv_launches"],
+                "flops_per_launch": prof["conv_flops"], "rows_per_launch": prof["conv_rows"],
+                "forward_ms": prof["forward_ms"] / max(prof["forwards"], 1),
+            }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, net)
+            except Exception as ex:  # the checker failing must not hide the GPU number
+                out["cpu_baseline"] = {"error": repr(ex)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -241,6 +241,10 @@ typedef struct TgSearchConfig {
     float exploration_base;   /* EXPLORATION_BASE 500 (mcts.rs:7) */
     float exploration_init;   /* EXPLORATION_INIT 4   (mcts.rs:8) */
     uint64_t seed;            /* counter-based RNG key (noise, move sampling, openings)      */
+    uint32_t slot_base;       /* global index of this engine's first game: RNG streams are keyed by
+                                 (seed, slot_base + g, …) so shards on different GPUs play different,
+                                 reproducible games (rank r of a sharded run passes r * games)        */
+    uint32_t reserved;
 } TgSearchConfig;
 
 int tg_search_create(TgEngine* e, const TgSearchConfig* cfg);
@@ -327,6 +331,22 @@ int tg_selfplay_stats(TgEngine* e, TgSelfPlayStats* out);
  * from the ring.  states: cap packed states; moves/visits: cap × TG_MAX_MOVES. */
 int tg_selfplay_drain(TgEngine* e, int cap, TgExampleHeader* headers, void* states, TgMove* moves,
                       uint32_t* visits, int32_t* n_out);
+
+/* ---------------------------------------------------------------------------------------
+ * Measurement hooks (no reference counterpart: the reference has no profiling).
+ * While enabled, every `sample_every`-th network forward brackets each residual-tower 3×3 conv
+ * launch with HIP events on the engine stream; tg_profile_read synchronises and returns the totals.
+ * ------------------------------------------------------------------------------------- */
+typedef struct TgProfile {
+    uint64_t conv_launches;   /* residual-tower conv launches timed (F→F 3×3, the dominant kernel) */
+    double conv_ms;           /* their summed duration                                           */
+    uint64_t forwards;        /* network forwards timed end to end                               */
+    double forward_ms;
+    int64_t conv_rows;        /* M = positions × N² of the timed launches (all equal)            */
+    int64_t conv_flops;       /* algorithmic FLOPs of one timed launch: 2·M·9·F·F                */
+} TgProfile;
+int tg_profile_enable(TgEngine* e, int sample_every); /* 0 disables */
+int tg_profile_read(TgEngine* e, TgProfile* out);     /* synchronises; resets the totals */
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,38 @@ struct Net {
     float value_b = 0.0f;
     // activations (max_batch positions)
     DevBuf x, y, logits, planes_nhwc, planes_nchw;
+    // measurement hooks (tg_profile_*)
+    int prof_every = 0;
+    uint64_t prof_counter = 0;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<std::vector<hipEvent_t>> ev_chains;  // per sampled forward: [start, after conv0, after each tower conv…, end]
+    double conv_ms = 0.0, fwd_ms = 0.0;
+    uint64_t conv_n = 0, fwd_n = 0;
+    int64_t conv_rows = 0, conv_flops = 0;
+    ~Net() {
+        for (auto& c : ev_chains) for (auto ev : c) (void)hipEventDestroy(ev);
+        for (auto ev : ev_pool) (void)hipEventDestroy(ev);
+    }
 };
+
+static hipEvent_t prof_event(Net* n, hipStream_t st) {
+    hipEvent_t ev = nullptr;
+    if (!n->ev_pool.empty()) { ev = n->ev_pool.back(); n->ev_pool.pop_back(); }
+    else if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    (void)hipEventRecord(ev, st);
+    return ev;
+}
+
+static void prof_collect(Net* n) {  // the stream must be idle
+    for (auto& c : n->ev_chains) {
+        float ms = 0.0f;
+        if (c.size() >= 2 && hipEventElapsedTime(&ms, c.front(), c.back()) == hipSuccess) { n->fwd_ms += ms; n->fwd_n++; }
+        for (size_t i = 1; i + 2 < c.size(); i++)  // intervals [after conv0 … after last tower conv]
+            if (hipEventElapsedTime(&ms, c[i], c[i + 1]) == hipSuccess) { n->conv_ms += ms; n->conv_n++; }
+        for (auto ev : c) n->ev_pool.push_back(ev);
+    }
+    n->ev_chains.clear();
+}
 
 void net_destroy(Net* n) { delete n; }
 
@@ -196,13 +227,28 @@ int net_forward_dev(TgEngine* e, int nb, const float* d_planes, float* d_policy,
     const int M = nb * nsq;
     float* x = n->x.as<float>();
     float* y = n->y.as<float>();
+    std::vector<hipEvent_t>* chain = nullptr;
+    if (n->prof_every > 0 && (n->prof_counter++ % (uint64_t)n->prof_every) == 0) {
+        if (n->ev_chains.size() >= 256) {  // bound the number of pending events
+            TG_HIP(hipStreamSynchronize(st));
+            prof_collect(n);
+        }
+        n->ev_chains.emplace_back();
+        chain = &n->ev_chains.back();
+        n->conv_rows = M;
+        n->conv_flops = 2ll * M * 9 * F * F;
+        chain->push_back(prof_event(n, st));
+    }
     TG_HIP(launch_conv3x3(st, d_planes, n->conv0.w.as<float>(), n->conv0.b.as<float>(), nullptr, x, M, N, n->cin_pad,
                           n->conv0.cout_pad, F, F, true));
+    if (chain) chain->push_back(prof_event(n, st));
     for (int i = 0; i < n->R; i++) {
         TG_HIP(launch_conv3x3(st, x, n->res1[i].w.as<float>(), n->res1[i].b.as<float>(), nullptr, y, M, N, F,
                               n->res1[i].cout_pad, F, F, true));
+        if (chain) chain->push_back(prof_event(n, st));
         TG_HIP(launch_conv3x3(st, y, n->res2[i].w.as<float>(), n->res2[i].b.as<float>(), x, x, M, N, F,
                               n->res2[i].cout_pad, F, F, true));
+        if (chain) chain->push_back(prof_event(n, st));
     }
     float* logits = n->logits.as<float>();
     if (e->cfg.policy_head == TG_HEAD_CONV) {
@@ -215,6 +261,28 @@ int net_forward_dev(TgEngine* e, int nb, const float* d_planes, float* d_policy,
         TG_HIP(launch_softmax(st, logits, n->policy_np, false, nsq, 0, e->policy_size, nb, d_policy));
     }
     TG_HIP(launch_value_head(st, x, n->value_w.as<float>(), n->value_b, nb, nsq * F, d_eval));
+    if (chain) chain->push_back(prof_event(n, st));
+    return TG_OK;
+}
+
+int net_profile_enable(TgEngine* e, int sample_every) {
+    if (!e || !e->net) return fail(TG_ERR_STATE, "engine has no network (evaluator is not TG_EVAL_RESNET)");
+    if (sample_every < 0) return fail(TG_ERR_INVALID_ARG, "sample_every must be >= 0");
+    e->net->prof_every = sample_every;
+    e->net->prof_counter = 0;
+    return TG_OK;
+}
+
+int net_profile_read(TgEngine* e, TgProfile* out) {
+    if (!e || !e->net || !out) return fail(TG_ERR_STATE, "engine has no network (evaluator is not TG_EVAL_RESNET)");
+    Net* n = e->net;
+    TG_HIP(hipSetDevice(e->cfg.device));
+    TG_HIP(hipStreamSynchronize(e->stream));
+    prof_collect(n);
+    out->conv_launches = n->conv_n; out->conv_ms = n->conv_ms; out->forwards = n->fwd_n; out->forward_ms = n->fwd_ms;
+    out->conv_rows = n->conv_rows; out->conv_flops = n->conv_flops;
+    n->conv_n = n->fwd_n = 0;
+    n->conv_ms = n->fwd_ms = 0.0;
     return TG_OK;
 }
 
@@ -226,6 +294,8 @@ extern "C" {
 
 int tg_net_set_tensor(TgEngine* e, const char* name, const float* data, size_t count) { return net_set_tensor(e, name, data, count); }
 int tg_net_finalize(TgEngine* e) { return net_finalize(e); }
+int tg_profile_enable(TgEngine* e, int sample_every) { return net_profile_enable(e, sample_every); }
+int tg_profile_read(TgEngine* e, TgProfile* out) { return net_profile_read(e, out); }
 
 // Network::policy_eval (net5.rs:120-130): encode on the device straight into NHWC, forward, copy out
 int tg_policy_eval_dev(TgEngine* e, int n, const void* d_states, float* d_policy, float* d_eval) {

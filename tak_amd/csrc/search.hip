@@ -137,7 +137,7 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     d.eval = s->eval.as<float>(); d.ctab = s->ctab.as<float>(); d.lut5 = e->lut5.as<int16_t>(); d.err = s->err.as<uint32_t>();
     d.counters = s->counters.as<unsigned long long>();
     d.G = cfg->games; d.cap = cfg->arena_nodes; d.n = e->g.n; d.cin_pad = cin_pad; d.P = e->policy_size; d.ctab_size = ctab_size;
-    d.legacy5 = e->legacy5 ? 1 : 0; d.evaluator = e->cfg.evaluator; d.slot_base = 0; d.seed = cfg->seed;
+    d.legacy5 = e->legacy5 ? 1 : 0; d.evaluator = e->cfg.evaluator; d.slot_base = cfg->slot_base; d.seed = cfg->seed;
     e->search = sp.release();
     return TG_OK;
 }

@@ -32,7 +32,15 @@ class TgConfig(C.Structure):
 
 class TgSearchConfig(C.Structure):
     _fields_ = [("games", C.c_int32), ("arena_nodes", C.c_int32), ("exploration_base", C.c_float),
-                ("exploration_init", C.c_float), ("seed", C.c_uint64)]
+                ("exploration_init", C.c_float), ("seed", C.c_uint64), ("slot_base", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class TgProfile(C.Structure):
+    _fields_ = [("conv_launches", C.c_uint64), ("conv_ms", C.c_double), ("forwards", C.c_uint64), ("forward_ms", C.c_double),
+                ("conv_rows", C.c_int64), ("conv_flops", C.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class TgSelfPlayConfig(C.Structure):
@@ -57,6 +65,7 @@ ABI_SYMBOLS = [
     "tg_search_create", "tg_search_reset", "tg_search_run", "tg_search_apply_dirichlet", "tg_search_apply_noise",
     "tg_search_root", "tg_search_play", "tg_search_states", "tg_search_dump", "tg_search_counters",
     "tg_selfplay_create", "tg_selfplay_step", "tg_selfplay_stats", "tg_selfplay_drain",
+    "tg_profile_enable", "tg_profile_read",
 ]
 
 
@@ -226,8 +235,8 @@ class Engine:
         self._check(self.lib.tg_policy_eval_dev(self.h, n, C.c_void_p(d_states), C.c_void_p(d_policy), C.c_void_p(d_eval)))
 
     # ---- Node / search ----------------------------------------------------------------------------
-    def search_create(self, games, arena_nodes=1 << 16, base=500.0, init=4.0, seed=0):
-        cfg = TgSearchConfig(games, arena_nodes, base, init, seed)
+    def search_create(self, games, arena_nodes=1 << 16, base=500.0, init=4.0, seed=0, slot_base=0):
+        cfg = TgSearchConfig(games, arena_nodes, base, init, seed, slot_base, 0)
         self._check(self.lib.tg_search_create(self.h, C.byref(cfg)))
         self.games = games
 
@@ -278,10 +287,20 @@ class Engine:
         self._check(self.lib.tg_search_counters(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    # ---- measurement hooks ----------------------------------------------------------------------
+    def profile_enable(self, sample_every):
+        self._check(self.lib.tg_profile_enable(self.h, sample_every))
+
+    def profile_read(self):
+        p = TgProfile()
+        self._check(self.lib.tg_profile_read(self.h, C.byref(p)))
+        return p.as_dict()
+
     # ---- self_play_parallel ------------------------------------------------------------------------
     def selfplay_create(self, games, arena_nodes=1 << 16, base=500.0, init=4.0, seed=0, rollouts=400, noise_plies=80,
-                        exploit_plies=40, noise_alpha=0.2, noise_ratio=0.3, komi=2, total_games=0, max_examples=1 << 16):
-        scfg = TgSearchConfig(games, arena_nodes, base, init, seed)
+                        exploit_plies=40, noise_alpha=0.2, noise_ratio=0.3, komi=2, total_games=0, max_examples=1 << 16,
+                        slot_base=0):
+        scfg = TgSearchConfig(games, arena_nodes, base, init, seed, slot_base, 0)
         cfg = TgSelfPlayConfig(rollouts, noise_plies, exploit_plies, noise_alpha, noise_ratio, komi, total_games, max_examples)
         self._check(self.lib.tg_selfplay_create(self.h, C.byref(scfg), C.byref(cfg)))
         self.games = games

@@ -93,9 +93,9 @@ def main():
     ap.add_argument("--profile-every", type=int, default=8, help="time the tower convs of every k-th forward (0 = off)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from tak_amd import dist as tdist
+
+    rank, world, local_rank = tdist.env_rank()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}", file=sys.stderr)
@@ -107,12 +107,7 @@ def main():
         print("bench.py: no GPU visible — the engine has no CPU fallback", file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dist = tdist.init("nccl", rank, world, device=torch.device("cuda", local_rank))
 
     import tak_amd
 
@@ -123,7 +118,7 @@ def main():
     eng.load_state_dict(tensors)
     steps_total = args.steps + args.warmup
     eng.selfplay_create(args.games, arena_nodes=args.arena, seed=args.seed, rollouts=args.rollouts,
-                        max_examples=max(1 << 14, args.games * (steps_total + 2)), slot_base=rank * args.games)
+                        max_examples=max(1 << 14, args.games * (steps_total + 2)), slot_base=tdist.slot_base(rank, args.games))
 
     def barrier():
         eng.sync()
@@ -152,15 +147,7 @@ def main():
     expansions = s1["expansions"] - s0["expansions"]
     evals = s1["evals"] - s0["evals"]
 
-    dt = dt_local
-    total_exp = expansions
-    if dist is not None:
-        t = torch.tensor([dt_local], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        c = torch.tensor([expansions], dtype=torch.float64, device="cuda")
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        total_exp = int(c.item())
+    dt, total_exp = tdist.reduce_time_and_count(dist, dt_local, expansions, device="cuda")
 
     if rank == 0:
         out = {

@@ -61,6 +61,7 @@ struct TgEngine {
     tg::Geom g;
     hipStream_t stream = nullptr;
     int cin = 0;          // input channels
+    int cin_pad = 0;      // channels per NHWC input row (multiple of 16, zero padded)
     int policy_size = 0;  // P
     bool legacy5 = false; // FC5 head → legacy 1575 LUT indices
     tg::DevBuf lut5;      // int16[25*4*32]

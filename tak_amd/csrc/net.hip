@@ -11,8 +11,8 @@
 namespace tg {
 
 struct ConvLayer {
-    DevBuf w, b;      // Wp [K/8][CoutP][8], bias [CoutP]
-    int cin_pad = 0;  // channels per input row (multiple of 8)
+    DevBuf w, b;      // Wp [K/16][CoutP][16], bias [CoutP]
+    int cin_pad = 0;  // channels per input row (multiple of 16)
     int cout = 0, cout_pad = 0;
 };
 
@@ -23,7 +23,7 @@ struct Net {
     ConvLayer conv0;
     std::vector<ConvLayer> res1, res2;
     ConvLayer policy_conv;            // TG_HEAD_CONV
-    DevBuf policy_w, policy_b;        // TG_HEAD_FC5: Wp [K/8][NP][8]
+    DevBuf policy_w, policy_b;        // TG_HEAD_FC5: Wp [K/16][NP][16]
     int policy_np = 0;                // padded FC outputs
     DevBuf value_w;                   // [nsq*F] in NHWC order
     float value_b = 0.0f;
@@ -72,7 +72,7 @@ int net_create(TgEngine* e) {
     n->F = e->cfg.filters;
     n->R = e->cfg.res_blocks;
     n->cin = e->cin;
-    n->cin_pad = round_up(e->cin, 8);
+    n->cin_pad = e->cin_pad;
     return TG_OK;
 }
 
@@ -124,7 +124,7 @@ bool fold_conv_bn(Net* n, const std::string& conv, const std::string& bn, int O,
     return true;
 }
 
-// OIHW → Wp[(tap*Ipad + c)/8][CoutP][(tap*Ipad + c)%8], tap = ky*3 + kx, zero padded
+// OIHW → Wp[(tap*Ipad + c)/16][CoutP][(tap*Ipad + c)%16], tap = ky*3 + kx, zero padded
 hipError_t upload_conv(const Folded& f, int O, int I, int Ipad, ConvLayer& L) {
     int OP = round_up(O, 64);
     size_t K = (size_t)9 * Ipad;
@@ -134,7 +134,7 @@ hipError_t upload_conv(const Folded& f, int O, int I, int Ipad, ConvLayer& L) {
         for (int c = 0; c < I; c++)
             for (int tap = 0; tap < 9; tap++) {
                 size_t k = (size_t)tap * Ipad + c;
-                wp[((k >> 3) * OP + o) * 8 + (k & 7)] = f.w[((size_t)o * I + c) * 9 + tap];
+                wp[((k >> 4) * OP + o) * 16 + (k & 15)] = f.w[((size_t)o * I + c) * 9 + tap];
             }
     }
     L.cin_pad = Ipad; L.cout = O; L.cout_pad = OP;
@@ -185,7 +185,7 @@ int net_finalize(TgEngine* e) {
             for (int c = 0; c < F; c++)
                 for (int sq = 0; sq < nsq; sq++) {
                     size_t k = (size_t)sq * F + c;
-                    wp[((k >> 3) * NP + o) * 8 + (k & 7)] = (*w)[(size_t)o * K + (size_t)c * nsq + sq];
+                    wp[((k >> 4) * NP + o) * 16 + (k & 15)] = (*w)[(size_t)o * K + (size_t)c * nsq + sq];
                 }
         }
         n->policy_np = NP;

@@ -86,9 +86,10 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, c
 
     const int col0 = blockIdx.y * (64 * CT) + wc * (32 * CT);
     const int chunks = Cpad >> 3;
-    // B fragment base: Wp[kchunk][col][8], this lane: column col0 + ct*32 + i, k sub-offset 4h
-    const float* wlane = Wp + ((size_t)(col0 + i) * 8 + 4 * h);
-    const size_t wchunk_stride = (size_t)CoutP * 8;
+    // B fragment base: Wp[k/16][col][16]; 8-wide sub-chunk c8 lives at [c8>>1][col][8*(c8&1) ..]; this lane:
+    // column col0 + ct*32 + i, k sub-offset 4h
+    const float* wlane = Wp + ((size_t)(col0 + i) * 16 + 4 * h);
+    const size_t wchunk_stride = (size_t)CoutP * 16;
 
     for (int tap = 0; tap < 9; tap++) {
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
@@ -99,11 +100,12 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, c
             bool ok = valid[rt] && yy >= 0 && yy < n && xx >= 0 && xx < n;
             aoff[rt] = ok ? base_off[rt] + (dy * n + dx) * LS : zero_off;
         }
-        const float* wtap = wlane + (size_t)tap * chunks * wchunk_stride;
+        const float* wtap = wlane + (size_t)tap * (chunks >> 1) * wchunk_stride;
         for (int c8 = 0; c8 < chunks; c8++) {
             f32x4 a[RT], b[CT];
 #pragma unroll
-            for (int ct = 0; ct < CT; ct++) b[ct] = *(const f32x4*)(wtap + (size_t)c8 * wchunk_stride + (size_t)ct * 32 * 8);
+            for (int ct = 0; ct < CT; ct++)
+                b[ct] = *(const f32x4*)(wtap + (size_t)(c8 >> 1) * wchunk_stride + (size_t)ct * 32 * 16 + 8 * (c8 & 1));
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) a[rt] = *(const f32x4*)&lds[aoff[rt] + c8 * 8];
 #pragma unroll
@@ -139,6 +141,134 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, c
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Whole-positions variant: a workgroup owns PW complete positions (PW·N² rows, e.g. 16 positions = 400
+// rows = 25 row tiles on 5×5; 4 positions = 144 rows = 9 tiles on 6×6) and CTW 16-wide channel tiles, so
+// the grid is an exact multiple of the 256 CUs (no tail wave) and no position is staged twice.
+// v_mfma_f32_16x16x4_f32 with the WEIGHTS as the A operand and the activations as B: the accumulator then
+// holds, per lane, 4 consecutive output channels of one row → 16-byte epilogue loads/stores.
+// Waves: wave = (row group rg, channel tile ct); each wave owns RTW row tiles × 1 channel tile.
+// ------------------------------------------------------------------------------------------------
+template <int RTW, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void k_conv_pos(const float* __restrict__ in, const float* __restrict__ Wp,
+                                                          const float* __restrict__ bias, const float* __restrict__ res,
+                                                          float* __restrict__ out, int B, int n, int Cpad, int CoutP,
+                                                          int out_stride, int cout_valid, int relu, int PW, int CTW) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    f32x4* lds4 = (f32x4*)lds;  // every access below is a whole 16-byte slot → ds_read_b128 / ds_write_b128
+    const int tid = threadIdx.x;
+    const int nsq = n * n;
+    const int LS4 = (Cpad + LDS_PAD) >> 2;
+    const int pos0 = blockIdx.x * PW;
+    const int npos = min(PW, B - pos0);
+    const int rows = npos * nsq;
+    {
+        const int vpr = Cpad >> 2;
+        const f32x4* src = (const f32x4*)(in + (size_t)pos0 * nsq * Cpad);
+        const int total = rows * vpr;
+        // all of a thread's loads are issued before the first LDS write (8 in flight per lane)
+        constexpr int UNR = 8;
+        for (int base = 0; base < total; base += NWAVES * 64 * UNR) {
+            f32x4 tmp[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                int idx = base + u * NWAVES * 64 + tid;
+                tmp[u] = idx < total ? src[idx] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                int idx = base + u * NWAVES * 64 + tid;
+                if (idx < total) {
+                    int r = idx / vpr, v = idx - r * vpr;
+                    lds4[r * LS4 + v] = tmp[u];
+                }
+            }
+        }
+        for (int idx = tid; idx < LS4; idx += NWAVES * 64) lds4[rows * LS4 + idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int ct = wave % CTW, rg = wave / CTW;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int zero4 = rows * LS4 + q;
+
+    int base4[RTW], pyx[RTW];
+#pragma unroll
+    for (int j = 0; j < RTW; j++) {
+        int rho = (rg * RTW + j) * 16 + r16;
+        bool valid = rho < rows;
+        int rr = valid ? rho : 0;
+        int p = rr / nsq;
+        int sq = rr - p * nsq;
+        int y = sq / n, x = sq - y * n;
+        pyx[j] = valid ? (y | (x << 8)) : 0x7f7f;  // invalid rows: every tap falls off the board
+        base4[j] = rr * LS4 + q;
+    }
+
+    f32x4 acc[RTW];
+#pragma unroll
+    for (int j = 0; j < RTW; j++) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int ch0 = (blockIdx.y * CTW + ct) * 16;
+    const int chunks = Cpad >> 4;
+    const int total_chunks = 9 * chunks;
+    // weights: Wp[k/16][ch][16] = 4 slots of 16 B per (chunk, channel); this lane reads slot q of channel ch0 + r16
+    const f32x4* wp = (const f32x4*)Wp + ((size_t)(ch0 + r16) * 4 + q);
+    const size_t wstride4 = (size_t)CoutP * 4;
+
+    f32x4 w_cur = wp[0];
+    int kk = 0;
+    for (int tap = 0; tap < 9; tap++) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        int aoff[RTW];
+#pragma unroll
+        for (int j = 0; j < RTW; j++) {
+            int yy = (pyx[j] & 0xff) + dy, xx = (pyx[j] >> 8) + dx;
+            bool ok = yy >= 0 && yy < n && xx >= 0 && xx < n;
+            aoff[j] = ok ? base4[j] + (dy * n + dx) * LS4 : zero4;
+        }
+        f32x4 a_cur[RTW];
+#pragma unroll
+        for (int j = 0; j < RTW; j++) a_cur[j] = lds4[aoff[j]];
+        for (int kc = 0; kc < chunks; kc++) {
+            // software pipeline: the next chunk's weights (L2) and activations (LDS) are in flight while
+            // this chunk's 4·RTW MFMAs issue
+            const int kkn = kk + 1 < total_chunks ? kk + 1 : kk;
+            const f32x4 w_nxt = wp[(size_t)kkn * wstride4];
+            const int kn = kc + 1 < chunks ? kc + 1 : kc;
+            f32x4 a_nxt[RTW];
+#pragma unroll
+            for (int j = 0; j < RTW; j++) a_nxt[j] = lds4[aoff[j] + kn * 4];
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int j = 0; j < RTW; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_cur[t], a_cur[j][t], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < RTW; j++) a_cur[j] = a_nxt[j];
+            w_cur = w_nxt;
+            kk++;
+        }
+    }
+
+    // epilogue: lane holds out[row = tile*16 + (lane&15)][ch0 + 4q .. 4q+3]
+    const int ch = ch0 + 4 * q;
+    const f32x4 bv = *(const f32x4*)&bias[ch];
+#pragma unroll
+    for (int j = 0; j < RTW; j++) {
+        int rho = (rg * RTW + j) * 16 + r16;
+        if (rho < rows && ch < cout_valid) {
+            size_t o = ((size_t)pos0 * nsq + rho) * out_stride + ch;
+            f32x4 v = acc[j] + bv;
+            if (res) v += *(const f32x4*)&res[o];
+            if (relu) { v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f); }
+            if (ch + 3 < cout_valid) *(f32x4*)&out[o] = v;
+            else for (int t = 0; t < 4; t++) if (ch + t < cout_valid) out[o + t] = v[t];
+        }
+    }
+}
+
 // Plain GEMM out[M][N] = A[M][K]·W[K][N] + bias for the 5×5 policy FC (net5.rs:56-61,108): the same
 // fragments, A staged through LDS in K-chunks of 32.
 template <int RT, int CT>
@@ -155,8 +285,8 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
     const int wr = wave & 1, wc = wave >> 1;
     const int i = lane & 31, h = lane >> 5;
     const int col0 = blockIdx.y * (64 * CT) + wc * (32 * CT);
-    const float* wlane = Wp + ((size_t)(col0 + i) * 8 + 4 * h);
-    const size_t wchunk_stride = (size_t)NP * 8;
+    const float* wlane = Wp + ((size_t)(col0 + i) * 16 + 4 * h);
+    const size_t wchunk_stride = (size_t)NP * 16;
 
     f32x16 acc[RT][CT];
 #pragma unroll
@@ -188,7 +318,8 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
             f32x4 a[RT], b[CT];
             const size_t kchunk = (size_t)kc * (KC / 8) + c8;
 #pragma unroll
-            for (int ct = 0; ct < CT; ct++) b[ct] = *(const f32x4*)(wlane + kchunk * wchunk_stride + (size_t)ct * 32 * 8);
+            for (int ct = 0; ct < CT; ct++)
+                b[ct] = *(const f32x4*)(wlane + (kchunk >> 1) * wchunk_stride + (size_t)ct * 32 * 16 + 8 * (kchunk & 1));
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) a[rt] = *(const f32x4*)&lds[buf][((wr * RT + rt) * 32 + i) * LS + c8 * 8 + 4 * h];
 #pragma unroll
@@ -315,8 +446,33 @@ static hipError_t launch_conv_t(hipStream_t st, const float* in, const float* Wp
     return hipGetLastError();
 }
 
+template <int RTW, int NWAVES>
+static hipError_t launch_conv_pos_t(hipStream_t st, const float* in, const float* Wp, const float* bias, const float* res,
+                                    float* out, int B, int n, int Cpad, int CoutP, int out_stride, int cout_valid, bool relu,
+                                    int PW, int CTW) {
+    size_t lds = (size_t)(PW * n * n + 1) * (Cpad + LDS_PAD) * sizeof(float);
+    static size_t configured = 0;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_conv_pos<RTW, NWAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    dim3 grid((B + PW - 1) / PW, CoutP / (CTW * 16));
+    hipLaunchKernelGGL((k_conv_pos<RTW, NWAVES>), grid, dim3(NWAVES * 64), lds, st, in, Wp, bias, res, out, B, n, Cpad, CoutP,
+                       out_stride, cout_valid, relu ? 1 : 0, PW, CTW);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv3x3(hipStream_t st, const float* in, const float* Wp, const float* bias, const float* res, float* out,
                           int M, int n, int Cpad, int CoutP, int out_stride, int cout_valid, bool relu) {
+    const int B = M / (n * n);
+    // whole-positions kernel where the shape divides evenly (the BASELINE configs); generic tiles otherwise
+    if (n == 5 && CoutP == 64 && Cpad <= 80)  // 16 positions = 25 row tiles, 4 channel tiles × 2 row groups of 13
+        return launch_conv_pos_t<13, 8>(st, in, Wp, bias, res, out, B, n, Cpad, CoutP, out_stride, cout_valid, relu, 16, 4);
+    if (n == 6 && CoutP % 128 == 0 && Cpad <= 128)  // 4 positions = 9 row tiles, 8 channel tiles
+        return launch_conv_pos_t<9, 8>(st, in, Wp, bias, res, out, B, n, Cpad, CoutP, out_stride, cout_valid, relu, 4, 8);
+    if (n == 5 && CoutP % 128 == 0 && Cpad <= 128)  // 8 positions = 200 rows in 13 row tiles, 8 channel tiles
+        return launch_conv_pos_t<13, 8>(st, in, Wp, bias, res, out, B, n, Cpad, CoutP, out_stride, cout_valid, relu, 8, 8);
     if (CoutP % 128 == 0) return launch_conv_t<2, 2>(st, in, Wp, bias, res, out, M, n, Cpad, CoutP, out_stride, cout_valid, relu);
     return launch_conv_t<2, 1>(st, in, Wp, bias, res, out, M, n, Cpad, CoutP, out_stride, cout_valid, relu);
 }

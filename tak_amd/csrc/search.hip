@@ -84,7 +84,7 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     Search* s = sp.get();
     s->cfg = *cfg;
     const size_t G = (size_t)cfg->games, cap = (size_t)cfg->arena_nodes;
-    const int cin_pad = (e->cin + 7) / 8 * 8;
+    const int cin_pad = e->cin_pad;
     TG_HIP(s->hot.ensure(G * 2 * cap * sizeof(NodeHot)));
     TG_HIP(s->cold.ensure(G * 2 * cap * sizeof(NodeCold)));
     TG_HIP(s->sel.ensure(G));

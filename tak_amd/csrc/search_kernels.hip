@@ -71,9 +71,16 @@ __global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __re
     uint32_t res = TG_ONGOING;
     bool terminal = false;
 
+    // The (visits, virtual, child, n|result) of the node being visited travel in registers: they are read
+    // once for the root and afterwards come out of the children scan of the level above, so each level
+    // costs ONE dependent memory round trip (the coalesced hot + cold records of all children).
+    uint32_t vis, vv, nres, cbase;
+    {
+        NodeHot nh = hot[0];
+        NodeCold nc = cold[0];
+        vis = uni(nh.visits); vv = uni(nh.virt); nres = uni((uint32_t)nc.nres); cbase = uni(nc.child);
+    }
     for (;;) {
-        NodeHot nh = hot[node];
-        uint32_t vis = uni(nh.visits), vv = uni(nh.virt);
         if (vis == 0 && vv == 0) {
             // uninitialised node: initialise it and stop (mcts.rs:41-53)
             res = ws_result(s, geo);
@@ -108,12 +115,10 @@ __global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __re
             terminal = res != TG_ONGOING;
             break;
         }
-        NodeCold nc = cold[node];
-        uint32_t nres = uni(nc.nres);
         res = nres >> 12;
         if (res != TG_ONGOING) { terminal = true; break; }  // known terminal node: same result again (mcts.rs:35-38)
         // ---- select, mcts.rs:94-118 ----
-        const uint32_t nchild = nres & 0xfffu, cbase = uni(nc.child);
+        const uint32_t nchild = nres & 0xfffu;
         const uint32_t nsum = vis + vv;
         const float visit_count = (float)nsum;
         uint32_t ti = nsum;
@@ -123,28 +128,41 @@ __global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __re
         float best = -INFINITY;
         int best_i = -1;
         bool nan = false;
+        NodeHot bh;      // records of this lane's best child
+        NodeCold bc;
+        bh.prior = 0.0f; bh.q = 0.0f; bh.visits = 0; bh.virt = 0;
+        bc.child = 0; bc.mv = 0; bc.nres = 0;
         for (uint32_t i = lane; i < nchild; i += 64) {
             NodeHot ch = hot[cbase + i];
+            NodeCold cc = cold[cbase + i];
             float cn = (float)(ch.visits + ch.virt);
             float qv = (ch.visits | ch.virt) ? (ch.q * (float)ch.visits - (float)ch.virt) / cn : 0.0f;
             float u = qv + c_rate * ch.prior * (root_n / (1.0f + cn));
             if (u != u) nan = true;
-            if (u >= best) { best = u; best_i = (int)i; }
+            if (u >= best) { best = u; best_i = (int)i; bh = ch; bc = cc; }
         }
+        float wb = best;
+        int wi = best_i;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
-            float ob = __shfl_xor(best, d);
-            int oi = __shfl_xor(best_i, d);
-            if (ob > best || (ob == best && oi > best_i)) { best = ob; best_i = oi; }
+            float ob = __shfl_xor(wb, d);
+            int oi = __shfl_xor(wi, d);
+            if (ob > wb || (ob == wb && oi > wi)) { wb = ob; wi = oi; }
         }
         if (__ballot(nan)) flag(S, ERRF_NAN);
-        if (best_i < 0) {  // cannot happen for a consistent tree; never index out of the arena
+        if (wi < 0) {  // cannot happen for a consistent tree; never index out of the arena
             flag(S, ERRF_NAN);
             if (lane == 0) S.leaf_kind[g] = 0;
             return;
         }
-        const uint32_t chosen = cbase + (uint32_t)best_i;
-        const uint32_t mv = uni((uint32_t)cold[chosen].mv);
+        // the winning lane (the one whose own best is the wave's best) hands its child's records down
+        const int src = __builtin_ctzll(__ballot(best_i == wi));
+        const uint32_t chosen = cbase + (uint32_t)wi;
+        const uint32_t mv = uni((uint32_t)__shfl((int)(uint32_t)bc.mv, src));
+        vis = uni((uint32_t)__shfl((int)bh.visits, src));
+        vv = uni((uint32_t)__shfl((int)bh.virt, src));
+        nres = uni((uint32_t)__shfl((int)(uint32_t)bc.nres, src));
+        cbase = uni((uint32_t)__shfl((int)bc.child, src));
         ws_play(s, mv, geo);
         if (depth >= MAX_DEPTH) {
             flag(S, ERRF_DEPTH);

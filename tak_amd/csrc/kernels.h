@@ -19,6 +19,16 @@ void launch_perft_expand(hipStream_t st, const uint8_t* states, int count, int n
 // net_kernels.hip
 hipError_t launch_conv3x3(hipStream_t st, const float* in, const float* Wp, const float* bias, const float* res, float* out,
                           int M, int n, int Cpad, int CoutP, int out_stride, int cout_valid, bool relu);
+// fused residual tower (k_tower): per-layer weight / bias pointers
+struct TowerParams {
+    const float* w[48];   // per layer: Wp[K/16][CoutP][16]
+    const float* b[48];   // per layer: bias[CoutP]
+    int nlayers;          // 1 + 2·R
+    int cin_pad;          // channels of the input planes (layer 0)
+    int F;                // channels of every later layer (= CoutP of every layer)
+};
+bool tower_supported(int n, int F, int cin_pad);
+hipError_t launch_tower(hipStream_t st, const float* in, const TowerParams& T, float* out, int B, int n);
 hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp, const float* bias, float* out, int M, int K,
                        int NP, int out_stride, int n_valid);
 hipError_t launch_value_head(hipStream_t st, const float* act, const float* wv, float bv, int B, int len, float* eval);

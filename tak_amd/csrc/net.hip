@@ -3,6 +3,7 @@
 // softmax) on the engine stream.  Replaces Network<N> of reference alpha-tak/src/model/network.rs:26-35
 // and the concrete Net5 / Net6 (model/net5.rs, net6.rs, res_block.rs) without any tch type.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "engine.h"
@@ -29,6 +30,8 @@ struct Net {
     float value_b = 0.0f;
     // activations (max_batch positions)
     DevBuf x, y, logits, planes_nhwc, planes_nchw;
+    bool fused = false;  // whole tower in one launch (k_tower)
+    TowerParams tower;
     // measurement hooks (tg_profile_*)
     int prof_every = 0;
     uint64_t prof_counter = 0;
@@ -206,6 +209,16 @@ int net_finalize(TgEngine* e) {
         TG_HIP(n->value_w.ensure(K * 4));
         TG_HIP(hipMemcpy(n->value_w.p, wv.data(), K * 4, hipMemcpyHostToDevice));
     }
+    n->fused = tower_supported(e->g.n, F, n->cin_pad) && 1 + 2 * R <= 48 && !getenv("TG_NO_FUSED_TOWER");
+    if (n->fused) {
+        TowerParams& T = n->tower;
+        T.nlayers = 1 + 2 * R; T.cin_pad = n->cin_pad; T.F = F;
+        T.w[0] = n->conv0.w.as<float>(); T.b[0] = n->conv0.b.as<float>();
+        for (int i = 0; i < R; i++) {
+            T.w[1 + 2 * i] = n->res1[i].w.as<float>(); T.b[1 + 2 * i] = n->res1[i].b.as<float>();
+            T.w[2 + 2 * i] = n->res2[i].w.as<float>(); T.b[2 + 2 * i] = n->res2[i].b.as<float>();
+        }
+    }
     size_t mb = (size_t)e->cfg.max_batch;
     TG_HIP(n->x.ensure(mb * nsq * F * 4));
     TG_HIP(n->y.ensure(mb * nsq * F * 4));
@@ -236,19 +249,26 @@ int net_forward_dev(TgEngine* e, int nb, const float* d_planes, float* d_policy,
         n->ev_chains.emplace_back();
         chain = &n->ev_chains.back();
         n->conv_rows = M;
-        n->conv_flops = 2ll * M * 9 * F * F;
+        // algorithmic FLOPs of one timed launch: one F→F conv (per-layer path) or the whole tower (fused)
+        n->conv_flops = n->fused ? 2ll * M * 9 * ((long long)n->cin * F + 2ll * n->R * F * F) : 2ll * M * 9 * F * F;
         chain->push_back(prof_event(n, st));
     }
-    TG_HIP(launch_conv3x3(st, d_planes, n->conv0.w.as<float>(), n->conv0.b.as<float>(), nullptr, x, M, N, n->cin_pad,
-                          n->conv0.cout_pad, F, F, true));
-    if (chain) chain->push_back(prof_event(n, st));
-    for (int i = 0; i < n->R; i++) {
-        TG_HIP(launch_conv3x3(st, x, n->res1[i].w.as<float>(), n->res1[i].b.as<float>(), nullptr, y, M, N, F,
-                              n->res1[i].cout_pad, F, F, true));
+    if (n->fused) {
         if (chain) chain->push_back(prof_event(n, st));
-        TG_HIP(launch_conv3x3(st, y, n->res2[i].w.as<float>(), n->res2[i].b.as<float>(), x, x, M, N, F,
-                              n->res2[i].cout_pad, F, F, true));
+        TG_HIP(launch_tower(st, d_planes, n->tower, x, nb, N));
         if (chain) chain->push_back(prof_event(n, st));
+    } else {
+        TG_HIP(launch_conv3x3(st, d_planes, n->conv0.w.as<float>(), n->conv0.b.as<float>(), nullptr, x, M, N, n->cin_pad,
+                              n->conv0.cout_pad, F, F, true));
+        if (chain) chain->push_back(prof_event(n, st));
+        for (int i = 0; i < n->R; i++) {
+            TG_HIP(launch_conv3x3(st, x, n->res1[i].w.as<float>(), n->res1[i].b.as<float>(), nullptr, y, M, N, F,
+                                  n->res1[i].cout_pad, F, F, true));
+            if (chain) chain->push_back(prof_event(n, st));
+            TG_HIP(launch_conv3x3(st, y, n->res2[i].w.as<float>(), n->res2[i].b.as<float>(), x, x, M, N, F,
+                                  n->res2[i].cout_pad, F, F, true));
+            if (chain) chain->push_back(prof_event(n, st));
+        }
     }
     float* logits = n->logits.as<float>();
     if (e->cfg.policy_head == TG_HEAD_CONV) {

@@ -269,6 +269,135 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_pos(const float* __restric
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fused residual tower: conv0 + R × (conv1, conv2 + skip) in ONE launch.  A workgroup keeps its PW
+// positions in LDS for the whole tower: each layer's MFMA loop reads the padded NHWC image of the
+// previous layer from LDS, the epilogue (bias, ReLU, skip) runs on the accumulators, and — behind a
+// barrier — the wave writes its 16-channel slice straight back into the same LDS image for the next
+// layer.  The skip connection never leaves registers (each wave keeps the block input of exactly the
+// tiles it produces).  Only the input planes are read from HBM and only the final activations are
+// written (for the policy / value heads); per layer the only global traffic is the L2-resident weights.
+// ------------------------------------------------------------------------------------------------
+template <int RTW, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__ in, TowerParams T, float* __restrict__ out,
+                                                       int B, int n, int PW, int CTW) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    f32x4* lds4 = (f32x4*)lds;
+    const int tid = threadIdx.x;
+    const int nsq = n * n;
+    const int pos0 = blockIdx.x * PW;
+    const int npos = min(PW, B - pos0);
+    const int rows = npos * nsq;
+    const int F = T.F;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int ct = wave % CTW, rg = wave / CTW;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int ch0 = ct * 16;
+
+    // ---- stage the input planes (row pitch cin_pad + 4) ----
+    int Cpad = T.cin_pad;
+    int LS4 = (Cpad + LDS_PAD) >> 2;
+    {
+        const int vpr = Cpad >> 2;
+        const f32x4* src = (const f32x4*)(in + (size_t)pos0 * nsq * Cpad);
+        const int total = rows * vpr;
+        for (int idx = tid; idx < total; idx += NWAVES * 64) {
+            int r = idx / vpr, v = idx - r * vpr;
+            lds4[r * LS4 + v] = src[idx];
+        }
+        for (int idx = tid; idx < LS4; idx += NWAVES * 64) lds4[rows * LS4 + idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    __syncthreads();
+
+    int pyx[RTW], rrow[RTW];
+#pragma unroll
+    for (int j = 0; j < RTW; j++) {
+        int rho = (rg * RTW + j) * 16 + r16;
+        bool valid = rho < rows;
+        int rr = valid ? rho : 0;
+        int p = rr / nsq;
+        int sq = rr - p * nsq;
+        int y = sq / n, x = sq - y * n;
+        pyx[j] = valid ? (y | (x << 8)) : 0x7f7f;
+        rrow[j] = valid ? rho : -1;
+    }
+
+    f32x4 skip[RTW];  // block input of this wave's own output tiles
+#pragma unroll
+    for (int j = 0; j < RTW; j++) skip[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    for (int layer = 0; layer < T.nlayers; layer++) {
+        const int zero4 = rows * LS4 + q;
+        f32x4 acc[RTW];
+#pragma unroll
+        for (int j = 0; j < RTW; j++) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const int chunks = Cpad >> 4;
+        const int total_chunks = 9 * chunks;
+        const f32x4* wp = (const f32x4*)T.w[layer] + ((size_t)(ch0 + r16) * 4 + q);
+        const size_t wstride4 = (size_t)F * 4;
+        f32x4 w_cur = wp[0];
+        int kk = 0;
+        for (int tap = 0; tap < 9; tap++) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            int aoff[RTW];
+#pragma unroll
+            for (int j = 0; j < RTW; j++) {
+                int yy = (pyx[j] & 0xff) + dy, xx = (pyx[j] >> 8) + dx;
+                bool ok = yy >= 0 && yy < n && xx >= 0 && xx < n;
+                aoff[j] = ok ? (rrow[j] + dy * n + dx) * LS4 + q : zero4;
+            }
+            f32x4 a_cur[RTW];
+#pragma unroll
+            for (int j = 0; j < RTW; j++) a_cur[j] = lds4[aoff[j]];
+            for (int kc = 0; kc < chunks; kc++) {
+                const int kkn = kk + 1 < total_chunks ? kk + 1 : kk;
+                const f32x4 w_nxt = wp[(size_t)kkn * wstride4];
+                const int kn = kc + 1 < chunks ? kc + 1 : kc;
+                f32x4 a_nxt[RTW];
+#pragma unroll
+                for (int j = 0; j < RTW; j++) a_nxt[j] = lds4[aoff[j] + kn * 4];
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int j = 0; j < RTW; j++)
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_cur[t], a_cur[j][t], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < RTW; j++) a_cur[j] = a_nxt[j];
+                w_cur = w_nxt;
+                kk++;
+            }
+        }
+        // ---- epilogue on the accumulators: lane holds out[row][ch0 + 4q .. 4q+3] ----
+        const f32x4 bv = *(const f32x4*)&T.b[layer][ch0 + 4 * q];
+        const bool add_skip = layer > 0 && (layer & 1) == 0;   // conv2 of a block
+        const bool save_skip = (layer & 1) == 0;               // conv0 output / block output = next block input
+#pragma unroll
+        for (int j = 0; j < RTW; j++) {
+            f32x4 v = acc[j] + bv;
+            if (add_skip) v += skip[j];
+            v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f);
+            acc[j] = v;
+            if (save_skip) skip[j] = v;
+        }
+        if (layer + 1 == T.nlayers) {
+#pragma unroll
+            for (int j = 0; j < RTW; j++)
+                if (rrow[j] >= 0) *(f32x4*)&out[((size_t)pos0 * nsq + rrow[j]) * F + ch0 + 4 * q] = acc[j];
+            break;
+        }
+        __syncthreads();  // every wave has finished reading the previous image
+        Cpad = F;
+        LS4 = (F + LDS_PAD) >> 2;
+#pragma unroll
+        for (int j = 0; j < RTW; j++)
+            if (rrow[j] >= 0) lds4[rrow[j] * LS4 + (ch0 >> 2) + q] = acc[j];
+        if (layer == 0)
+            for (int idx = tid; idx < LS4; idx += NWAVES * 64) lds4[rows * LS4 + idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        __syncthreads();
+    }
+}
+
 // Plain GEMM out[M][N] = A[M][K]·W[K][N] + bias for the 5×5 policy FC (net5.rs:56-61,108): the same
 // fragments, A staged through LDS in K-chunks of 32.
 template <int RT, int CT>
@@ -475,6 +604,35 @@ hipError_t launch_conv3x3(hipStream_t st, const float* in, const float* Wp, cons
         return launch_conv_pos_t<13, 8>(st, in, Wp, bias, res, out, B, n, Cpad, CoutP, out_stride, cout_valid, relu, 8, 8);
     if (CoutP % 128 == 0) return launch_conv_t<2, 2>(st, in, Wp, bias, res, out, M, n, Cpad, CoutP, out_stride, cout_valid, relu);
     return launch_conv_t<2, 1>(st, in, Wp, bias, res, out, M, n, Cpad, CoutP, out_stride, cout_valid, relu);
+}
+
+
+template <int RTW, int NWAVES>
+static hipError_t launch_tower_t(hipStream_t st, const float* in, const TowerParams& T, float* out, int B, int n, int PW, int CTW) {
+    int cmax = T.cin_pad > T.F ? T.cin_pad : T.F;
+    size_t lds = (size_t)(PW * n * n + 1) * (cmax + LDS_PAD) * sizeof(float);
+    static size_t configured = 0;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_tower<RTW, NWAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    hipLaunchKernelGGL((k_tower<RTW, NWAVES>), dim3((B + PW - 1) / PW), dim3(NWAVES * 64), lds, st, in, T, out, B, n, PW, CTW);
+    return hipGetLastError();
+}
+
+bool tower_supported(int n, int F, int cin_pad) {
+    if (n == 5 && F == 64 && cin_pad <= 80) return true;
+    if (n == 6 && F == 128 && cin_pad <= 128) return true;
+    if (n == 5 && F == 128 && cin_pad <= 128) return true;
+    return false;
+}
+
+hipError_t launch_tower(hipStream_t st, const float* in, const TowerParams& T, float* out, int B, int n) {
+    if (n == 5 && T.F == 64) return launch_tower_t<13, 8>(st, in, T, out, B, n, 16, 4);
+    if (n == 6 && T.F == 128) return launch_tower_t<9, 8>(st, in, T, out, B, n, 4, 8);
+    if (n == 5 && T.F == 128) return launch_tower_t<13, 8>(st, in, T, out, B, n, 8, 8);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp, const float* bias, float* out, int M, int K,

@@ -181,7 +181,9 @@ int net_finalize(TgEngine* e) {
         auto w = find(n, "policy.weight", (size_t)P * K, err);
         auto b = w ? find(n, "policy.bias", P, err) : nullptr;
         if (!b) return fail(TG_ERR_WEIGHTS, err);
-        int NP = round_up(P, 64);
+        // 13 output tiles of 16 per workgroup column (k_fc_lds): 1575 → 1664 = 8·208; 208 is also a multiple of
+        // nothing the generic k_gemm needs, so shapes with K % 64 != 0 keep the 64-wide padding
+        int NP = (K % 64 == 0) ? round_up(P, 208) : round_up(P, 64);
         std::vector<float> wp(K * NP, 0.0f), bp(NP, 0.0f);
         for (int o = 0; o < P; o++) {
             bp[o] = (*b)[o];

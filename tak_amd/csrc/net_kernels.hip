@@ -142,6 +142,71 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, c
 }
 
 
+
+// Implicit-GEMM main loop shared by k_conv_pos / k_tower: RTW row tiles × one 16-channel tile, K = 9·Cpad.
+// The row tiles are split in two halves that are reloaded in place, so that the LDS reads of one half are
+// in flight while the MFMAs of the other half issue (no second register set, no copies):
+//     load H2(k) | MFMA H1(k) | load H1(k+1), w(k+1) | MFMA H2(k)
+// rho0 = first row of this wave's tile 0 for this lane; rows ≥ `rows` are invalid (all taps read zeros).
+template <int RTW>
+__device__ __forceinline__ void conv_mainloop(const f32x4* __restrict__ lds4, const f32x4* __restrict__ wp, size_t wstride4,
+                                              int Cpad, int LS4, int rows, int n, int nsq, int rho0, int q, f32x4 (&acc)[RTW]) {
+    constexpr int H1 = (RTW + 1) / 2;
+    const int chunks = Cpad >> 4;
+    const int total = 9 * chunks;
+    const int zero4 = rows * LS4 + q;
+    int pyx[RTW];
+#pragma unroll
+    for (int j = 0; j < RTW; j++) {
+        int rho = rho0 + j * 16;
+        int p = rho / nsq;
+        int sq = rho - p * nsq;
+        int y = sq / n, x = sq - y * n;
+        pyx[j] = rho < rows ? (y | (x << 8)) : 0x7f7f;
+    }
+    int aoff[RTW];
+    auto set_tap = [&](int tap) {
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+        for (int j = 0; j < RTW; j++) {
+            int yy = (pyx[j] & 0xff) + dy, xx = (pyx[j] >> 8) + dx;
+            bool ok = yy >= 0 && yy < n && xx >= 0 && xx < n;
+            aoff[j] = ok ? (rho0 + j * 16 + dy * n + dx) * LS4 + q : zero4;
+        }
+    };
+    f32x4 a[RTW];
+    set_tap(0);
+#pragma unroll
+    for (int j = 0; j < H1; j++) a[j] = lds4[aoff[j]];
+    f32x4 w = wp[0];
+    int tap = 0, kc = 0;
+    for (int s = 0; s < total; s++) {
+#pragma unroll
+        for (int j = H1; j < RTW; j++) a[j] = lds4[aoff[j] + kc * 4];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int j = 0; j < H1; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t], a[j][t], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // advance to step s+1 and prefetch its first half + weights
+        kc++;
+        if (kc == chunks) { kc = 0; tap++; if (tap < 9) set_tap(tap); }
+        const f32x4 wn = wp[(size_t)(s + 1 < total ? s + 1 : s) * wstride4];
+        if (s + 1 < total) {
+#pragma unroll
+            for (int j = 0; j < H1; j++) a[j] = lds4[aoff[j] + kc * 4];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int j = H1; j < RTW; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t], a[j][t], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        w = wn;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Whole-positions variant: a workgroup owns PW complete positions (PW·N² rows, e.g. 16 positions = 400
 // rows = 25 row tiles on 5×5; 4 positions = 144 rows = 9 tiles on 6×6) and CTW 16-wide channel tiles, so
@@ -310,64 +375,18 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
     }
     __syncthreads();
 
-    int pyx[RTW], rrow[RTW];
-#pragma unroll
-    for (int j = 0; j < RTW; j++) {
-        int rho = (rg * RTW + j) * 16 + r16;
-        bool valid = rho < rows;
-        int rr = valid ? rho : 0;
-        int p = rr / nsq;
-        int sq = rr - p * nsq;
-        int y = sq / n, x = sq - y * n;
-        pyx[j] = valid ? (y | (x << 8)) : 0x7f7f;
-        rrow[j] = valid ? rho : -1;
-    }
+    const int rho0 = rg * RTW * 16 + r16;
 
     f32x4 skip[RTW];  // block input of this wave's own output tiles
 #pragma unroll
     for (int j = 0; j < RTW; j++) skip[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     for (int layer = 0; layer < T.nlayers; layer++) {
-        const int zero4 = rows * LS4 + q;
         f32x4 acc[RTW];
 #pragma unroll
         for (int j = 0; j < RTW; j++) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        const int chunks = Cpad >> 4;
-        const int total_chunks = 9 * chunks;
         const f32x4* wp = (const f32x4*)T.w[layer] + ((size_t)(ch0 + r16) * 4 + q);
-        const size_t wstride4 = (size_t)F * 4;
-        f32x4 w_cur = wp[0];
-        int kk = 0;
-        for (int tap = 0; tap < 9; tap++) {
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            int aoff[RTW];
-#pragma unroll
-            for (int j = 0; j < RTW; j++) {
-                int yy = (pyx[j] & 0xff) + dy, xx = (pyx[j] >> 8) + dx;
-                bool ok = yy >= 0 && yy < n && xx >= 0 && xx < n;
-                aoff[j] = ok ? (rrow[j] + dy * n + dx) * LS4 + q : zero4;
-            }
-            f32x4 a_cur[RTW];
-#pragma unroll
-            for (int j = 0; j < RTW; j++) a_cur[j] = lds4[aoff[j]];
-            for (int kc = 0; kc < chunks; kc++) {
-                const int kkn = kk + 1 < total_chunks ? kk + 1 : kk;
-                const f32x4 w_nxt = wp[(size_t)kkn * wstride4];
-                const int kn = kc + 1 < chunks ? kc + 1 : kc;
-                f32x4 a_nxt[RTW];
-#pragma unroll
-                for (int j = 0; j < RTW; j++) a_nxt[j] = lds4[aoff[j] + kn * 4];
-#pragma unroll
-                for (int t = 0; t < 4; t++)
-#pragma unroll
-                    for (int j = 0; j < RTW; j++)
-                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_cur[t], a_cur[j][t], acc[j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < RTW; j++) a_cur[j] = a_nxt[j];
-                w_cur = w_nxt;
-                kk++;
-            }
-        }
+        conv_mainloop<RTW>(lds4, wp, (size_t)F * 4, Cpad, LS4, rows, n, nsq, rho0, q, acc);
         // ---- epilogue on the accumulators: lane holds out[row][ch0 + 4q .. 4q+3] ----
         const f32x4 bv = *(const f32x4*)&T.b[layer][ch0 + 4 * q];
         const bool add_skip = layer > 0 && (layer & 1) == 0;   // conv2 of a block
@@ -383,7 +402,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
         if (layer + 1 == T.nlayers) {
 #pragma unroll
             for (int j = 0; j < RTW; j++)
-                if (rrow[j] >= 0) *(f32x4*)&out[((size_t)pos0 * nsq + rrow[j]) * F + ch0 + 4 * q] = acc[j];
+                if (rho0 + j * 16 < rows) *(f32x4*)&out[((size_t)pos0 * nsq + rho0 + j * 16) * F + ch0 + 4 * q] = acc[j];
             break;
         }
         __syncthreads();  // every wave has finished reading the previous image
@@ -391,7 +410,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
         LS4 = (F + LDS_PAD) >> 2;
 #pragma unroll
         for (int j = 0; j < RTW; j++)
-            if (rrow[j] >= 0) lds4[rrow[j] * LS4 + (ch0 >> 2) + q] = acc[j];
+            if (rho0 + j * 16 < rows) lds4[(rho0 + j * 16) * LS4 + (ch0 >> 2) + q] = acc[j];
         if (layer == 0)
             for (int idx = tid; idx < LS4; idx += NWAVES * 64) lds4[rows * LS4 + idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         __syncthreads();
@@ -474,6 +493,94 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
                 if (m < M && col < n_valid) out[(size_t)m * out_stride + col] = acc[rt][ct][r] + bv;
             }
         }
+}
+
+
+// Policy FC (net5.rs:56-61,108) for the BASELINE shape M = 4096, K = 1600, N = 1575: workgroup tile
+// 128 rows × 208 outputs (13 MFMA tiles) → 32 × 8 = 256 workgroups, one per CU.  Wave w owns row tile w
+// (16 positions) and all 13 output tiles.  The weights (shared by the 8 waves) are staged global → LDS
+// in K-steps of 64, double buffered, in four 16-byte-slot planes (one per k-quarter) so that a wave's 16
+// lanes of one plane hit 16 different bank groups: conflict-free ds_read_b128.  The wave's own 16
+// activation rows are the MFMA B operand, read straight from global one chunk ahead.
+constexpr int FC_CT = 13;            // output tiles per workgroup
+constexpr int FC_COLS = FC_CT * 16;  // 208
+constexpr int FC_KSTEP = 64;         // 4 chunks of 16
+constexpr int FC_PLANE = (FC_KSTEP / 16) * FC_COLS;  // 832 slots per k-quarter plane (≡ 0 mod 16)
+
+__global__ __launch_bounds__(512) void k_fc_lds(const float* __restrict__ A, int lda, const float* __restrict__ Wp,
+                                                const float* __restrict__ bias, float* __restrict__ out, int M, int K, int NP,
+                                                int out_stride, int n_valid) {
+    __shared__ f32x4 wl[2][4][FC_PLANE];  // [buffer][k-quarter][chunk*208 + col]  = 106.5 KB
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int row = blockIdx.x * 128 + wave * 16 + r16;
+    const bool row_ok = row < M;
+    const int n0 = blockIdx.y * FC_COLS;
+    const f32x4* ap = (const f32x4*)(A + (size_t)(row_ok ? row : 0) * lda) + q;
+    const f32x4* wg = (const f32x4*)Wp;  // slot (chunk, col, q) at (chunk*NP + col)*4 + q
+    const int nsteps = K / FC_KSTEP;
+
+    // staging assignment: 4 planes × 832 slots = 3328 slots per step, 7 per thread (the last partly idle)
+    auto stage_load = [&](int step, f32x4 (&r)[7]) {
+#pragma unroll
+        for (int u = 0; u < 7; u++) {
+            int idx = u * 512 + tid;
+            if (idx < 4 * FC_PLANE) {
+                int qq = idx / FC_PLANE, rem = idx - qq * FC_PLANE;
+                int c = rem / FC_COLS, col = rem - c * FC_COLS;
+                r[u] = wg[((size_t)(step * 4 + c) * NP + n0 + col) * 4 + qq];
+            }
+        }
+    };
+    auto stage_store = [&](int buf, const f32x4 (&r)[7]) {
+#pragma unroll
+        for (int u = 0; u < 7; u++) {
+            int idx = u * 512 + tid;
+            if (idx < 4 * FC_PLANE) (&wl[buf][0][0])[idx] = r[u];
+        }
+    };
+
+    f32x4 acc[FC_CT];
+#pragma unroll
+    for (int j = 0; j < FC_CT; j++) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 stg[7];
+    stage_load(0, stg);
+    stage_store(0, stg);
+    f32x4 a_cur = row_ok ? ap[0] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    __syncthreads();
+    for (int step = 0; step < nsteps; step++) {
+        const int buf = step & 1;
+        if (step + 1 < nsteps) stage_load(step + 1, stg);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int kc = step * 4 + c;
+            const int kn = kc + 1 < nsteps * 4 ? kc + 1 : kc;
+            const f32x4 a_nxt = row_ok ? ap[(size_t)kn * 4] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            f32x4 w[FC_CT];
+#pragma unroll
+            for (int j = 0; j < FC_CT; j++) w[j] = wl[buf][q][c * FC_COLS + j * 16 + r16];
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int j = 0; j < FC_CT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j][t], a_cur[t], acc[j], 0, 0, 0);
+            a_cur = a_nxt;
+        }
+        if (step + 1 < nsteps) stage_store(buf ^ 1, stg);
+        __syncthreads();
+    }
+    if (row_ok) {
+#pragma unroll
+        for (int j = 0; j < FC_CT; j++) {
+            const int nn = n0 + j * 16 + 4 * q;
+            if (nn < n_valid) {
+                f32x4 v = acc[j] + *(const f32x4*)&bias[nn];
+                float* o = out + (size_t)row * out_stride + nn;
+                if (nn + 3 < n_valid) *(f32x4*)o = v;
+                else for (int t = 0; t < 4; t++) if (nn + t < n_valid) o[t] = v[t];
+            }
+        }
+    }
 }
 
 __device__ inline float wave_sum(float v) {
@@ -637,6 +744,11 @@ hipError_t launch_tower(hipStream_t st, const float* in, const TowerParams& T, f
 
 hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp, const float* bias, float* out, int M, int K,
                        int NP, int out_stride, int n_valid) {
+    if (NP % FC_COLS == 0 && K % FC_KSTEP == 0) {
+        dim3 grid((M + 127) / 128, NP / FC_COLS);
+        hipLaunchKernelGGL(k_fc_lds, grid, dim3(512), 0, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid);
+        return hipGetLastError();
+    }
     dim3 grid((M + 127) / 128, NP / 64);
     hipLaunchKernelGGL((k_gemm<2, 1>), grid, dim3(256), 0, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid);
     return hipGetLastError();

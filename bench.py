@@ -182,7 +182,7 @@ def main():
                 except Exception:
                     traffic = None
             out["roofline"] = {
-                "bound": "mfma", "kernel": "k_conv3x3<2,1> (3x3 conv F->F, f32 MFMA 32x32x2)",
+                "bound": "mfma", "kernel": "k_tower (fused conv0 + residual tower, f32 MFMA 16x16x4; one launch = 1+2R 3x3 convs)",
                 "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
                 "traffic": traffic, "avg_launch_ms": avg_ms, "launches_timed": prof["conv_launches"],
                 "flops_per_launch": prof["conv_flops"], "rows_per_launch": prof["conv_rows"],

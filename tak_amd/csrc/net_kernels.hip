@@ -17,14 +17,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "conv_mainloop.cuh"
 #include "kernels.h"
 
 namespace tg {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-constexpr int LDS_PAD = 4;  // floats appended to every LDS row: consecutive rows shift by 4 banks
 
 // Workgroup = 4 waves as 2 (rows) × 2 (cols); each wave owns RT×CT tiles of 32×32.
 template <int RT, int CT>
@@ -142,70 +139,6 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ in, c
 }
 
 
-
-// Implicit-GEMM main loop shared by k_conv_pos / k_tower: RTW row tiles × one 16-channel tile, K = 9·Cpad.
-// The row tiles are split in two halves that are reloaded in place, so that the LDS reads of one half are
-// in flight while the MFMAs of the other half issue (no second register set, no copies):
-//     load H2(k) | MFMA H1(k) | load H1(k+1), w(k+1) | MFMA H2(k)
-// rho0 = first row of this wave's tile 0 for this lane; rows ≥ `rows` are invalid (all taps read zeros).
-template <int RTW>
-__device__ __forceinline__ void conv_mainloop(const f32x4* __restrict__ lds4, const f32x4* __restrict__ wp, size_t wstride4,
-                                              int Cpad, int LS4, int rows, int n, int nsq, int rho0, int q, f32x4 (&acc)[RTW]) {
-    constexpr int H1 = (RTW + 1) / 2;
-    const int chunks = Cpad >> 4;
-    const int total = 9 * chunks;
-    const int zero4 = rows * LS4 + q;
-    int pyx[RTW];
-#pragma unroll
-    for (int j = 0; j < RTW; j++) {
-        int rho = rho0 + j * 16;
-        int p = rho / nsq;
-        int sq = rho - p * nsq;
-        int y = sq / n, x = sq - y * n;
-        pyx[j] = rho < rows ? (y | (x << 8)) : 0x7f7f;
-    }
-    int aoff[RTW];
-    auto set_tap = [&](int tap) {
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-#pragma unroll
-        for (int j = 0; j < RTW; j++) {
-            int yy = (pyx[j] & 0xff) + dy, xx = (pyx[j] >> 8) + dx;
-            bool ok = yy >= 0 && yy < n && xx >= 0 && xx < n;
-            aoff[j] = ok ? (rho0 + j * 16 + dy * n + dx) * LS4 + q : zero4;
-        }
-    };
-    f32x4 a[RTW];
-    set_tap(0);
-#pragma unroll
-    for (int j = 0; j < H1; j++) a[j] = lds4[aoff[j]];
-    f32x4 w = wp[0];
-    int tap = 0, kc = 0;
-    for (int s = 0; s < total; s++) {
-#pragma unroll
-        for (int j = H1; j < RTW; j++) a[j] = lds4[aoff[j] + kc * 4];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int j = 0; j < H1; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t], a[j][t], acc[j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        // advance to step s+1 and prefetch its first half + weights
-        kc++;
-        if (kc == chunks) { kc = 0; tap++; if (tap < 9) set_tap(tap); }
-        const f32x4 wn = wp[(size_t)(s + 1 < total ? s + 1 : s) * wstride4];
-        if (s + 1 < total) {
-#pragma unroll
-            for (int j = 0; j < H1; j++) a[j] = lds4[aoff[j] + kc * 4];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int j = H1; j < RTW; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t], a[j][t], acc[j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        w = wn;
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // Whole-positions variant: a workgroup owns PW complete positions (PW·N² rows, e.g. 16 positions = 400
@@ -344,7 +277,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_pos(const float* __restric
 // tiles it produces).  Only the input planes are read from HBM and only the final activations are
 // written (for the policy / value heads); per layer the only global traffic is the L2-resident weights.
 // ------------------------------------------------------------------------------------------------
-template <int RTW, int NWAVES>
+template <int RTW, int NWAVES, int CH0, int CH>
 __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__ in, TowerParams T, float* __restrict__ out,
                                                        int B, int n, int PW, int CTW) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -377,27 +310,38 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
 
     const int rho0 = rg * RTW * 16 + r16;
 
-    f32x4 skip[RTW];  // block input of this wave's own output tiles
-#pragma unroll
-    for (int j = 0; j < RTW; j++) skip[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
+    // The skip connection (block input of exactly the tiles this lane produces) is parked in the output
+    // buffer between conv1 and conv2 of a block: same lane, same addresses, so program order makes it visible.
     for (int layer = 0; layer < T.nlayers; layer++) {
         f32x4 acc[RTW];
 #pragma unroll
         for (int j = 0; j < RTW; j++) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         const f32x4* wp = (const f32x4*)T.w[layer] + ((size_t)(ch0 + r16) * 4 + q);
-        conv_mainloop<RTW>(lds4, wp, (size_t)F * 4, Cpad, LS4, rows, n, nsq, rho0, q, acc);
+        if (layer == 0) conv_mainloop<RTW, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, nsq, rho0, q, acc);
+        else conv_mainloop<RTW, CH>(lds4, wp, (size_t)F * 4, LS4, rows, n, nsq, rho0, q, acc);
+        asm volatile("" ::: "memory");  // keep the skip loads below out of the main loop's register budget
         // ---- epilogue on the accumulators: lane holds out[row][ch0 + 4q .. 4q+3] ----
         const f32x4 bv = *(const f32x4*)&T.b[layer][ch0 + 4 * q];
         const bool add_skip = layer > 0 && (layer & 1) == 0;   // conv2 of a block
-        const bool save_skip = (layer & 1) == 0;               // conv0 output / block output = next block input
+        const bool save_skip = (layer & 1) == 0 && layer + 1 < T.nlayers;  // conv0 output / block output = next block input
+        float* skip_ptr = out + ((size_t)pos0 * nsq + rho0) * F + ch0 + 4 * q;
+        if (add_skip) {
+            f32x4 sk[RTW];
+#pragma unroll
+            for (int j = 0; j < RTW; j++) sk[j] = rho0 + j * 16 < rows ? *(const f32x4*)(skip_ptr + (size_t)j * 16 * F) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < RTW; j++) acc[j] += sk[j];
+        }
 #pragma unroll
         for (int j = 0; j < RTW; j++) {
             f32x4 v = acc[j] + bv;
-            if (add_skip) v += skip[j];
             v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f);
             acc[j] = v;
-            if (save_skip) skip[j] = v;
+        }
+        if (save_skip) {
+#pragma unroll
+            for (int j = 0; j < RTW; j++)
+                if (rho0 + j * 16 < rows) *(f32x4*)(skip_ptr + (size_t)j * 16 * F) = acc[j];
         }
         if (layer + 1 == T.nlayers) {
 #pragma unroll
@@ -714,31 +658,31 @@ hipError_t launch_conv3x3(hipStream_t st, const float* in, const float* Wp, cons
 }
 
 
-template <int RTW, int NWAVES>
+template <int RTW, int NWAVES, int CH0, int CH>
 static hipError_t launch_tower_t(hipStream_t st, const float* in, const TowerParams& T, float* out, int B, int n, int PW, int CTW) {
     int cmax = T.cin_pad > T.F ? T.cin_pad : T.F;
     size_t lds = (size_t)(PW * n * n + 1) * (cmax + LDS_PAD) * sizeof(float);
     static size_t configured = 0;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_tower<RTW, NWAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_tower<RTW, NWAVES, CH0, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    hipLaunchKernelGGL((k_tower<RTW, NWAVES>), dim3((B + PW - 1) / PW), dim3(NWAVES * 64), lds, st, in, T, out, B, n, PW, CTW);
+    hipLaunchKernelGGL((k_tower<RTW, NWAVES, CH0, CH>), dim3((B + PW - 1) / PW), dim3(NWAVES * 64), lds, st, in, T, out, B, n, PW, CTW);
     return hipGetLastError();
 }
 
 bool tower_supported(int n, int F, int cin_pad) {
-    if (n == 5 && F == 64 && cin_pad <= 80) return true;
-    if (n == 6 && F == 128 && cin_pad <= 128) return true;
-    if (n == 5 && F == 128 && cin_pad <= 128) return true;
+    if (n == 5 && F == 64 && cin_pad == 80) return true;   // config C2
+    if (n == 6 && F == 128 && cin_pad == 96) return true;  // config C3
+    if (n == 5 && F == 128 && cin_pad == 80) return true;  // config C5 network
     return false;
 }
 
 hipError_t launch_tower(hipStream_t st, const float* in, const TowerParams& T, float* out, int B, int n) {
-    if (n == 5 && T.F == 64) return launch_tower_t<13, 8>(st, in, T, out, B, n, 16, 4);
-    if (n == 6 && T.F == 128) return launch_tower_t<9, 8>(st, in, T, out, B, n, 4, 8);
-    if (n == 5 && T.F == 128) return launch_tower_t<13, 8>(st, in, T, out, B, n, 8, 8);
+    if (n == 5 && T.F == 64 && T.cin_pad == 80) return launch_tower_t<13, 8, 5, 4>(st, in, T, out, B, n, 16, 4);
+    if (n == 6 && T.F == 128 && T.cin_pad == 96) return launch_tower_t<9, 8, 6, 8>(st, in, T, out, B, n, 4, 8);
+    if (n == 5 && T.F == 128 && T.cin_pad == 80) return launch_tower_t<13, 8, 5, 8>(st, in, T, out, B, n, 8, 8);
     return hipErrorInvalidValue;
 }
 

@@ -74,4 +74,86 @@ __device__ __forceinline__ void conv_mainloop(const f32x4* __restrict__ lds4, co
     }
 }
 
+
+// Variant 2: explicit half-tile software pipeline that also runs across tap boundaries.
+//     load H2(s) | MFMA H1(s) | load H1(s+1), w(s+2) | MFMA H2(s)
+// The two halves of the row tiles are reloaded in place (no second register set); the tap offsets of a half are
+// refreshed (3 VALU per tile) right before that half's first load of the new tap.
+template <int RTW, int CH>
+__device__ __forceinline__ void conv_mainloop_v2(const f32x4* __restrict__ lds4, const f32x4* __restrict__ wp, size_t wstride4,
+                                                 int LS4, int rows, int n, int nsq, int rho0, int q, f32x4 (&acc)[RTW]) {
+    constexpr int total = 9 * CH;
+    constexpr int H1 = (RTW + 1) / 2;
+    const int zero4 = rows * LS4 + q;
+    int vmask[RTW];
+#pragma unroll
+    for (int j = 0; j < RTW; j++) {
+        int rho = rho0 + j * 16;
+        int p = rho / nsq;
+        int sq = rho - p * nsq;
+        int y = sq / n, x = sq - y * n;
+        int m = 0;
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (yy >= 0 && yy < n && xx >= 0 && xx < n) m |= 1 << t;
+        }
+        vmask[j] = rho < rows ? m : 0;
+    }
+    const int base0 = rho0 * LS4 + q;
+    int aoff[RTW];
+    auto tap_shift = [&](int tap) { return ((tap / 3 - 1) * n + (tap % 3 - 1)) * LS4; };
+    {
+        const int sh = tap_shift(0);
+#pragma unroll
+        for (int j = 0; j < RTW; j++) aoff[j] = (vmask[j] & 1) ? base0 + j * 16 * LS4 + sh : zero4;
+    }
+    f32x4 a[RTW];
+#pragma unroll
+    for (int j = 0; j < H1; j++) a[j] = lds4[aoff[j]];
+    f32x4 w0 = wp[0];
+    f32x4 w1 = wp[wstride4];
+    int kk = 0;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; tap++) {
+#pragma unroll
+        for (int kc = 0; kc < CH; kc++) {
+            if (kc == 0 && tap > 0) {
+                const int sh = tap_shift(tap);
+#pragma unroll
+                for (int j = H1; j < RTW; j++) aoff[j] = ((vmask[j] >> tap) & 1) ? base0 + j * 16 * LS4 + sh : zero4;
+            }
+#pragma unroll
+            for (int j = H1; j < RTW; j++) a[j] = lds4[aoff[j] + kc * 4];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int j = 0; j < H1; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t], a[j][t], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const int k2 = kk + 2 < total ? kk + 2 : total - 1;
+            const f32x4 w2 = wp[(size_t)k2 * wstride4];
+            if (kc + 1 < CH) {
+#pragma unroll
+                for (int j = 0; j < H1; j++) a[j] = lds4[aoff[j] + (kc + 1) * 4];
+            } else if (tap + 1 < 9) {
+                const int sh = tap_shift(tap + 1);
+#pragma unroll
+                for (int j = 0; j < H1; j++) aoff[j] = ((vmask[j] >> (tap + 1)) & 1) ? base0 + j * 16 * LS4 + sh : zero4;
+#pragma unroll
+                for (int j = 0; j < H1; j++) a[j] = lds4[aoff[j]];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int j = H1; j < RTW; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t], a[j][t], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            w0 = w1;
+            w1 = w2;
+            kk++;
+        }
+    }
+}
+
 }  // namespace tg

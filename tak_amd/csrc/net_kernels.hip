@@ -317,8 +317,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < RTW; j++) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         const f32x4* wp = (const f32x4*)T.w[layer] + ((size_t)(ch0 + r16) * 4 + q);
-        if (layer == 0) conv_mainloop<RTW, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, nsq, rho0, q, acc);
-        else conv_mainloop<RTW, CH>(lds4, wp, (size_t)F * 4, LS4, rows, n, nsq, rho0, q, acc);
+        if (layer == 0) conv_mainloop_v2<RTW, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, nsq, rho0, q, acc);
+        else conv_mainloop_v2<RTW, CH>(lds4, wp, (size_t)F * 4, LS4, rows, n, nsq, rho0, q, acc);
         asm volatile("" ::: "memory");  // keep the skip loads below out of the main loop's register budget
         // ---- epilogue on the accumulators: lane holds out[row][ch0 + 4q .. 4q+3] ----
         const f32x4 bv = *(const f32x4*)&T.b[layer][ch0 + 4 * q];

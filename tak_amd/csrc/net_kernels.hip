@@ -317,8 +317,17 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < RTW; j++) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         const f32x4* wp = (const f32x4*)T.w[layer] + ((size_t)(ch0 + r16) * 4 + q);
-        if (layer == 0) conv_mainloop_v2<RTW, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, nsq, rho0, q, acc);
-        else conv_mainloop_v2<RTW, CH>(lds4, wp, (size_t)F * 4, LS4, rows, n, nsq, rho0, q, acc);
+        // the last row group may own one tile less (25 = 13 + 12 on 5×5): it runs the loop specialised for
+        // RTW-1 tiles instead of issuing a whole tile of zero MFMAs (wave-uniform branch)
+        const bool short_group = (rg * RTW + RTW - 1) * 16 >= rows && RTW > 1;
+        if (short_group) {
+            f32x4 (&acs)[RTW - 1] = *reinterpret_cast<f32x4 (*)[RTW - 1]>(&acc[0]);
+            if (layer == 0) conv_mainloop_v2<RTW - 1, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, nsq, rho0, q, acs);
+            else conv_mainloop_v2<RTW - 1, CH>(lds4, wp, (size_t)F * 4, LS4, rows, n, nsq, rho0, q, acs);
+        } else {
+            if (layer == 0) conv_mainloop_v2<RTW, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, nsq, rho0, q, acc);
+            else conv_mainloop_v2<RTW, CH>(lds4, wp, (size_t)F * 4, LS4, rows, n, nsq, rho0, q, acc);
+        }
         asm volatile("" ::: "memory");  // keep the skip loads below out of the main loop's register budget
         // ---- epilogue on the accumulators: lane holds out[row][ch0 + 4q .. 4q+3] ----
         const f32x4 bv = *(const f32x4*)&T.b[layer][ch0 + 4 * q];

@@ -346,6 +346,12 @@ typedef struct TgProfile {
     int64_t conv_flops;       /* algorithmic FLOPs of one timed launch: 2·M·9·F·F                */
 } TgProfile;
 int tg_profile_enable(TgEngine* e, int sample_every); /* 0 disables */
+/* Board-path micro-benchmark: uploads n states + one legal move each, then runs `reps`
+ * fused passes (Game::play → Game::result → possible_moves count → game_repr planes, all on the device,
+ * inputs resident in HBM) bracketed by HIP events.  Returns the average pass time; out_* (host, optional)
+ * receive the outputs of the last pass: stepped states, results, move counts. */
+int tg_board_pass_bench(TgEngine* e, int n, const void* states, const TgMove* moves, int reps, double* avg_ms,
+                        void* out_states, uint8_t* out_results, int32_t* out_counts);
 int tg_profile_read(TgEngine* e, TgProfile* out);     /* synchronises; resets the totals */
 
 #ifdef __cplusplus

@@ -415,6 +415,27 @@ __device__ inline void ws_encode(const WState& s, const Geom& g, float* out, int
     int st0, cp0;
     starting_stones(g.n, st0, cp0);
     float fcd = fcd_value(s, g);
+    if (NHWC && (cstride & 3) == 0) {
+        // 16 bytes per lane: 4 consecutive channels of one square (cstride is a multiple of 4)
+        const int per_sq = cstride >> 2;
+        const int total4 = per_sq * g.nsq;
+        for (int e0 = 0; e0 < total4; e0 += 64) {
+            int e = e0 + lane;
+            int ee = e < total4 ? e : 0;
+            int sq = ee / per_sq;
+            int c0 = (ee - sq * per_sq) << 2;
+            uint64_t stk = shfl64(s.stack, sq);
+            uint32_t h = (uint32_t)__shfl((int)s.height, sq);
+            uint32_t tp = (uint32_t)__shfl((int)s.top, sq);
+            float4 v;
+            v.x = c0 + 0 < C ? repr_value(c0 + 0, stk, h, tp, s, g.n, st0, cp0, fcd) : 0.0f;
+            v.y = c0 + 1 < C ? repr_value(c0 + 1, stk, h, tp, s, g.n, st0, cp0, fcd) : 0.0f;
+            v.z = c0 + 2 < C ? repr_value(c0 + 2, stk, h, tp, s, g.n, st0, cp0, fcd) : 0.0f;
+            v.w = c0 + 3 < C ? repr_value(c0 + 3, stk, h, tp, s, g.n, st0, cp0, fcd) : 0.0f;
+            if (e < total4) ((float4*)out)[e] = v;
+        }
+        return;
+    }
     const int total = cstride * g.nsq;
     for (int e0 = 0; e0 < total; e0 += 64) {
         int e = e0 + lane;

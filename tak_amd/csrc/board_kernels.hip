@@ -105,6 +105,25 @@ __global__ __launch_bounds__(256) void k_perft_expand(const uint8_t* __restrict_
     }
 }
 
+// One fused pass of the board path over a batch (the micro-benchmark of SURVEY.md §8d): play a move,
+// evaluate the terminal test, count the legal moves and encode the NHWC planes.  Algorithmic bytes per
+// position = state in + state out + f32 planes (256 + 256 + 7200 on 5×5).
+__global__ __launch_bounds__(256) void k_board_pass(const uint8_t* __restrict__ states, const uint16_t* __restrict__ moves, int count,
+                                                    int n, uint8_t* __restrict__ out_states, uint8_t* __restrict__ results,
+                                                    int32_t* __restrict__ counts, float* __restrict__ planes, int cstride) {
+    int gi = wave_global_id();
+    if (gi >= count) return;
+    Geom g = make_geom(n);
+    WState s;
+    ws_load(s, states + (size_t)gi * g.bytes, g);
+    ws_play(s, uni((uint32_t)moves[gi]), g);
+    uint32_t r = ws_result(s, g);
+    int c = r == TG_ONGOING ? ws_movegen(s, g, 0, [](int, uint32_t) {}) : 0;
+    ws_store(s, out_states + (size_t)gi * g.bytes, g);
+    ws_encode<true>(s, g, planes + (size_t)gi * cstride * g.nsq, cstride);
+    if (lane_id() == 0) { results[gi] = (uint8_t)r; counts[gi] = c; }
+}
+
 // ---- launchers --------------------------------------------------------------------------------
 static inline dim3 wave_grid(int count) { return dim3((count + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK); }
 
@@ -125,6 +144,10 @@ void launch_encode(hipStream_t st, const uint8_t* states, int count, int n, floa
 }
 void launch_encode_nhwc(hipStream_t st, const uint8_t* states, int count, int n, float* planes, int cstride) {
     if (count > 0) hipLaunchKernelGGL(k_encode<true>, wave_grid(count), dim3(256), 0, st, states, count, n, planes, cstride);
+}
+void launch_board_pass(hipStream_t st, const uint8_t* states, const uint16_t* moves, int count, int n, uint8_t* out_states,
+                       uint8_t* results, int32_t* counts, float* planes, int cstride) {
+    if (count > 0) hipLaunchKernelGGL(k_board_pass, wave_grid(count), dim3(256), 0, st, states, moves, count, n, out_states, results, counts, planes, cstride);
 }
 void launch_move_index(hipStream_t st, const uint16_t* moves, int count, int n, bool legacy5, const int16_t* lut5, int32_t* index) {
     if (count > 0) hipLaunchKernelGGL(k_move_index, dim3((count + 255) / 256), dim3(256), 0, st, moves, count, n, legacy5 ? 1 : 0, lut5, index);

@@ -65,7 +65,7 @@ ABI_SYMBOLS = [
     "tg_search_create", "tg_search_reset", "tg_search_run", "tg_search_apply_dirichlet", "tg_search_apply_noise",
     "tg_search_root", "tg_search_play", "tg_search_states", "tg_search_dump", "tg_search_counters",
     "tg_selfplay_create", "tg_selfplay_step", "tg_selfplay_stats", "tg_selfplay_drain",
-    "tg_profile_enable", "tg_profile_read",
+    "tg_profile_enable", "tg_profile_read", "tg_board_pass_bench",
 ]
 
 
@@ -295,6 +295,17 @@ class Engine:
         p = TgProfile()
         self._check(self.lib.tg_profile_read(self.h, C.byref(p)))
         return p.as_dict()
+
+    def board_pass_bench(self, states, moves, reps=10):
+        """Fused play → result → movegen-count → encode pass on device-resident inputs (micro-benchmark)."""
+        states, k = self._states(states)
+        moves = np.ascontiguousarray(moves, np.uint16).reshape(k)
+        ms = C.c_double(0)
+        out_states = np.zeros_like(states)
+        res = np.zeros(k, np.uint8)
+        cnt = np.zeros(k, np.int32)
+        self._check(self.lib.tg_board_pass_bench(self.h, k, _p(states), _p(moves), reps, C.byref(ms), _p(out_states), _p(res), _p(cnt)))
+        return ms.value, out_states, res, cnt
 
     # ---- self_play_parallel ------------------------------------------------------------------------
     def selfplay_create(self, games, arena_nodes=1 << 16, base=500.0, init=4.0, seed=0, rollouts=400, noise_plies=80,

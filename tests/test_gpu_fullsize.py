@@ -1,0 +1,117 @@
+"""BASELINE.json's full sizes (4096 concurrent games, the C2 network) checked through size-independent
+properties, plus bit-exact comparison of a slice against the oracle."""
+import numpy as np
+import pytest
+
+import torch_ref
+
+pytestmark = pytest.mark.gpu
+G = 4096
+
+
+@pytest.fixture(scope="module")
+def c2(orc):
+    import tak_amd
+
+    net = torch_ref.make_net(5, 6, 64, "fc5", seed=0, randomize_bn=False)
+    tensors = torch_ref.abi_tensors(net)
+    e = tak_amd.Engine(5, res_blocks=6, filters=64, evaluator=tak_amd.EVAL_RESNET, max_batch=G)
+    e.load_state_dict(tensors)
+    yield e, net, tensors
+    e.close()
+
+
+def _roots(orc, count):
+    base = orc.random_positions(5, 3000, seed=21, max_plies=60, half_komi=4)
+    base = base[orc.result(5, base) == 0]
+    return np.tile(base, (count // len(base) + 1, 1))[:count]
+
+
+def test_policy_eval_full_batch_properties(c2, orc):
+    e, net, _ = c2
+    sts = _roots(orc, G)
+    p, v = e.policy_eval(sts)
+    assert np.abs(p.sum(1) - 1).max() < 1e-5 and (p > 0).all() and (np.abs(v) <= 1).all()
+    # identical positions in different batch slots get identical outputs (tiles are batch-position independent)
+    first = {}
+    for i in range(0, G, 97):
+        key = sts[i].tobytes()
+        if key in first:
+            assert np.array_equal(p[i], p[first[key]]) and v[i] == v[first[key]]
+        first.setdefault(key, i)
+    # a slice against PyTorch fp32 (north_star tolerance)
+    idx = np.arange(0, G, 64)
+    p_ref, v_ref = torch_ref.forward(net, orc.encode(5, sts[idx]))
+    assert np.abs(p[idx] - p_ref).max() <= 1e-4 and np.abs(v[idx] - v_ref).max() <= 1e-4
+
+
+def test_search_full_size_invariants_and_slice_parity(c2, orc):
+    import tak_amd
+
+    e, net, tensors = c2
+    iters = 24
+    sts = _roots(orc, G)
+    e.search_create(G, arena_nodes=1 << 13)
+    e.search_reset(sts)
+    e.search_run(iters)
+    r = e.search_root()
+    exp, ev = e.search_counters()
+    assert exp == G * iters and ev <= exp
+    assert (r["root_visits"] == iters).all()              # every rollout adds exactly one real visit to its root
+    cs = np.array([r["visits"][g, : r["counts"][g]].sum() for g in range(G)])
+    assert (cs == iters - 1).all()                         # the first visit expands the root itself
+    assert np.array_equal(r["counts"], orc.movegen(5, sts)[1])
+    assert (np.abs(r["q"]) <= 1.0 + 1e-6).all() and (np.abs(r["root_q"]) <= 1.0 + 1e-6).all()
+    # 16 of the 4096 games, whole trees, bit for bit against the oracle fed by the same network kernels
+    ev_eng = tak_amd.Engine(5, res_blocks=6, filters=64, evaluator=tak_amd.EVAL_RESNET, max_batch=64)
+    ev_eng.load_state_dict(tensors)
+    pick = np.arange(0, G, G // 16)
+    s = orc.Search(5, head=orc.HEAD_FC5, py_eval=lambda st: ev_eng.policy_eval(st))
+    s.reset(sts[pick])
+    s.run(iters)
+    for k, g in enumerate(pick):
+        a, b = e.search_dump(int(g)), s.dump(k)
+        assert len(a) == len(b) and all(np.array_equal(a[f], b[f]) for f in a.dtype.names), g
+        assert (a["virtual_visits"] == 0).all()
+    ev_eng.close()
+
+
+def test_selfplay_full_size_two_plies(c2, orc):
+    e, _, _ = c2
+    rollouts = 16
+    e.selfplay_create(G, arena_nodes=1 << 13, seed=9, rollouts=rollouts, max_examples=G * 4)
+    e.selfplay_step(2)
+    st = e.selfplay_stats()
+    assert st["plies"] == 2 and st["games_finished"] == 0 and st["instant_wins"] == 0
+    assert st["expansions"] == 2 * G * (rollouts + 1) == st["evals"]   # nothing is terminal at plies 2-3 of 5x5
+    states = e.search_states()
+    plies = states[:, 256 - 16 + 2].astype(int) | (states[:, 256 - 16 + 3].astype(int) << 8)
+    assert (plies == 4).all()                                           # a1, far corner, two searched moves
+    # stone conservation: reserves + stones on the board are constant
+    heights = (states[:, 200:225] & 63).sum(1)
+    reserves = states[:, 256 - 16 + 4 : 256 - 16 + 8].astype(int).sum(1)
+    assert (heights + reserves == 44).all()
+    # both opening corners occur (RNG purpose 1) and games differ (noise + sampling)
+    assert len({s.tobytes() for s in states}) > G // 2
+
+
+def test_board_pass_million_positions(orc):
+    import tak_amd
+
+    n = 5
+    base = orc.random_positions(n, 6000, seed=3, max_plies=120, half_komi=4)
+    base = base[orc.result(n, base) == 0][:4096]
+    mv, cnt = orc.movegen(n, base)
+    moves = mv[np.arange(len(base)), (np.arange(len(base)) * 7) % cnt]
+    reps = (1 << 20) // len(base)
+    e = tak_amd.Engine(n, evaluator=tak_amd.EVAL_DUMMY, max_batch=1024)
+    ms, out_states, res, counts = e.board_pass_bench(np.tile(base, (reps, 1)), np.tile(moves, reps), reps=2)
+    o_states, o_status = orc.play(n, base, moves)
+    assert not o_status.any()
+    # every copy of a position gives the same, oracle-exact answer wherever it sits in the 2^20 batch
+    out_states = out_states.reshape(reps, len(base), -1)
+    assert (out_states == o_states[None]).all()
+    assert (res.reshape(reps, -1) == orc.result(n, o_states)[None]).all()
+    ong = orc.result(n, o_states) == 0
+    assert (counts.reshape(reps, -1)[:, ong] == orc.movegen(n, o_states)[1][ong][None]).all()
+    e.close()

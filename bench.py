@@ -50,6 +50,9 @@ def cpu_baseline(args, net, seconds_budget=20.0):
 
     n = args.board
     head = orc.HEAD_FC5 if args.head == "fc5" else orc.HEAD_CONV
+    # the GPU box gives one GPU's worth of host cores (16); PyTorch's default of one thread per visible core
+    # (128+) oversubscribes them on these small convolutions
+    torch.set_num_threads(min(args.cpu_threads, os.cpu_count() or 1))
 
     def py_eval(states):
         return torch_ref.forward(net, orc.encode(n, states))
@@ -89,6 +92,7 @@ def main():
     ap.add_argument("--arena", type=int, default=1 << 17, help="MCTS nodes per game arena")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-games", type=int, default=48)
+    ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-every", type=int, default=8, help="time the tower convs of every k-th forward (0 = off)")
     args = ap.parse_args()

@@ -333,6 +333,22 @@ int tg_selfplay_drain(TgEngine* e, int cap, TgExampleHeader* headers, void* stat
                       uint32_t* visits, int32_t* n_out);
 
 /* ---------------------------------------------------------------------------------------
+ * Text formats at the edge of the path (host only).  PTN moves / TPS positions follow takparse 0.5.5's
+ * Display + FromStr as used by tak/src/game.rs:79 and tak/src/tps.rs:7-96; the example line follows
+ * alpha-tak/src/example.rs:81-133 ("{tps};{w_stones};{w_caps};{b_stones};{b_caps};{half_komi};{result};
+ * {move:visits,…}"), so drained examples can be written as the reference's `_examples/*.data` files.
+ * format functions return the text length (≥ 0) or a negative TgStatus.
+ * ------------------------------------------------------------------------------------- */
+int tg_format_move(int n, TgMove mv, char* buf, size_t cap);
+int tg_parse_move(int n, const char* text, TgMove* out);
+int tg_format_tps(int n, const void* state, char* buf, size_t cap);
+int tg_parse_tps(int n, const char* text, void* state); /* reserves derived from the board, half_komi 0 */
+int tg_format_example(int n, const void* state, int n_moves, const TgMove* moves, const uint32_t* visits, float result,
+                      char* buf, size_t cap);
+int tg_parse_example(int n, const char* line, void* state, int cap_moves, TgMove* moves, uint32_t* visits,
+                     int32_t* n_moves, float* result);
+
+/* ---------------------------------------------------------------------------------------
  * Measurement hooks (no reference counterpart: the reference has no profiling).
  * While enabled, every `sample_every`-th network forward brackets each residual-tower 3×3 conv
  * launch with HIP events on the engine stream; tg_profile_read synchronises and returns the totals.

@@ -66,6 +66,7 @@ ABI_SYMBOLS = [
     "tg_search_root", "tg_search_play", "tg_search_states", "tg_search_dump", "tg_search_counters",
     "tg_selfplay_create", "tg_selfplay_step", "tg_selfplay_stats", "tg_selfplay_drain",
     "tg_profile_enable", "tg_profile_read", "tg_board_pass_bench",
+    "tg_format_move", "tg_parse_move", "tg_format_tps", "tg_parse_tps", "tg_format_example", "tg_parse_example",
 ]
 
 
@@ -111,6 +112,57 @@ def policy_size(n, head):
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _text_check(rc):
+    if rc < 0:
+        raise TgError(rc, load_library().tg_last_error().decode())
+    return rc
+
+
+# ---- text formats (host only; no GPU needed): PTN, TPS, example lines of alpha-tak/src/example.rs:81-133 ----
+def format_move(n, code):
+    buf = C.create_string_buffer(32)
+    _text_check(load_library().tg_format_move(n, C.c_uint16(int(code)), buf, C.c_size_t(32)))
+    return buf.value.decode()
+
+
+def parse_move(n, text):
+    out = C.c_uint16(0)
+    _text_check(load_library().tg_parse_move(n, text.encode(), C.byref(out)))
+    return out.value
+
+
+def format_tps(n, state):
+    st = np.ascontiguousarray(state, np.uint8)
+    buf = C.create_string_buffer(2048)
+    _text_check(load_library().tg_format_tps(n, _p(st), buf, C.c_size_t(2048)))
+    return buf.value.decode()
+
+
+def parse_tps(n, text):
+    st = np.zeros(state_bytes(n), np.uint8)
+    _text_check(load_library().tg_parse_tps(n, text.encode(), _p(st)))
+    return st
+
+
+def format_example(n, state, moves, visits, result):
+    st = np.ascontiguousarray(state, np.uint8)
+    mv = np.ascontiguousarray(moves, np.uint16)
+    vs = np.ascontiguousarray(visits, np.uint32)
+    buf = C.create_string_buffer(1 << 14)
+    _text_check(load_library().tg_format_example(n, _p(st), int(mv.size), _p(mv), _p(vs), C.c_float(float(result)), buf, C.c_size_t(1 << 14)))
+    return buf.value.decode()
+
+
+def parse_example(n, line):
+    st = np.zeros(state_bytes(n), np.uint8)
+    mv = np.zeros(TG_MAX_MOVES, np.uint16)
+    vs = np.zeros(TG_MAX_MOVES, np.uint32)
+    k = C.c_int32(0)
+    res = C.c_float(0)
+    _text_check(load_library().tg_parse_example(n, line.encode(), _p(st), TG_MAX_MOVES, _p(mv), _p(vs), C.byref(k), C.byref(res)))
+    return st, mv[: k.value].copy(), vs[: k.value].copy(), res.value
 
 
 def _mask(active):
@@ -323,6 +375,15 @@ class Engine:
         s = TgSelfPlayStats()
         self._check(self.lib.tg_selfplay_stats(self.h, C.byref(s)))
         return s.as_dict()
+
+    def write_examples(self, path, cap=1 << 16):
+        """Drain finished examples and append them to `path` in the reference's `.data` text format."""
+        hdr, states, moves, visits = self.selfplay_drain(cap)
+        with open(path, "a") as f:
+            for i in range(len(hdr)):
+                k = int(hdr["n_moves"][i])
+                f.write(format_example(self.n, states[i], moves[i, :k], visits[i, :k], float(hdr["result"][i])) + "\n")
+        return len(hdr)
 
     def selfplay_drain(self, cap=4096):
         hdr = np.zeros(cap, EXAMPLE_HEADER)

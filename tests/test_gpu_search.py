@@ -218,3 +218,29 @@ def test_selfplay_driver_matches_oracle(orc, n, games, rollouts, total):
     assert np.array_equal(gh, oh)
     assert np.array_equal(gs, os_) and np.array_equal(gm, om) and np.array_equal(gv, ov)
     e.close()
+
+
+def test_examples_written_in_reference_text_format(orc, tmp_path):
+    # alpha-tak/src/example.rs:81-133: drained GPU examples → `.data` lines → parsed back
+    import tak_amd
+
+    n, games = 4, 6
+    kw = dict(rollouts=10, noise_plies=6, exploit_plies=4, total_games=8)
+    e = _mk(n, tak_amd.EVAL_HASH, games)
+    e.selfplay_create(games, arena_nodes=1 << 14, seed=12, max_examples=1 << 12, **kw)
+    e.selfplay_step(120)
+    path = tmp_path / "0.data"
+    wrote = e.write_examples(str(path))
+    assert wrote == e.selfplay_stats()["examples"] > 0
+    sp = orc.SelfPlay(n, games, evaluator=orc.EVAL_HASH, seed=12, **kw)
+    sp.step(120)
+    oh, os_, om, ov = sp.drain(1 << 12)
+    lines = path.read_text().splitlines()
+    assert len(lines) == len(oh)
+    for i, line in enumerate(lines):
+        st, mv, vs, res = tak_amd.parse_example(n, line)
+        k = int(oh["n_moves"][i])
+        want = os_[i].copy()
+        want[256 - 16 + 9] = 0
+        assert np.array_equal(st, want) and np.array_equal(mv, om[i, :k]) and np.array_equal(vs, ov[i, :k]) and res == oh["result"][i]
+    e.close()

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Soak run of the GPU self-play driver at full width with the hash evaluator (no network cost): many plies,
+games finishing and recycling, examples drained — checks that no device error flag (arena / staging / queue
+overflow, NaN, illegal move) is ever raised and prints game statistics."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+import tak_amd
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--board", type=int, default=5)
+ap.add_argument("--games", type=int, default=4096)
+ap.add_argument("--rollouts", type=int, default=400)
+ap.add_argument("--plies", type=int, default=200)
+ap.add_argument("--arena", type=int, default=1 << 17)
+ap.add_argument("--evaluator", default="hash")
+args = ap.parse_args()
+ev = tak_amd.EVAL_HASH if args.evaluator == "hash" else tak_amd.EVAL_DUMMY
+e = tak_amd.Engine(args.board, evaluator=ev, max_batch=args.games)
+e.selfplay_create(args.games, arena_nodes=args.arena, seed=1, rollouts=args.rollouts, max_examples=1 << 18)
+t0 = time.time()
+drained = 0
+lens = []
+for p in range(0, args.plies, 10):
+    e.selfplay_step(10)
+    st = e.selfplay_stats()  # synchronises and raises on any device error flag
+    hdr, states, moves, visits = e.selfplay_drain(1 << 18)
+    drained += len(hdr)
+    print(json.dumps({"ply": p + 10, "t": round(time.time() - t0, 1), **st, "drained": drained}), flush=True)
+assert drained == st["examples"] or st["examples"] - drained <= 0
+print("soak ok")

@@ -75,17 +75,10 @@ __device__ __forceinline__ void conv_mainloop(const f32x4* __restrict__ lds4, co
 }
 
 
-// Variant 2: explicit half-tile software pipeline that also runs across tap boundaries.
-//     load H2(s) | MFMA H1(s) | load H1(s+1), w(s+2) | MFMA H2(s)
-// The two halves of the row tiles are reloaded in place (no second register set); the tap offsets of a half are
-// refreshed (3 VALU per tile) right before that half's first load of the new tap.
-template <int RTW, int CH>
-__device__ __forceinline__ void conv_mainloop_v2(const f32x4* __restrict__ lds4, const f32x4* __restrict__ wp, size_t wstride4,
-                                                 int LS4, int rows, int n, int nsq, int rho0, int q, f32x4 (&acc)[RTW]) {
-    constexpr int total = 9 * CH;
-    constexpr int H1 = (RTW + 1) / 2;
-    const int zero4 = rows * LS4 + q;
-    int vmask[RTW];
+// 9-bit tap-validity mask of the row tiles of one lane: bit t set ⇔ tap t (dy = t/3-1, dx = t%3-1) of that row
+// stays on the board; rows ≥ `rows` get 0 (every tap reads the zero row).
+template <int RTW>
+__device__ __forceinline__ void conv_tap_masks(int rows, int n, int nsq, int rho0, int (&vmask)[RTW]) {
 #pragma unroll
     for (int j = 0; j < RTW; j++) {
         int rho = rho0 + j * 16;
@@ -100,6 +93,20 @@ __device__ __forceinline__ void conv_mainloop_v2(const f32x4* __restrict__ lds4,
         }
         vmask[j] = rho < rows ? m : 0;
     }
+}
+
+// Variant 2: explicit half-tile software pipeline that also runs across tap boundaries.
+//     load H2(s) | MFMA H1(s) | load H1(s+1), w(s+2) | MFMA H2(s)
+// The two halves of the row tiles are reloaded in place (no second register set); the tap offsets of a half are
+// refreshed (3 VALU per tile) right before that half's first load of the new tap.
+template <int RTW, int CH, int NM>
+__device__ __forceinline__ void conv_mainloop_v2(const f32x4* __restrict__ lds4, const f32x4* __restrict__ wp, size_t wstride4,
+                                                 int LS4, int rows, int n, int rho0, int q, const int (&vmask)[NM],
+                                                 f32x4 (&acc)[RTW]) {
+    static_assert(NM >= RTW, "tap masks for every row tile");
+    constexpr int total = 9 * CH;
+    constexpr int H1 = (RTW + 1) / 2;
+    const int zero4 = rows * LS4 + q;
     const int base0 = rho0 * LS4 + q;
     int aoff[RTW];
     auto tap_shift = [&](int tap) { return ((tap / 3 - 1) * n + (tap % 3 - 1)) * LS4; };

@@ -310,47 +310,35 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
 
     const int rho0 = rg * RTW * 16 + r16;
 
-    // The skip connection (block input of exactly the tiles this lane produces) is parked in the output
-    // buffer between conv1 and conv2 of a block: same lane, same addresses, so program order makes it visible.
-    for (int layer = 0; layer < T.nlayers; layer++) {
-        f32x4 acc[RTW];
+    // Skip connection without any storage of its own: after conv1 of a block every wave reads the block input X
+    // of exactly the tiles it owns back from the LDS image (just before it overwrites them with conv1's output)
+    // and uses it as the initial value of conv2's accumulators.
+    f32x4 acc[RTW];
 #pragma unroll
-        for (int j = 0; j < RTW; j++) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int j = 0; j < RTW; j++) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    int vmask[RTW];  // board geometry is the same for every layer
+    conv_tap_masks<RTW>(rows, n, nsq, rho0, vmask);
+
+    for (int layer = 0; layer < T.nlayers; layer++) {
         const f32x4* wp = (const f32x4*)T.w[layer] + ((size_t)(ch0 + r16) * 4 + q);
         // the last row group may own one tile less (25 = 13 + 12 on 5×5): it runs the loop specialised for
         // RTW-1 tiles instead of issuing a whole tile of zero MFMAs (wave-uniform branch)
         const bool short_group = (rg * RTW + RTW - 1) * 16 >= rows && RTW > 1;
         if (short_group) {
             f32x4 (&acs)[RTW - 1] = *reinterpret_cast<f32x4 (*)[RTW - 1]>(&acc[0]);
-            if (layer == 0) conv_mainloop_v2<RTW - 1, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, nsq, rho0, q, acs);
-            else conv_mainloop_v2<RTW - 1, CH>(lds4, wp, (size_t)F * 4, LS4, rows, n, nsq, rho0, q, acs);
+            if (layer == 0) conv_mainloop_v2<RTW - 1, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acs);
+            else conv_mainloop_v2<RTW - 1, CH>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acs);
         } else {
-            if (layer == 0) conv_mainloop_v2<RTW, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, nsq, rho0, q, acc);
-            else conv_mainloop_v2<RTW, CH>(lds4, wp, (size_t)F * 4, LS4, rows, n, nsq, rho0, q, acc);
+            if (layer == 0) conv_mainloop_v2<RTW, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acc);
+            else conv_mainloop_v2<RTW, CH>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acc);
         }
-        asm volatile("" ::: "memory");  // keep the skip loads below out of the main loop's register budget
         // ---- epilogue on the accumulators: lane holds out[row][ch0 + 4q .. 4q+3] ----
         const f32x4 bv = *(const f32x4*)&T.b[layer][ch0 + 4 * q];
-        const bool add_skip = layer > 0 && (layer & 1) == 0;   // conv2 of a block
-        const bool save_skip = (layer & 1) == 0 && layer + 1 < T.nlayers;  // conv0 output / block output = next block input
-        float* skip_ptr = out + ((size_t)pos0 * nsq + rho0) * F + ch0 + 4 * q;
-        if (add_skip) {
-            f32x4 sk[RTW];
-#pragma unroll
-            for (int j = 0; j < RTW; j++) sk[j] = rho0 + j * 16 < rows ? *(const f32x4*)(skip_ptr + (size_t)j * 16 * F) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int j = 0; j < RTW; j++) acc[j] += sk[j];
-        }
 #pragma unroll
         for (int j = 0; j < RTW; j++) {
             f32x4 v = acc[j] + bv;
             v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f);
             acc[j] = v;
-        }
-        if (save_skip) {
-#pragma unroll
-            for (int j = 0; j < RTW; j++)
-                if (rho0 + j * 16 < rows) *(f32x4*)(skip_ptr + (size_t)j * 16 * F) = acc[j];
         }
         if (layer + 1 == T.nlayers) {
 #pragma unroll
@@ -359,13 +347,23 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
             break;
         }
         __syncthreads();  // every wave has finished reading the previous image
+        const int LS4n = (F + LDS_PAD) >> 2;
+        const bool conv1 = (layer & 1) == 1;  // next layer is conv2 of the same block: it starts from the block input
+        f32x4 nxt[RTW];
+#pragma unroll
+        for (int j = 0; j < RTW; j++) {
+            nxt[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (conv1 && rho0 + j * 16 < rows) nxt[j] = lds4[(rho0 + j * 16) * LS4n + (ch0 >> 2) + q];  // own tile of X
+        }
         Cpad = F;
-        LS4 = (F + LDS_PAD) >> 2;
+        LS4 = LS4n;
 #pragma unroll
         for (int j = 0; j < RTW; j++)
             if (rho0 + j * 16 < rows) lds4[(rho0 + j * 16) * LS4 + (ch0 >> 2) + q] = acc[j];
         if (layer == 0)
             for (int idx = tid; idx < LS4; idx += NWAVES * 64) lds4[rows * LS4 + idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < RTW; j++) acc[j] = nxt[j];
         __syncthreads();
     }
 }

@@ -404,6 +404,54 @@ __device__ inline float fcd_value(const WState& s, const Geom& g) {
     return (float)((double)fcd / (double)g.nsq);  // f64 division then narrowing, game.rs:35-37
 }
 
+// Every input channel is 0/1 except the last (fcd), so one square's row of game_repr is a ≤128-bit mask:
+// top one-hot, buried stones, reserve one-hots, colour (alpha-tak/src/repr/{board,reserves,game}.rs).
+// The lane of a square builds its own mask — no cross-lane traffic.
+struct RowMask { uint32_t w[4]; };
+
+__device__ inline RowMask ws_row_mask(const WState& s, const Geom& g) {
+    int st0, cp0;
+    starting_stones(g.n, st0, cp0);
+    const int bc = board_channels(g.n);
+    RowMask m;
+    m.w[0] = m.w[1] = m.w[2] = m.w[3] = 0u;
+    auto setbit = [&](int c) {
+        if (c < 32) m.w[0] |= 1u << c; else if (c < 64) m.w[1] |= 1u << (c - 32); else if (c < 96) m.w[2] |= 1u << (c - 64); else m.w[3] |= 1u << (c - 96);
+    };
+    if (s.height) {
+        uint32_t tcol = (uint32_t)((s.stack >> (s.height - 1)) & 1ull);
+        setbit(2 * (int)s.top + (tcol == s.to_move ? 0 : 1));
+        const int depth = (int)s.height - 1 < g.n + 5 ? (int)s.height - 1 : g.n + 5;  // take(N+6).skip(1)
+        for (int i = 0; i < depth; i++) {
+            uint32_t col = (uint32_t)((s.stack >> (s.height - 2 - (uint32_t)i)) & 1ull);
+            setbit(6 + 2 * i + (col == s.to_move ? 0 : 1));
+        }
+    }
+    const bool w = s.to_move == 0;
+    const int my_st = w ? s.ws : s.bs, en_st = w ? s.bs : s.ws, my_cp = w ? s.wc : s.bc, en_cp = w ? s.bc : s.wc;
+    if (my_st > 0 && my_st <= st0) setbit(bc + my_st - 1);
+    if (en_st > 0 && en_st <= st0) setbit(bc + st0 + en_st - 1);
+    if (my_cp > 0 && my_cp <= cp0) setbit(bc + 2 * st0 + my_cp - 1);
+    if (en_cp > 0 && en_cp <= cp0) setbit(bc + 2 * st0 + cp0 + en_cp - 1);
+    if (w) setbit(bc + 2 * st0 + 2 * cp0);
+    return m;
+}
+
+// channels 4k .. 4k+3 of the row as floats; channel C-1 is the fcd plane
+__device__ inline float4 row_mask_value(const RowMask& m, int k, int C, float fcd) {
+    const int c0 = k << 2;
+    const uint32_t word = c0 < 32 ? m.w[0] : c0 < 64 ? m.w[1] : c0 < 96 ? m.w[2] : m.w[3];
+    const uint32_t nib = (word >> (c0 & 31)) & 15u;
+    float4 v;
+    v.x = (nib & 1u) ? 1.0f : 0.0f;
+    v.y = (nib & 2u) ? 1.0f : 0.0f;
+    v.z = (nib & 4u) ? 1.0f : 0.0f;
+    v.w = (nib & 8u) ? 1.0f : 0.0f;
+    const int r = C - 1 - c0;
+    if (r == 0) v.x = fcd; else if (r == 1) v.y = fcd; else if (r == 2) v.z = fcd; else if (r == 3) v.w = fcd;
+    return v;
+}
+
 // Write the encoded planes of one game, fully coalesced.  NCHW: out[c*nsq + sq] (the reference
 // tensor); NHWC: out[sq*cstride + c] with channels C..cstride-1 zero (the layout the conv kernels
 // consume, rows padded to a multiple of 8 channels).
@@ -416,50 +464,11 @@ __device__ inline void ws_encode(const WState& s, const Geom& g, float* out, int
     starting_stones(g.n, st0, cp0);
     float fcd = fcd_value(s, g);
     if (NHWC && (cstride & 3) == 0 && cstride <= 128) {
-        // Every channel is 0/1 except the last (fcd): the lane of a square builds the ≤128-bit mask of its row
-        // (top one-hot, buried stones, reserve one-hots, colour) and streams it out as 16-byte stores — no
-        // cross-lane traffic and ~10 VALU per store.
-        const int bc = board_channels(g.n);
-        uint32_t m[4] = {0u, 0u, 0u, 0u};
-        auto setbit = [&](int c) {
-            if (c < 32) m[0] |= 1u << c; else if (c < 64) m[1] |= 1u << (c - 32); else if (c < 96) m[2] |= 1u << (c - 64); else m[3] |= 1u << (c - 96);
-        };
-        if (s.height) {
-            uint32_t tcol = (uint32_t)((s.stack >> (s.height - 1)) & 1ull);
-            setbit(2 * (int)s.top + (tcol == s.to_move ? 0 : 1));
-            const int depth = (int)s.height - 1 < g.n + 5 ? (int)s.height - 1 : g.n + 5;  // take(N+6).skip(1)
-            for (int i = 0; i < depth; i++) {
-                uint32_t col = (uint32_t)((s.stack >> (s.height - 2 - (uint32_t)i)) & 1ull);
-                setbit(6 + 2 * i + (col == s.to_move ? 0 : 1));
-            }
-        }
-        {
-            const bool w = s.to_move == 0;
-            const int my_st = w ? s.ws : s.bs, en_st = w ? s.bs : s.ws, my_cp = w ? s.wc : s.bc, en_cp = w ? s.bc : s.wc;
-            if (my_st > 0 && my_st <= st0) setbit(bc + my_st - 1);
-            if (en_st > 0 && en_st <= st0) setbit(bc + st0 + en_st - 1);
-            if (my_cp > 0 && my_cp <= cp0) setbit(bc + 2 * st0 + my_cp - 1);
-            if (en_cp > 0 && en_cp <= cp0) setbit(bc + 2 * st0 + cp0 + en_cp - 1);
-            if (w) setbit(bc + 2 * st0 + 2 * cp0);
-        }
+        RowMask m = ws_row_mask(s, g);
         if (lane < g.nsq) {
             float4* row = (float4*)(out + (size_t)lane * cstride);
             const int per_sq = cstride >> 2;
-            for (int k = 0; k < per_sq; k++) {
-                const int c0 = k << 2;
-                const uint32_t word = c0 < 32 ? m[0] : c0 < 64 ? m[1] : c0 < 96 ? m[2] : m[3];
-                const uint32_t nib = (word >> (c0 & 31)) & 15u;
-                float4 v;
-                v.x = (nib & 1u) ? 1.0f : 0.0f;
-                v.y = (nib & 2u) ? 1.0f : 0.0f;
-                v.z = (nib & 4u) ? 1.0f : 0.0f;
-                v.w = (nib & 8u) ? 1.0f : 0.0f;
-                if (C - 1 >= c0 && C - 1 < c0 + 4) {  // the fcd plane
-                    int r = C - 1 - c0;
-                    if (r == 0) v.x = fcd; else if (r == 1) v.y = fcd; else if (r == 2) v.z = fcd; else v.w = fcd;
-                }
-                row[k] = v;
-            }
+            for (int k = 0; k < per_sq; k++) row[k] = row_mask_value(m, k, C, fcd);
         }
         return;
     }

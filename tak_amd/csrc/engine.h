@@ -84,4 +84,7 @@ int net_finalize(TgEngine* e);
 bool net_ready(const TgEngine* e);
 // forward on device: planes NHWC (n × nsq × C) → policy (n × P, softmax) and eval (n)
 int net_forward_dev(TgEngine* e, int n, const float* d_planes_nhwc, float* d_policy, float* d_eval);
+// same from packed states (device); encodes inside the fused tower when the topology allows, else via k_encode
+int net_forward_states_dev(TgEngine* e, int n, const uint8_t* d_states, float* d_policy, float* d_eval);
+bool net_takes_states(const TgEngine* e);  // true when the fused tower encodes in-kernel
 }  // namespace tg

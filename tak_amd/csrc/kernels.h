@@ -31,6 +31,7 @@ struct TowerParams {
 };
 bool tower_supported(int n, int F, int cin_pad);
 hipError_t launch_tower(hipStream_t st, const float* in, const TowerParams& T, float* out, int B, int n);
+hipError_t launch_tower_states(hipStream_t st, const uint8_t* states, const TowerParams& T, float* out, int B, int n);
 hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp, const float* bias, float* out, int M, int K,
                        int NP, int out_stride, int n_valid);
 hipError_t launch_value_head(hipStream_t st, const float* act, const float* wv, float bv, int B, int len, float* eval);

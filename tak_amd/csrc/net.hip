@@ -231,8 +231,25 @@ int net_finalize(TgEngine* e) {
     return TG_OK;
 }
 
+static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const uint8_t* d_states, float* d_policy, float* d_eval);
+
 // planes NHWC [nb][nsq][cin_pad] (device) → policy [nb][P] (softmax, reference order), eval [nb]
 int net_forward_dev(TgEngine* e, int nb, const float* d_planes, float* d_policy, float* d_eval) {
+    return net_forward_impl(e, nb, d_planes, nullptr, d_policy, d_eval);
+}
+
+bool net_takes_states(const TgEngine* e) { return net_ready(e) && e->net->fused; }
+
+int net_forward_states_dev(TgEngine* e, int nb, const uint8_t* d_states, float* d_policy, float* d_eval) {
+    if (!net_ready(e)) return fail(TG_ERR_STATE, "network weights not finalized (tg_net_finalize)");
+    if (nb <= 0) return TG_OK;
+    if (e->net->fused) return net_forward_impl(e, nb, nullptr, d_states, d_policy, d_eval);
+    launch_encode_nhwc(e->stream, d_states, nb, e->g.n, e->net->planes_nhwc.as<float>(), e->net->cin_pad);
+    TG_HIP(hipGetLastError());
+    return net_forward_impl(e, nb, e->net->planes_nhwc.as<float>(), nullptr, d_policy, d_eval);
+}
+
+static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const uint8_t* d_states, float* d_policy, float* d_eval) {
     if (!net_ready(e)) return fail(TG_ERR_STATE, "network weights not finalized (tg_net_finalize)");
     if (nb <= 0) return TG_OK;
     if (nb > e->cfg.max_batch) return fail(TG_ERR_INVALID_ARG, "batch larger than max_batch");
@@ -257,7 +274,8 @@ int net_forward_dev(TgEngine* e, int nb, const float* d_planes, float* d_policy,
     }
     if (n->fused) {
         if (chain) chain->push_back(prof_event(n, st));
-        TG_HIP(launch_tower(st, d_planes, n->tower, x, nb, N));
+        if (d_states) TG_HIP(launch_tower_states(st, d_states, n->tower, x, nb, N));
+        else TG_HIP(launch_tower(st, d_planes, n->tower, x, nb, N));
         if (chain) chain->push_back(prof_event(n, st));
     } else {
         TG_HIP(launch_conv3x3(st, d_planes, n->conv0.w.as<float>(), n->conv0.b.as<float>(), nullptr, x, M, N, n->cin_pad,
@@ -325,10 +343,7 @@ int tg_policy_eval_dev(TgEngine* e, int n, const void* d_states, float* d_policy
     if (n < 0 || n > e->cfg.max_batch) return fail(TG_ERR_INVALID_ARG, "tg_policy_eval_dev: n out of range");
     if (n == 0) return TG_OK;
     TG_HIP(hipSetDevice(e->cfg.device));
-    Net* net = e->net;
-    launch_encode_nhwc(e->stream, (const uint8_t*)d_states, n, e->g.n, net->planes_nhwc.as<float>(), net->cin_pad);
-    TG_HIP(hipGetLastError());
-    return net_forward_dev(e, n, net->planes_nhwc.as<float>(), d_policy, d_eval);
+    return net_forward_states_dev(e, n, (const uint8_t*)d_states, d_policy, d_eval);
 }
 
 int tg_policy_eval(TgEngine* e, int n, const void* states, float* policy, float* eval) {

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "board.cuh"
 #include "conv_mainloop.cuh"
 #include "kernels.h"
 
@@ -277,7 +278,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_pos(const float* __restric
 // tiles it produces).  Only the input planes are read from HBM and only the final activations are
 // written (for the policy / value heads); per layer the only global traffic is the L2-resident weights.
 // ------------------------------------------------------------------------------------------------
-template <int RTW, int NWAVES, int CH0, int CH>
+// FROM_STATES: `in` points at packed game states and the planes are encoded straight into the LDS image
+// (game_repr fused into the tower: the f32 planes never touch HBM).
+template <int RTW, int NWAVES, int CH0, int CH, bool FROM_STATES>
 __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__ in, TowerParams T, float* __restrict__ out,
                                                        int B, int n, int PW, int CTW) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -296,7 +299,25 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
     // ---- stage the input planes (row pitch cin_pad + 4) ----
     int Cpad = T.cin_pad;
     int LS4 = (Cpad + LDS_PAD) >> 2;
-    {
+    if (FROM_STATES) {
+        const Geom geo = make_geom(n);
+        const uint8_t* states = (const uint8_t*)in;
+        const int C = input_channels(n);
+        for (int p = wave; p < npos; p += NWAVES) {  // one wave encodes one position at a time, lane = square
+            WState ws;
+            ws_load(ws, states + (size_t)(pos0 + p) * geo.bytes, geo);
+            const float fcd = fcd_value(ws, geo);
+            const RowMask m = ws_row_mask(ws, geo);
+            if (lane < nsq) {
+                f32x4* row = lds4 + (size_t)(p * nsq + lane) * LS4;
+                for (int k = 0; k < (Cpad >> 2); k++) {
+                    float4 v = row_mask_value(m, k, C, fcd);
+                    row[k] = f32x4{v.x, v.y, v.z, v.w};
+                }
+            }
+        }
+        for (int idx = tid; idx < LS4; idx += NWAVES * 64) lds4[rows * LS4 + idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    } else {
         const int vpr = Cpad >> 2;
         const f32x4* src = (const f32x4*)(in + (size_t)pos0 * nsq * Cpad);
         const int total = rows * vpr;
@@ -665,17 +686,17 @@ hipError_t launch_conv3x3(hipStream_t st, const float* in, const float* Wp, cons
 }
 
 
-template <int RTW, int NWAVES, int CH0, int CH>
+template <int RTW, int NWAVES, int CH0, int CH, bool FROM_STATES>
 static hipError_t launch_tower_t(hipStream_t st, const float* in, const TowerParams& T, float* out, int B, int n, int PW, int CTW) {
     int cmax = T.cin_pad > T.F ? T.cin_pad : T.F;
     size_t lds = (size_t)(PW * n * n + 1) * (cmax + LDS_PAD) * sizeof(float);
     static size_t configured = 0;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_tower<RTW, NWAVES, CH0, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_tower<RTW, NWAVES, CH0, CH, FROM_STATES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    hipLaunchKernelGGL((k_tower<RTW, NWAVES, CH0, CH>), dim3((B + PW - 1) / PW), dim3(NWAVES * 64), lds, st, in, T, out, B, n, PW, CTW);
+    hipLaunchKernelGGL((k_tower<RTW, NWAVES, CH0, CH, FROM_STATES>), dim3((B + PW - 1) / PW), dim3(NWAVES * 64), lds, st, in, T, out, B, n, PW, CTW);
     return hipGetLastError();
 }
 
@@ -687,9 +708,18 @@ bool tower_supported(int n, int F, int cin_pad) {
 }
 
 hipError_t launch_tower(hipStream_t st, const float* in, const TowerParams& T, float* out, int B, int n) {
-    if (n == 5 && T.F == 64 && T.cin_pad == 80) return launch_tower_t<13, 8, 5, 4>(st, in, T, out, B, n, 16, 4);
-    if (n == 6 && T.F == 128 && T.cin_pad == 96) return launch_tower_t<9, 8, 6, 8>(st, in, T, out, B, n, 4, 8);
-    if (n == 5 && T.F == 128 && T.cin_pad == 80) return launch_tower_t<13, 8, 5, 8>(st, in, T, out, B, n, 8, 8);
+    if (n == 5 && T.F == 64 && T.cin_pad == 80) return launch_tower_t<13, 8, 5, 4, false>(st, in, T, out, B, n, 16, 4);
+    if (n == 6 && T.F == 128 && T.cin_pad == 96) return launch_tower_t<9, 8, 6, 8, false>(st, in, T, out, B, n, 4, 8);
+    if (n == 5 && T.F == 128 && T.cin_pad == 80) return launch_tower_t<13, 8, 5, 8, false>(st, in, T, out, B, n, 8, 8);
+    return hipErrorInvalidValue;
+}
+
+// same, with the input planes encoded in-kernel from packed game states
+hipError_t launch_tower_states(hipStream_t st, const uint8_t* states, const TowerParams& T, float* out, int B, int n) {
+    const float* in = (const float*)states;
+    if (n == 5 && T.F == 64 && T.cin_pad == 80) return launch_tower_t<13, 8, 5, 4, true>(st, in, T, out, B, n, 16, 4);
+    if (n == 6 && T.F == 128 && T.cin_pad == 96) return launch_tower_t<9, 8, 6, 8, true>(st, in, T, out, B, n, 4, 8);
+    if (n == 5 && T.F == 128 && T.cin_pad == 80) return launch_tower_t<13, 8, 5, 8, true>(st, in, T, out, B, n, 8, 8);
     return hipErrorInvalidValue;
 }
 

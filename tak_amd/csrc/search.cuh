@@ -63,7 +63,8 @@ struct SearchDev {
     uint32_t* path;      // [G][MAX_DEPTH]
     uint8_t* leaf_kind;  // [G] 0 skipped, 1 needs evaluation, 2 terminal (already backed up)
     uint64_t* leaf_hash; // [G] (TG_EVAL_HASH)
-    float* planes;       // [G][nsq][cin_pad] NHWC network input
+    float* planes;       // [G][nsq][cin_pad] NHWC network input (null when the tower encodes from leaf_state)
+    uint8_t* leaf_state; // [G][state bytes] packed leaf positions
     float* policy;       // [G][P]
     float* eval;         // [G]
     // constants

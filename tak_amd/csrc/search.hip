@@ -14,7 +14,7 @@ namespace tg {
 struct Search {
     TgSearchConfig cfg;
     SearchDev d;
-    DevBuf hot, cold, sel, alloc, root_state, alive, generation, path_len, path, leaf_kind, leaf_hash, planes, policy, eval,
+    DevBuf hot, cold, sel, alloc, root_state, alive, generation, path_len, path, leaf_kind, leaf_hash, planes, leaf_state, policy, eval,
         ctab, err, counters, op, active, noise;
     DevBuf r_moves, r_visits, r_prior, r_q, r_counts, r_rv, r_rq, s_moves;
     // self-play
@@ -110,10 +110,14 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     TG_HIP(s->r_rq.ensure(G * 4));
     TG_HIP(s->s_moves.ensure(G * 2));
     if (e->cfg.evaluator == TG_EVAL_RESNET) {
+        if (net_takes_states(e)) {
+            TG_HIP(s->leaf_state.ensure(G * e->g.bytes));
+            TG_HIP(hipMemset(s->leaf_state.p, 0, s->leaf_state.bytes));
+        } else
         TG_HIP(s->planes.ensure(G * e->g.nsq * cin_pad * 4));
         TG_HIP(s->policy.ensure(G * (size_t)e->policy_size * 4));
         TG_HIP(s->eval.ensure(G * 4));
-        TG_HIP(hipMemset(s->planes.p, 0, s->planes.bytes));
+        if (s->planes.p) TG_HIP(hipMemset(s->planes.p, 0, s->planes.bytes));
     }
     // exploration_rate(n) = ln((1 + n + base) / base) + init for integer visit counts (mcts.rs:10-12),
     // evaluated once on the host in f32 so that every GPU and the CPU agree on the last bit
@@ -133,7 +137,8 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     d.hot = s->hot.as<NodeHot>(); d.cold = s->cold.as<NodeCold>(); d.sel = s->sel.as<uint8_t>(); d.alloc = s->alloc.as<uint32_t>();
     d.root_state = s->root_state.as<uint8_t>(); d.alive = s->alive.as<uint8_t>(); d.generation = s->generation.as<uint32_t>();
     d.path_len = s->path_len.as<int32_t>(); d.path = s->path.as<uint32_t>(); d.leaf_kind = s->leaf_kind.as<uint8_t>();
-    d.leaf_hash = s->leaf_hash.as<uint64_t>(); d.planes = s->planes.as<float>(); d.policy = s->policy.as<float>();
+    d.leaf_hash = s->leaf_hash.as<uint64_t>(); d.planes = s->planes.as<float>(); d.leaf_state = s->leaf_state.as<uint8_t>();
+    d.policy = s->policy.as<float>();
     d.eval = s->eval.as<float>(); d.ctab = s->ctab.as<float>(); d.lut5 = e->lut5.as<int16_t>(); d.err = s->err.as<uint32_t>();
     d.counters = s->counters.as<unsigned long long>();
     d.G = cfg->games; d.cap = cfg->arena_nodes; d.n = e->g.n; d.cin_pad = cin_pad; d.P = e->policy_size; d.ctab_size = ctab_size;
@@ -161,7 +166,8 @@ static int search_iterate(TgEngine* e, const uint8_t* d_active) {
     launch_select(e->stream, s->d, d_active);
     TG_HIP(hipGetLastError());
     if (e->cfg.evaluator == TG_EVAL_RESNET) {
-        int rc = net_forward_dev(e, s->d.G, s->d.planes, s->d.policy, s->d.eval);
+        int rc = s->d.planes ? net_forward_dev(e, s->d.G, s->d.planes, s->d.policy, s->d.eval)
+                             : net_forward_states_dev(e, s->d.G, s->d.leaf_state, s->d.policy, s->d.eval);
         if (rc) return rc;
     }
     launch_backup(e->stream, s->d);

@@ -194,7 +194,10 @@ __global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __re
     uint32_t* gpath = S.path + (size_t)g * MAX_DEPTH;
     for (int d = lane; d < depth; d += 64) gpath[d] = path[d];
     if (!terminal) {
-        if (S.evaluator == TG_EVAL_RESNET) ws_encode<true>(s, geo, S.planes + (size_t)g * geo.nsq * S.cin_pad, S.cin_pad);
+        if (S.evaluator == TG_EVAL_RESNET) {
+            if (S.planes) ws_encode<true>(s, geo, S.planes + (size_t)g * geo.nsq * S.cin_pad, S.cin_pad);
+            else ws_store(s, S.leaf_state + (size_t)g * geo.bytes, geo);  // game_repr happens inside the fused tower
+        }
         else if (S.evaluator == TG_EVAL_HASH) {
             uint64_t h = ws_hash(s, geo);
             if (lane == 0) S.leaf_hash[g] = h;

@@ -71,7 +71,8 @@ struct SearchDev {
     const float* ctab;   // exploration_rate(n) for integer n (host logf, mcts.rs:10-12)
     const int16_t* lut5;
     uint32_t* err;       // error flag word
-    unsigned long long* counters;  // [0] expansions [1] evals
+    unsigned long long* counters;  // [G][2] per game: expansions, evals (summed on read; a single shared word would
+                                   // serialise 2·G same-address atomics per iteration, ≈ 11 ns each)
     int G, cap, n, cin_pad, P, ctab_size, legacy5, evaluator;
     uint32_t slot_base;
     uint64_t seed;

@@ -100,7 +100,7 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     TG_HIP(s->active.ensure(G));
     TG_HIP(s->noise.ensure(G * EX_MOVES * 4));
     TG_HIP(s->err.ensure(4));
-    TG_HIP(s->counters.ensure(16));
+    TG_HIP(s->counters.ensure(G * 16));
     TG_HIP(s->r_moves.ensure(G * EX_MOVES * 2));
     TG_HIP(s->r_visits.ensure(G * EX_MOVES * 4));
     TG_HIP(s->r_prior.ensure(G * EX_MOVES * 4));
@@ -130,7 +130,7 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     TG_HIP(s->ctab.ensure((size_t)ctab_size * 4));
     TG_HIP(hipMemcpy(s->ctab.p, ctab.data(), (size_t)ctab_size * 4, hipMemcpyHostToDevice));
     TG_HIP(hipMemset(s->err.p, 0, 4));
-    TG_HIP(hipMemset(s->counters.p, 0, 16));
+    TG_HIP(hipMemset(s->counters.p, 0, G * 16));
     TG_HIP(hipMemset(s->generation.p, 0, G * 4));
     TG_HIP(hipMemset(s->alive.p, 0, G));
     SearchDev& d = s->d;
@@ -172,6 +172,17 @@ static int search_iterate(TgEngine* e, const uint8_t* d_active) {
     }
     launch_backup(e->stream, s->d);
     TG_HIP(hipGetLastError());
+    return TG_OK;
+}
+
+static int read_counters(TgEngine* e, unsigned long long* expansions, unsigned long long* evals) {
+    Search* s = e->search;
+    std::vector<unsigned long long> h((size_t)s->d.G * 2);
+    TG_HIP(hipMemcpy(h.data(), s->counters.p, h.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long a = 0, b = 0;
+    for (int g = 0; g < s->d.G; g++) { a += h[2 * (size_t)g]; b += h[2 * (size_t)g + 1]; }
+    *expansions = a;
+    *evals = b;
     return TG_OK;
 }
 
@@ -359,7 +370,8 @@ int tg_search_counters(TgEngine* e, uint64_t* expansions, uint64_t* evals) {
     rc = sync_and_check(e);
     if (rc) return rc;
     unsigned long long c[2];
-    TG_HIP(hipMemcpy(c, e->search->counters.p, 16, hipMemcpyDeviceToHost));
+    rc = read_counters(e, &c[0], &c[1]);
+    if (rc) return rc;
     if (expansions) *expansions = c[0];
     if (evals) *evals = c[1];
     return TG_OK;
@@ -464,7 +476,8 @@ int tg_selfplay_stats(TgEngine* e, TgSelfPlayStats* out) {
     if (rc) return rc;
     unsigned long long st[ST_COUNT], c[2];
     TG_HIP(hipMemcpy(st, s->stats.p, sizeof st, hipMemcpyDeviceToHost));
-    TG_HIP(hipMemcpy(c, s->counters.p, 16, hipMemcpyDeviceToHost));
+    rc = read_counters(e, &c[0], &c[1]);
+    if (rc) return rc;
     out->games_finished = st[ST_FINISHED]; out->examples = st[ST_EXAMPLES]; out->plies = st[ST_PLIES];
     out->white_wins = st[ST_WHITE]; out->black_wins = st[ST_BLACK]; out->draws = st[ST_DRAWS]; out->instant_wins = st[ST_INSTANT];
     out->expansions = c[0]; out->evals = c[1];

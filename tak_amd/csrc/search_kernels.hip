@@ -206,8 +206,8 @@ __global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __re
     if (lane == 0) {
         S.path_len[g] = depth;
         S.leaf_kind[g] = terminal ? 2 : 1;
-        atomicAdd(&S.counters[0], 1ull);
-        if (!terminal) atomicAdd(&S.counters[1], 1ull);
+        S.counters[2 * (size_t)g] += 1ull;
+        if (!terminal) S.counters[2 * (size_t)g + 1] += 1ull;
     }
 }
 

@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--head", default="fc5", choices=["fc5", "conv"])
     ap.add_argument("--arena", type=int, default=1 << 17, help="MCTS nodes per game arena")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--cpu-games", type=int, default=48)
+    ap.add_argument("--cpu-games", type=int, default=256)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-every", type=int, default=8, help="time the tower convs of every k-th forward (0 = off)")

@@ -21,13 +21,9 @@ __global__ __launch_bounds__(512) void probe(float* out, const float* __restrict
         if (wave >= 4) __builtin_amdgcn_s_sleep(STAG);
 #endif
         const f32x4* wp = (const f32x4*)wglob + ((size_t)(ct * 16 + r16) * 4 + q);
-#ifdef USE_V2
         int vmask[RTW];
         conv_tap_masks<RTW>(rows, n, nsq, rho0, vmask);
-        conv_mainloop_v2<RTW, CH>(lds4, wp, (size_t)64 * 4, LS4, rows, n, rho0, q, vmask, acc);
-#else
-        conv_mainloop<RTW, CH>(lds4, wp, (size_t)64 * 4, LS4, rows, n, nsq, rho0, q, acc);
-#endif
+        conv_mainloop<RTW, CH>(lds4, wp, (size_t)64 * 4, LS4, rows, n, rho0, q, vmask, acc);
         for (int j = 0; j < RTW; j++) tot += acc[j];
     }
     out[blockIdx.x * 512 + tid] = tot[0] + tot[1] + tot[2] + tot[3];

@@ -9,71 +9,12 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int LDS_PAD = 4;  // floats appended to every LDS row: consecutive rows shift by 4 banks
 
-// Implicit-GEMM main loop of k_tower: RTW row tiles × one 16-channel tile, K = 9·16·CH.
-// What the MFMA pipe is sensitive to (scripts/probes/mfma_probe.hip, MI355X): a per-chunk global weight load
-// consumed in the next iteration (−11 %: hipcc sinks it next to its use) and bursts of address arithmetic at
-// every tap that the two waves of a SIMD execute in lock-step (−12 %).  So: the 9-bit tap-validity mask of
-// every row is computed once, a tap switch costs 3 VALU per tile, chunk offsets are ds_read immediates
-// (CH is a compile-time constant), and the weights run two chunks ahead of the MFMAs.
-template <int RTW, int CH>
-__device__ __forceinline__ void conv_mainloop(const f32x4* __restrict__ lds4, const f32x4* __restrict__ wp, size_t wstride4,
-                                              int LS4, int rows, int n, int nsq, int rho0, int q, f32x4 (&acc)[RTW]) {
-    constexpr int total = 9 * CH;
-    const int zero4 = rows * LS4 + q;
-    int vmask[RTW];  // bit t set ⇔ tap t of this row stays on the board
-#pragma unroll
-    for (int j = 0; j < RTW; j++) {
-        int rho = rho0 + j * 16;
-        int p = rho / nsq;
-        int sq = rho - p * nsq;
-        int y = sq / n, x = sq - y * n;
-        int m = 0;
-#pragma unroll
-        for (int t = 0; t < 9; t++) {
-            int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-            if (yy >= 0 && yy < n && xx >= 0 && xx < n) m |= 1 << t;
-        }
-        vmask[j] = rho < rows ? m : 0;
-    }
-    const int base0 = rho0 * LS4 + q;
-    f32x4 w0 = wp[0];
-    f32x4 w1 = wp[wstride4];
-    int kk = 0;
-#pragma unroll 1
-    for (int tap = 0; tap < 9; tap++) {
-        const int shift = ((tap / 3 - 1) * n + (tap % 3 - 1)) * LS4;  // scalar
-        int aoff[RTW];
-#pragma unroll
-#if defined(PROBE_NO_SHIFT)
-        for (int j = 0; j < RTW; j++) aoff[j] = base0 + j * 16 * LS4;
-#else
-        for (int j = 0; j < RTW; j++) aoff[j] = ((vmask[j] >> tap) & 1) ? base0 + j * 16 * LS4 + shift : zero4;
-#endif
-#pragma unroll
-        for (int kc = 0; kc < CH; kc++) {
-            const int k2 = kk + 2 < total ? kk + 2 : total - 1;
-#if defined(PROBE_NO_WSTREAM)
-            const f32x4 w2 = w1;
-#else
-            const f32x4 w2 = wp[(size_t)k2 * wstride4];
-#endif
-            f32x4 a[RTW];
-#pragma unroll
-            for (int j = 0; j < RTW; j++) a[j] = lds4[aoff[j] + kc * 4];
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-#pragma unroll
-                for (int j = 0; j < RTW; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t], a[j][t], acc[j], 0, 0, 0);
-#if defined(PROBE_CHUNK_FENCE)
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-            w0 = w1;
-            w1 = w2;
-            kk++;
-        }
-    }
-}
-
+// What the MFMA pipe is sensitive to (scripts/probes/, MI355X): a per-chunk global weight load consumed in the
+// next iteration costs 11 % (hipcc sinks it next to its use), bursts of address arithmetic at every tap that the
+// two waves of a SIMD execute in lock-step cost 12 %.  So: the 9-bit tap-validity mask of every row is computed
+// once per kernel, a tap switch costs 3 VALU per tile, chunk offsets are ds_read immediates (CH is a compile-time
+// constant), the weights run two chunks ahead of the MFMAs, and the row tiles are split in two halves that are
+// reloaded in place while the other half's MFMAs issue.
 
 // 9-bit tap-validity mask of the row tiles of one lane: bit t set ⇔ tap t (dy = t/3-1, dx = t%3-1) of that row
 // stays on the board; rows ≥ `rows` get 0 (every tap reads the zero row).
@@ -95,12 +36,13 @@ __device__ __forceinline__ void conv_tap_masks(int rows, int n, int nsq, int rho
     }
 }
 
-// Variant 2: explicit half-tile software pipeline that also runs across tap boundaries.
+// Implicit-GEMM main loop of k_tower: RTW row tiles × one 16-channel tile, K = 9·16·CH.  Explicit half-tile
+// software pipeline that also runs across tap boundaries:
 //     load H2(s) | MFMA H1(s) | load H1(s+1), w(s+2) | MFMA H2(s)
 // The two halves of the row tiles are reloaded in place (no second register set); the tap offsets of a half are
 // refreshed (3 VALU per tile) right before that half's first load of the new tap.
 template <int RTW, int CH, int NM>
-__device__ __forceinline__ void conv_mainloop_v2(const f32x4* __restrict__ lds4, const f32x4* __restrict__ wp, size_t wstride4,
+__device__ __forceinline__ void conv_mainloop(const f32x4* __restrict__ lds4, const f32x4* __restrict__ wp, size_t wstride4,
                                                  int LS4, int rows, int n, int rho0, int q, const int (&vmask)[NM],
                                                  f32x4 (&acc)[RTW]) {
     static_assert(NM >= RTW, "tap masks for every row tile");

@@ -347,11 +347,11 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
         const bool short_group = (rg * RTW + RTW - 1) * 16 >= rows && RTW > 1;
         if (short_group) {
             f32x4 (&acs)[RTW - 1] = *reinterpret_cast<f32x4 (*)[RTW - 1]>(&acc[0]);
-            if (layer == 0) conv_mainloop_v2<RTW - 1, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acs);
-            else conv_mainloop_v2<RTW - 1, CH>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acs);
+            if (layer == 0) conv_mainloop<RTW - 1, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acs);
+            else conv_mainloop<RTW - 1, CH>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acs);
         } else {
-            if (layer == 0) conv_mainloop_v2<RTW, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acc);
-            else conv_mainloop_v2<RTW, CH>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acc);
+            if (layer == 0) conv_mainloop<RTW, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acc);
+            else conv_mainloop<RTW, CH>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acc);
         }
         // ---- epilogue on the accumulators: lane holds out[row][ch0 + 4q .. 4q+3] ----
         const f32x4 bv = *(const f32x4*)&T.b[layer][ch0 + 4 * q];

@@ -601,22 +601,52 @@ __global__ __launch_bounds__(256) void k_softmax(const float* __restrict__ logit
         int ch = p / nsq, sq = p - ch * nsq;
         return x[sq * ch_stride + ch];
     };
+    // the row is read once and kept in registers when it fits (P ≤ 8·256: the FC head's 1575 outputs)
+    constexpr int KEEP = 8;
+    const bool cached = P <= KEEP * 256;
+    float v[KEEP];
     float mx = -INFINITY;
-    for (int p = tid; p < P; p += 256) mx = fmaxf(mx, at(p));
+    if (cached) {
+#pragma unroll
+        for (int k = 0; k < KEEP; k++) {
+            int p = tid + k * 256;
+            v[k] = p < P ? at(p) : -INFINITY;
+            mx = fmaxf(mx, v[k]);
+        }
+    } else {
+        for (int p = tid; p < P; p += 256) mx = fmaxf(mx, at(p));
+    }
     mx = wave_max(mx);
     if ((tid & 63) == 0) red[tid >> 6] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
     float s = 0.0f;
-    for (int p = tid; p < P; p += 256) s += expf(at(p) - mx);
+    if (cached) {
+#pragma unroll
+        for (int k = 0; k < KEEP; k++) {
+            int p = tid + k * 256;
+            v[k] = p < P ? expf(v[k] - mx) : 0.0f;
+            s += v[k];
+        }
+    } else {
+        for (int p = tid; p < P; p += 256) s += expf(at(p) - mx);
+    }
     s = wave_sum(s);
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
     s = (red[0] + red[1]) + (red[2] + red[3]);
     float inv = 1.0f / s;
     float* o = policy + (size_t)b * P;
-    for (int p = tid; p < P; p += 256) o[p] = expf(at(p) - mx) * inv;
+    if (cached) {
+#pragma unroll
+        for (int k = 0; k < KEEP; k++) {
+            int p = tid + k * 256;
+            if (p < P) o[p] = v[k] * inv;
+        }
+    } else {
+        for (int p = tid; p < P; p += 256) o[p] = expf(at(p) - mx) * inv;
+    }
 }
 
 // NCHW planes (the reference tensor layout) → NHWC rows padded to Cpad channels

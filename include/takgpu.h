@@ -200,6 +200,13 @@ int tg_encode(TgEngine* e, int n, const void* states, float* planes);
  * would panic ("could not map turn to index"). */
 int tg_move_index(TgEngine* e, int k, const TgMove* moves, int32_t* index);
 
+/* Example::to_tensors (alpha-tak/src/example.rs:62-78) over Symmetry (tak/src/symm.rs:7-97): the 8 dihedral
+ * images of n examples.  In: n states, per example n_moves[i] (move, visits) pairs in rows of TG_MAX_MOVES.
+ * Out: 8n packed states (image order of symm.rs:11-20; feed them to tg_encode for the input planes) and 8n
+ * policy targets of P floats: visits/total at move_index of the transformed move, 0 elsewhere. */
+int tg_augment_examples(TgEngine* e, int n, const void* states, const int32_t* n_moves, const TgMove* moves,
+                        const uint32_t* visits, void* out_states, float* pi);
+
 /* perft of tak/tests/perft.rs:3-18 evaluated on the GPU: one count per input state.
  * depth ≥ 0.  Expands level by level on the device (movegen+play+result kernels). */
 int tg_perft(TgEngine* e, int n, const void* states, int depth, uint64_t* counts);

@@ -180,6 +180,19 @@ def move_index(n, moves):
     return out
 
 
+def augment(n, head, states, n_moves, moves, visits):
+    """Example::to_tensors: (8k states, 8k × P policy targets) in the order of tak/src/symm.rs."""
+    states, k = _states(n, states)
+    psize = policy_size(n, head)
+    n_moves = np.ascontiguousarray(n_moves, np.int32)
+    moves = np.ascontiguousarray(moves, np.uint16).reshape(k, TG_MAX_MOVES)
+    visits = np.ascontiguousarray(visits, np.uint32).reshape(k, TG_MAX_MOVES)
+    out = np.zeros((k * 8, state_bytes(n)), np.uint8)
+    pi = np.zeros((k * 8, psize), np.float32)
+    lib().orc_augment(n, k, psize, _p(states), _p(n_moves), _p(moves), _p(visits), _p(out), _p(pi))
+    return out, pi
+
+
 def perft(n, state, depth):
     return int(lib().orc_perft(n, _p(np.ascontiguousarray(state, np.uint8)), depth))
 

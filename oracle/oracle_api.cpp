@@ -314,6 +314,28 @@ void orc_selfplay_states(void* hh, uint8_t* states, uint8_t* alive) {
     for (size_t g = 0; g < sp.s.games.size(); g++) { pack(sp.s.games[g], states + g * sb); alive[g] = sp.s.alive[g]; }
 }
 
+// Example::to_tensors: k examples → 8k symmetric states + 8k policy targets (policy_size each)
+void orc_augment(int n, int k, int policy_size, const uint8_t* states, const int32_t* n_moves, const TgMove* moves,
+                 const uint32_t* visits, uint8_t* out_states, float* pi) {
+    size_t sb = state_bytes(n);
+    for (int e = 0; e < k; e++) {
+        Game g = unpack(states + e * sb, n);
+        std::vector<Move> mv;
+        std::vector<uint32_t> vs;
+        for (int j = 0; j < n_moves[e]; j++) {
+            mv.push_back(decode_move(moves[(size_t)e * TG_MAX_MOVES + j], n));
+            vs.push_back(visits[(size_t)e * TG_MAX_MOVES + j]);
+        }
+        Game og[8];
+        std::vector<float> opi[8];
+        example_symmetries(g, mv, vs, policy_size, og, opi);
+        for (int i = 0; i < 8; i++) {
+            pack(og[i], out_states + ((size_t)e * 8 + i) * sb);
+            std::memcpy(pi + ((size_t)e * 8 + i) * policy_size, opi[i].data(), (size_t)policy_size * 4);
+        }
+    }
+}
+
 // rng / math spec probes (so tests can compare the product's device implementation)
 void orc_philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t* out) { Philox::gen(seed, c0, c1, c2, c3, out); }
 void orc_dirichlet(int k, double alpha, uint64_t seed, uint32_t slot, uint32_t generation, uint32_t ply, float* out) {

@@ -145,4 +145,61 @@ inline int move_index(const Move& m, int n) {
     return channel * n * n + m.row * n + m.col;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Symmetry, tak/src/symm.rs:7-97 — the 8 dihedral images of squares, directions, moves, boards, games.
+// takparse's Square::rotate/mirror and Direction::rotate/mirror are not vendored; the orientation used here
+// (rotate: (col,row) → (row, n-1-col), Up→Right→Down→Left; mirror: col → n-1-col, Left↔Right) is one of the
+// mutually consistent choices that tak/tests/symm.rs pins.  Any consistent choice yields the same SET of 8
+// images (used together for training), possibly in another order: "parity unpinned" for the order only.
+// ---------------------------------------------------------------------------------------
+inline void sq_rotate(int n, int& col, int& row) { int c = row, r = n - 1 - col; col = c; row = r; }
+inline void sq_mirror(int n, int& col, int& row) { col = n - 1 - col; (void)row; }
+inline uint8_t dir_rotate(uint8_t d) { return d == UP ? RIGHT : d == RIGHT ? DOWN : d == DOWN ? LEFT : UP; }
+inline uint8_t dir_mirror(uint8_t d) { return d == LEFT ? RIGHT : d == RIGHT ? LEFT : d; }
+
+// i-th symmetry (order of symm.rs:11-20): i<4 → rotate^i ; i≥4 → mirror then rotate^(i-4)
+inline void sq_symmetry(int n, int i, int& col, int& row) {
+    if (i >= 4) sq_mirror(n, col, row);
+    for (int k = 0; k < (i & 3); k++) sq_rotate(n, col, row);
+}
+inline uint8_t dir_symmetry(int i, uint8_t d) {
+    if (i >= 4) d = dir_mirror(d);
+    for (int k = 0; k < (i & 3); k++) d = dir_rotate(d);
+    return d;
+}
+inline Move move_symmetry(int n, int i, const Move& m) {  // symm.rs:40-52
+    Move o = m;
+    int c = m.col, r = m.row;
+    sq_symmetry(n, i, c, r);
+    o.col = (uint8_t)c; o.row = (uint8_t)r;
+    if (m.spread) o.dir = dir_symmetry(i, m.dir);
+    return o;
+}
+inline Game game_symmetry(int i, const Game& g) {  // symm.rs:55-97
+    Game o = g;
+    for (int y = 0; y < g.n; y++) for (int x = 0; x < g.n; x++) {
+        int c = x, r = y;
+        sq_symmetry(g.n, i, c, r);
+        o.board[r][c] = g.board[y][x];
+    }
+    return o;
+}
+
+// Example::to_tensors, alpha-tak/src/example.rs:62-78: per symmetry the transformed game and the policy target
+inline void example_symmetries(const Game& g, const std::vector<Move>& moves, const std::vector<uint32_t>& visits, int policy_size,
+                               Game out_games[8], std::vector<float> out_pi[8]) {
+    uint32_t total_u = 0;
+    for (uint32_t v : visits) total_u += v;
+    float total = (float)total_u;
+    for (int i = 0; i < 8; i++) {
+        out_games[i] = game_symmetry(i, g);
+        out_pi[i].assign(policy_size, 0.0f);
+        for (size_t k = 0; k < moves.size(); k++) {
+            int idx = move_index(move_symmetry(g.n, i, moves[k]), g.n);
+            if (idx >= 0 && idx < policy_size) out_pi[i][idx] = (float)visits[k] / total;
+        }
+    }
+}
+
 }  // namespace orc

@@ -124,6 +124,64 @@ __global__ __launch_bounds__(256) void k_board_pass(const uint8_t* __restrict__ 
     if (lane_id() == 0) { results[gi] = (uint8_t)r; counts[gi] = c; }
 }
 
+// Symmetry (tak/src/symm.rs) + Example::to_tensors (alpha-tak/src/example.rs:62-78): one wave per
+// (example, symmetry).  Squares: rotate (col,row) → (row, n-1-col), mirror col → n-1-col; symmetry i < 4 is
+// rotate^i, i ≥ 4 is mirror then rotate^(i-4).  Directions follow the squares (Up→Right→Down→Left, Left↔Right).
+__device__ inline void sym_apply(int n, int i, int& col, int& row) {
+    if (i >= 4) col = n - 1 - col;
+    for (int k = 0; k < (i & 3); k++) { int c = row, r = n - 1 - col; col = c; row = r; }
+}
+__device__ inline void sym_apply_inverse(int n, int i, int& col, int& row) {
+    for (int k = 0; k < (i & 3); k++) { int c = n - 1 - row, r = col; col = c; row = r; }
+    if (i >= 4) col = n - 1 - col;
+}
+__device__ inline uint32_t sym_dir(int i, uint32_t d) {
+    if (i >= 4) d = d == LEFT ? RIGHT : d == RIGHT ? LEFT : d;
+    for (int k = 0; k < (i & 3); k++) d = d == UP ? RIGHT : d == RIGHT ? DOWN : d == DOWN ? LEFT : UP;
+    return d;
+}
+
+__global__ __launch_bounds__(256) void k_augment(const uint8_t* __restrict__ states, const int32_t* __restrict__ n_moves,
+                                                 const uint16_t* __restrict__ moves, const uint32_t* __restrict__ visits, int count,
+                                                 int n, int P, int legacy5, const int16_t* __restrict__ lut5,
+                                                 uint8_t* __restrict__ out_states, float* __restrict__ pi) {
+    int wi = wave_global_id();
+    if (wi >= count * 8) return;
+    const int ex = wi >> 3, sym = wi & 7;
+    const int lane = lane_id();
+    Geom g = make_geom(n);
+    WState s;
+    ws_load(s, states + (size_t)ex * g.bytes, g);
+    // board: the square this lane ends up holding comes from its pre-image under the symmetry
+    int col = lane % n, row = lane / n;
+    sym_apply_inverse(n, sym, col, row);
+    int src = lane < g.nsq ? row * n + col : lane;
+    WState t = s;
+    t.stack = shfl64(s.stack, src);
+    t.height = (uint32_t)__shfl((int)s.height, src);
+    t.top = (uint32_t)__shfl((int)s.top, src);
+    ws_store(t, out_states + (size_t)wi * g.bytes, g);
+    // policy target: visits / total at the index of the transformed move (pi is zeroed by the host)
+    const int nm = n_moves[ex];
+    const uint32_t* vs = visits + (size_t)ex * TG_MAX_MOVES;
+    const uint16_t* mv = moves + (size_t)ex * TG_MAX_MOVES;
+    uint32_t part = 0;
+    for (int k = lane; k < nm; k += 64) part += vs[k];
+    for (int d = 32; d >= 1; d >>= 1) part += (uint32_t)__shfl_xor((int)part, d);
+    const float total = (float)part;
+    float* row_pi = pi + (size_t)wi * P;
+    for (int k = lane; k < nm; k += 64) {
+        uint32_t m = mv[k];
+        int c = (int)(m & 63u) % n, r = (int)(m & 63u) / n;
+        sym_apply(n, sym, c, r);
+        uint32_t pat = m >> 8, f = (m >> 6) & 3u;
+        if (pat) f = sym_dir(sym, f);
+        uint32_t tm = (uint32_t)(r * n + c) | (f << 6) | (pat << 8);
+        int idx = move_index_dev(tm, n, legacy5 != 0, lut5);
+        if (idx >= 0 && idx < P) row_pi[idx] = (float)vs[k] / total;
+    }
+}
+
 // ---- launchers --------------------------------------------------------------------------------
 static inline dim3 wave_grid(int count) { return dim3((count + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK); }
 
@@ -148,6 +206,11 @@ void launch_encode_nhwc(hipStream_t st, const uint8_t* states, int count, int n,
 void launch_board_pass(hipStream_t st, const uint8_t* states, const uint16_t* moves, int count, int n, uint8_t* out_states,
                        uint8_t* results, int32_t* counts, float* planes, int cstride) {
     if (count > 0) hipLaunchKernelGGL(k_board_pass, wave_grid(count), dim3(256), 0, st, states, moves, count, n, out_states, results, counts, planes, cstride);
+}
+void launch_augment(hipStream_t st, const uint8_t* states, const int32_t* n_moves, const uint16_t* moves, const uint32_t* visits, int count,
+                    int n, int P, bool legacy5, const int16_t* lut5, uint8_t* out_states, float* pi) {
+    if (count > 0) hipLaunchKernelGGL(k_augment, wave_grid(count * 8), dim3(256), 0, st, states, n_moves, moves, visits, count, n, P,
+                                      legacy5 ? 1 : 0, lut5, out_states, pi);
 }
 void launch_move_index(hipStream_t st, const uint16_t* moves, int count, int n, bool legacy5, const int16_t* lut5, int32_t* index) {
     if (count > 0) hipLaunchKernelGGL(k_move_index, dim3((count + 255) / 256), dim3(256), 0, st, moves, count, n, legacy5 ? 1 : 0, lut5, index);

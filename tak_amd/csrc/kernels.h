@@ -13,6 +13,8 @@ void launch_encode(hipStream_t st, const uint8_t* states, int count, int n, floa
 void launch_encode_nhwc(hipStream_t st, const uint8_t* states, int count, int n, float* planes, int cstride);
 void launch_board_pass(hipStream_t st, const uint8_t* states, const uint16_t* moves, int count, int n, uint8_t* out_states,
                        uint8_t* results, int32_t* counts, float* planes, int cstride);
+void launch_augment(hipStream_t st, const uint8_t* states, const int32_t* n_moves, const uint16_t* moves, const uint32_t* visits, int count,
+                    int n, int P, bool legacy5, const int16_t* lut5, uint8_t* out_states, float* pi);
 void launch_move_index(hipStream_t st, const uint16_t* moves, int count, int n, bool legacy5, const int16_t* lut5, int32_t* index);
 void launch_perft_count(hipStream_t st, const uint8_t* states, int count, int n, int32_t* nchild, uint8_t* terminal);
 void launch_perft_expand(hipStream_t st, const uint8_t* states, int count, int n, const int64_t* offsets, const int32_t* root_of,

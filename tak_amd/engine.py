@@ -66,6 +66,7 @@ ABI_SYMBOLS = [
     "tg_search_root", "tg_search_play", "tg_search_states", "tg_search_dump", "tg_search_counters",
     "tg_selfplay_create", "tg_selfplay_step", "tg_selfplay_stats", "tg_selfplay_drain",
     "tg_profile_enable", "tg_profile_read", "tg_board_pass_bench",
+    "tg_augment_examples",
     "tg_format_move", "tg_parse_move", "tg_format_tps", "tg_parse_tps", "tg_format_example", "tg_parse_example",
 ]
 
@@ -249,6 +250,17 @@ class Engine:
         out = np.zeros(moves.size, np.int32)
         self._check(self.lib.tg_move_index(self.h, moves.size, _p(moves), _p(out)))
         return out
+
+    def augment_examples(self, states, n_moves, moves, visits):
+        """Example::to_tensors: 8 symmetric states and policy targets per example."""
+        states, k = self._states(states)
+        n_moves = np.ascontiguousarray(n_moves, np.int32)
+        moves = np.ascontiguousarray(moves, np.uint16).reshape(k, TG_MAX_MOVES)
+        visits = np.ascontiguousarray(visits, np.uint32).reshape(k, TG_MAX_MOVES)
+        out = np.zeros((k * 8, self.sb), np.uint8)
+        pi = np.zeros((k * 8, self.psize), np.float32)
+        self._check(self.lib.tg_augment_examples(self.h, k, _p(states), _p(n_moves), _p(moves), _p(visits), _p(out), _p(pi)))
+        return out, pi
 
     def perft(self, states, depth):
         states, k = self._states(states)

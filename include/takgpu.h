@@ -340,10 +340,59 @@ int tg_selfplay_drain(TgEngine* e, int cap, TgExampleHeader* headers, void* stat
                       uint32_t* visits, int32_t* n_out);
 
 /* ---------------------------------------------------------------------------------------
+ * Training step (replaces Network::train / train_inner, alpha-tak/src/model/network.rs:37-97, and the
+ * forward_training of net5.rs:113-118 / net6.rs:111-122).  SURVEY.md §8(f) N2 / config C5.
+ * The master parameters live on the device in tch layout; every chunk is augmented with the 8 symmetries
+ * (Example::to_tensors), encoded, run forward with BatchNorm in training mode (batch statistics, running
+ * statistics updated with momentum), and back-propagated with hand-written HIP kernels; gradients accumulate
+ * over `chunks_in_step` chunks, then one Adam step (L2 weight decay, as tch's nn::Adam{wd}).
+ * Data parallel: after tg_train_comm_init every optimiser step all-reduces (RCCL, sum, f32) the flat gradient
+ * buffer and divides by the world size — the only collective of the whole build.
+ * ------------------------------------------------------------------------------------- */
+typedef struct TgTrainConfig {
+    float learning_rate;    /* LEARNING_RATE 1e-4 (network.rs:14) */
+    float weight_decay;     /* WEIGHT_DECAY 1e-4 (network.rs:15)  */
+    float beta1, beta2, eps;/* tch Adam defaults 0.9, 0.999, 1e-8 */
+    float bn_momentum;      /* tch BatchNormConfig default 0.1 */
+    float bn_eps;           /* 1e-5 */
+    int32_t chunk_size;     /* CHUNK_SIZE 500 examples; ×8 symmetries = positions per forward/backward */
+    int32_t chunks_in_step; /* CHUNKS_IN_STEP 20 */
+    int32_t reserved;
+} TgTrainConfig;
+
+/* Adam{wd}.build(vs, lr) (network.rs:40-45): creates the trainer from the tensors given to tg_net_set_tensor
+ * (all of them, as for tg_net_finalize) with zero optimiser state and zero gradients. */
+int tg_train_create(TgEngine* e, const TgTrainConfig* cfg);
+/* train_inner (network.rs:58-97) on one chunk of n ≤ chunk_size examples (layout of tg_selfplay_drain:
+ * states, n_moves, rows of TG_MAX_MOVES moves / visits; results = Example::result).  Returns the two losses
+ * the reference prints (loss_p, loss_z); *stepped = 1 when this chunk completed an optimiser step. */
+int tg_train_chunk(TgEngine* e, int n, const void* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
+                   const float* results, float* loss_p, float* loss_z, int32_t* stepped);
+/* Network::train (network.rs:37-56): fresh Adam state, shuffle (Philox keyed by seed; the reference uses
+ * thread_rng), chunks_exact(chunk_size) → tg_train_chunk each.  mean losses over the chunks are returned. */
+int tg_train(TgEngine* e, int n, const void* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
+             const float* results, uint64_t seed, float* mean_loss_p, float* mean_loss_z, int32_t* steps);
+/* opt.step(); opt.zero_grad() now (network.rs:92-96), whatever the chunk counter says */
+int tg_train_step(TgEngine* e);
+/* forward_training (net5.rs:113-118): n ≤ 8·chunk_size states → log_softmax policy (n × P) and eval (n),
+ * BatchNorm on the statistics of this batch (running statistics are updated, as in libtorch). */
+int tg_train_forward(TgEngine* e, int n, const void* states, float* logp, float* eval);
+/* current value of a parameter / BN buffer (names of tg_net_set_tensor) and of its accumulated gradient */
+int tg_train_get_tensor(TgEngine* e, const char* name, float* out, size_t count);
+int tg_train_get_grad(TgEngine* e, const char* name, float* out, size_t count);
+/* make the trained parameters the ones tg_policy_eval / search / self-play use (tg_net_set_tensor of every
+ * tensor + tg_net_finalize).  With a communicator the BN running statistics are averaged over the ranks first. */
+int tg_train_commit(TgEngine* e);
+/* RCCL communicator for the gradient all-reduce: rank 0 calls tg_comm_unique_id (128 bytes) and hands the id
+ * to every rank (any host transport); then every rank calls tg_train_comm_init. */
+int tg_comm_unique_id(void* id128);
+int tg_train_comm_init(TgEngine* e, int rank, int world_size, const void* id128);
+
+/* ---------------------------------------------------------------------------------------
  * Text formats at the edge of the path (host only).  PTN moves / TPS positions follow takparse 0.5.5's
  * Display + FromStr as used by tak/src/game.rs:79 and tak/src/tps.rs:7-96; the example line follows
  * alpha-tak/src/example.rs:81-133 ("{tps};{w_stones};{w_caps};{b_stones};{b_caps};{half_komi};{result};
- * {move:visits,…}"), so drained examples can be written as the reference's `_examples/*.data` files.
+ * {move:visits,…}"), so drained examples can be written as the reference's `_examples/{time}.data` files.
  * format functions return the text length (≥ 0) or a negative TgStatus.
  * ------------------------------------------------------------------------------------- */
 int tg_format_move(int n, TgMove mv, char* buf, size_t cap);

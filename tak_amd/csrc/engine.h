@@ -53,6 +53,7 @@ struct DevBuf {
 
 struct Net;     // net.hip
 struct Search;  // search.hip
+struct Trainer; // train.hip
 
 }  // namespace tg
 
@@ -69,6 +70,7 @@ struct TgEngine {
     tg::DevBuf s_states, s_moves, s_counts, s_status, s_planes, s_policy, s_eval, s_index;
     tg::Net* net = nullptr;
     tg::Search* search = nullptr;
+    tg::Trainer* trainer = nullptr;
     ~TgEngine();
 };
 
@@ -87,4 +89,7 @@ int net_forward_dev(TgEngine* e, int n, const float* d_planes_nhwc, float* d_pol
 // same from packed states (device); encodes inside the fused tower when the topology allows, else via k_encode
 int net_forward_states_dev(TgEngine* e, int n, const uint8_t* d_states, float* d_policy, float* d_eval);
 bool net_takes_states(const TgEngine* e);  // true when the fused tower encodes in-kernel
+const std::map<std::string, std::vector<float>>* net_tensors(const TgEngine* e);  // tensors as given to tg_net_set_tensor
+// train.hip
+void trainer_destroy(Trainer* t);
 }  // namespace tg

@@ -41,6 +41,38 @@ hipError_t launch_softmax(hipStream_t st, const float* logits, int row_stride, b
                           int B, float* policy);
 hipError_t launch_nchw_to_nhwc(hipStream_t st, const float* src, int B, int C, int nsq, int Cpad, float* dst);
 
+// train_kernels.hip
+hipError_t launch_pack_conv_fwd(hipStream_t st, const float* W, int O, int I, int Ipad, int OP, float* dst);
+hipError_t launch_pack_conv_bwd(hipStream_t st, const float* W, int O, int I, int Opad, int IP, float* dst);
+hipError_t launch_pack_fc_fwd(hipStream_t st, const float* W, int P, int F, int nsq, int NP, float* dst);
+hipError_t launch_pack_fc_bwd(hipStream_t st, const float* W, int P, int F, int nsq, int Pp, int KP, float* dst);
+hipError_t launch_pack_value(hipStream_t st, const float* W, int F, int nsq, float* dst);
+hipError_t launch_pad_copy(hipStream_t st, const float* src, int n, int npad, float* dst);
+int col_reduce_blocks(int M, int F, int* rows_per_block);
+hipError_t launch_bn_stats(hipStream_t st, const float* z, int M, int F, float eps, float momentum, double* part, float* mean,
+                           float* invstd, float* running_mean, float* running_var);
+hipError_t launch_bn_fwd_apply(hipStream_t st, const float* z, const float* mean, const float* invstd, const float* gamma,
+                               const float* beta, const float* skip, float* y, int M, int F);
+hipError_t launch_bn_bwd(hipStream_t st, const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
+                         const float* gamma, int M, int F, double* part, float* mean_g, float* mean_gx, float* grad_gamma,
+                         float* grad_beta, float* dz, float* gskip);
+hipError_t launch_colsum_acc(hipStream_t st, const float* a, int M, int Fp, int valid, double* part, float* grad);
+hipError_t launch_policy_loss(hipStream_t st, const float* logits, int row_stride, bool conv_head, int nsq, int ch_stride, int P, int B,
+                              const float* pi, float inv_b, float* dlogits, float* logp_out, float* loss_rows);
+hipError_t launch_value_train(hipStream_t st, const float* act, const float* wv, const float* bv, int B, int len, const float* zt,
+                              float inv_b, float* eval, float* dpre, float* loss_rows);
+hipError_t launch_value_bwd(hipStream_t st, const float* act, const float* dpre, const float* wv, int B, int F, int nsq, float* ds,
+                            double* part, float* grad_w, float* grad_b);
+size_t wgrad_conv_workspace(int B, int n, int I, int O);
+hipError_t launch_wgrad_conv(hipStream_t st, const float* X, int xs, int I, const float* G, int gs, int O, int B, int n, float* part,
+                             float* grad);
+size_t wgrad_fc_workspace(int B, int K, int P);
+hipError_t launch_wgrad_fc(hipStream_t st, const float* S, int K, const float* G, int gs, int P, int B, int F, int nsq, float* part,
+                           float* grad);
+hipError_t launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                       float wd, float bc1, float bc2_sqrt, float gscale);
+hipError_t launch_sum_rows(hipStream_t st, const float* rows, int n, double* out);
+
 // search_kernels.hip
 struct SearchDev;
 struct SelfPlayDev;

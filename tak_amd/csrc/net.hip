@@ -88,6 +88,7 @@ int net_set_tensor(TgEngine* e, const char* name, const float* data, size_t coun
 }
 
 bool net_ready(const TgEngine* e) { return e && e->net && e->net->ready; }
+const std::map<std::string, std::vector<float>>* net_tensors(const TgEngine* e) { return e && e->net ? &e->net->tensors : nullptr; }
 
 namespace {
 

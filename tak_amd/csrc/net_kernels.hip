@@ -711,6 +711,10 @@ hipError_t launch_conv3x3(hipStream_t st, const float* in, const float* Wp, cons
         return launch_conv_pos_t<9, 8>(st, in, Wp, bias, res, out, B, n, Cpad, CoutP, out_stride, cout_valid, relu, 4, 8);
     if (n == 5 && CoutP % 128 == 0 && Cpad <= 128)  // 8 positions = 200 rows in 13 row tiles, 8 channel tiles
         return launch_conv_pos_t<13, 8>(st, in, Wp, bias, res, out, B, n, Cpad, CoutP, out_stride, cout_valid, relu, 8, 8);
+    if (conv_lds_bytes(2, n, Cpad) > 160 * 1024) {  // wide inputs (data gradient of the 6×6 policy head): 64-row tiles
+        if (CoutP % 128 == 0) return launch_conv_t<1, 2>(st, in, Wp, bias, res, out, M, n, Cpad, CoutP, out_stride, cout_valid, relu);
+        return launch_conv_t<1, 1>(st, in, Wp, bias, res, out, M, n, Cpad, CoutP, out_stride, cout_valid, relu);
+    }
     if (CoutP % 128 == 0) return launch_conv_t<2, 2>(st, in, Wp, bias, res, out, M, n, Cpad, CoutP, out_stride, cout_valid, relu);
     return launch_conv_t<2, 1>(st, in, Wp, bias, res, out, M, n, Cpad, CoutP, out_stride, cout_valid, relu);
 }

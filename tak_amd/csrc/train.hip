@@ -1,0 +1,636 @@
+// train.hip — host side of the training step: Network::train / train_inner (reference
+// alpha-tak/src/model/network.rs:37-97) and forward_training (net5.rs:113-118, net6.rs:111-122) without tch.
+//
+// Master parameters, gradients and Adam moments are flat f32 device buffers in tch layout (conv OIHW,
+// linear [out,in], BN vectors) in the creation order of net5.rs:29-62, so Adam is one elementwise kernel and
+// the data-parallel gradient exchange is ONE RCCL all-reduce of the flat gradient buffer per optimiser step.
+// Before a forward the parameters are re-packed (cheap, ≤ 8 M floats) into the MFMA fragment layouts of the
+// forward and data-gradient convolutions.  Schedule per chunk (everything on the engine stream):
+//   augment ×8 → encode NHWC → [conv → BN(batch stats) → ReLU(+skip)]×(1+2R) → heads → losses
+//   → head gradients → per layer in reverse: BN backward → weight gradient (TN implicit GEMM) → data gradient.
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "engine.h"
+#include "kernels.h"
+#include "rng.cuh"
+
+namespace tg {
+
+struct Id128 { char bytes[128]; };  // ncclUniqueId
+
+namespace {
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct ParamInfo {
+    std::string name;
+    size_t off = 0, count = 0;
+    bool buffer = false;  // BN running statistics (not trained)
+};
+
+struct TrainConv {
+    int I = 0, O = 0;        // channels
+    int in_stride = 0;       // row stride of its input activation
+    int OP = 0;              // padded output channels of the forward fragments
+    int out_stride = 0;      // row stride of its output (z)
+    int bn = -1;             // BatchNorm index, -1 for the policy conv head
+    size_t w = 0, b = 0, gamma = 0, beta = 0;  // offsets into params / grads
+    size_t rmean = 0, rvar = 0;                // offsets into the BN buffer
+    DevBuf wf, wb, bias_pad;                   // forward fragments, data-gradient fragments, padded bias
+    DevBuf z, y;                               // conv output, activation after BN/ReLU(/skip)
+};
+
+// ---- RCCL through dlopen: self-play users never load it -----------------------------------------
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id128 /*ncclUniqueId by value*/, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load() {
+    if (g_rccl.lib) return TG_OK;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(TG_ERR_STATE, std::string("cannot load librccl: ") + dlerror());
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+        return fail(TG_ERR_STATE, "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce");
+    g_rccl.lib = h;
+    return TG_OK;
+}
+constexpr int NCCL_FLOAT32 = 7, NCCL_SUM = 0;  // ncclDataType_t / ncclRedOp_t values of rccl.h
+}  // namespace
+
+struct Trainer {
+    TgTrainConfig cfg{};
+    int Bmax = 0;  // positions per chunk
+    std::vector<ParamInfo> infos;
+    std::map<std::string, int> index;
+    size_t n_params = 0, n_buffers = 0;
+    DevBuf params, grads, adam_m, adam_v, bnbuf;
+    std::vector<TrainConv> convs;  // conv0, res0.conv1, res0.conv2, …
+    bool conv_head = false;
+    TrainConv pol;                 // conv policy head
+    // FC policy head
+    size_t fc_w = 0, fc_b = 0;
+    int NP = 0, Pp = 0, KP = 0;
+    DevBuf fc_wf, fc_wb, fc_bias;
+    // value head
+    size_t val_w = 0, val_b = 0;
+    DevBuf wv;
+    // chunk inputs / targets
+    DevBuf ex_states, ex_nmoves, ex_moves, ex_visits, states_aug, pi, zt, planes;
+    // heads
+    DevBuf logits, dlogits, logp, eval, dpre, loss_p_rows, loss_z_rows, loss_sums;
+    // backward
+    DevBuf d_a, d_b, dz, gskip, stats, mean_g, mean_gx, zero_bias;
+    DevBuf part_d, part_w;
+    bool packed = false;
+    uint64_t adam_t = 0;
+    int chunk_num = 0;
+    // communicator
+    void* comm = nullptr;
+    int world = 1, rank = 0;
+    ~Trainer() {
+        if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
+    }
+};
+
+void trainer_destroy(Trainer* t) { delete t; }
+
+namespace {
+
+size_t add_info(Trainer* t, const std::string& name, size_t count, bool buffer) {
+    ParamInfo pi;
+    pi.name = name;
+    pi.count = count;
+    pi.buffer = buffer;
+    size_t& cursor = buffer ? t->n_buffers : t->n_params;
+    pi.off = cursor;
+    cursor += (count + 3) / 4 * 4;  // 16-byte aligned slots; the padding stays zero
+    t->index[name] = (int)t->infos.size();
+    t->infos.push_back(pi);
+    return pi.off;
+}
+
+void add_conv(Trainer* t, TrainConv& c, const std::string& conv, const std::string& bn, int O, int I) {
+    c.O = O; c.I = I;
+    c.w = add_info(t, conv + ".weight", (size_t)O * I * 9, false);
+    c.b = add_info(t, conv + ".bias", O, false);
+    (void)bn;
+}
+void add_bn(Trainer* t, TrainConv& c, const std::string& bn, int F, int bn_index) {
+    c.bn = bn_index;
+    c.gamma = add_info(t, bn + ".weight", F, false);
+    c.beta = add_info(t, bn + ".bias", F, false);
+    c.rmean = add_info(t, bn + ".running_mean", F, true);
+    c.rvar = add_info(t, bn + ".running_var", F, true);
+}
+
+int pack_params(TgEngine* e) {
+    Trainer* t = e->trainer;
+    if (t->packed) return TG_OK;
+    hipStream_t st = e->stream;
+    const float* P = t->params.as<float>();
+    const int F = e->cfg.filters, nsq = e->g.nsq;
+    auto pack_conv = [&](TrainConv& c, bool need_bwd) -> hipError_t {
+        hipError_t err = launch_pack_conv_fwd(st, P + c.w, c.O, c.I, c.in_stride, c.OP, c.wf.as<float>());
+        if (err != hipSuccess) return err;
+        err = launch_pad_copy(st, P + c.b, c.O, c.OP, c.bias_pad.as<float>());
+        if (err != hipSuccess) return err;
+        if (need_bwd) err = launch_pack_conv_bwd(st, P + c.w, c.O, c.I, c.out_stride, round_up(c.I, 64), c.wb.as<float>());
+        return err;
+    };
+    for (size_t l = 0; l < t->convs.size(); l++) TG_HIP(pack_conv(t->convs[l], l > 0));
+    if (t->conv_head) TG_HIP(pack_conv(t->pol, true));
+    else {
+        TG_HIP(launch_pack_fc_fwd(st, P + t->fc_w, e->policy_size, F, nsq, t->NP, t->fc_wf.as<float>()));
+        TG_HIP(launch_pack_fc_bwd(st, P + t->fc_w, e->policy_size, F, nsq, t->Pp, t->KP, t->fc_wb.as<float>()));
+        TG_HIP(launch_pad_copy(st, P + t->fc_b, e->policy_size, t->NP, t->fc_bias.as<float>()));
+    }
+    TG_HIP(launch_pack_value(st, P + t->val_w, F, nsq, t->wv.as<float>()));
+    t->packed = true;
+    return TG_OK;
+}
+
+// forward in training mode from the NHWC planes of B positions; fills z/y of every layer, logits, eval
+int forward_train(TgEngine* e, int B, bool with_targets, float* d_logp) {
+    Trainer* t = e->trainer;
+    hipStream_t st = e->stream;
+    const int F = e->cfg.filters, nsq = e->g.nsq, N = e->g.n, M = B * nsq;
+    float* P = t->params.as<float>();
+    float* BN = t->bnbuf.as<float>();
+    float* stats = t->stats.as<float>();
+    int rc = pack_params(e);
+    if (rc) return rc;
+    const float* in = t->planes.as<float>();
+    for (size_t l = 0; l < t->convs.size(); l++) {
+        TrainConv& c = t->convs[l];
+        TG_HIP(launch_conv3x3(st, in, c.wf.as<float>(), c.bias_pad.as<float>(), nullptr, c.z.as<float>(), M, N, c.in_stride, c.OP, F, F, false));
+        float* mean = stats + (size_t)c.bn * 2 * F;
+        float* invstd = mean + F;
+        TG_HIP(launch_bn_stats(st, c.z.as<float>(), M, F, t->cfg.bn_eps, t->cfg.bn_momentum, t->part_d.as<double>(), mean, invstd,
+                               BN + c.rmean, BN + c.rvar));
+        // conv2 of block i (l = 2, 4, …) adds the block input: y of layer l-2
+        const float* skip = (l >= 2 && (l % 2) == 0) ? t->convs[l - 2].y.as<float>() : nullptr;
+        TG_HIP(launch_bn_fwd_apply(st, c.z.as<float>(), mean, invstd, P + c.gamma, P + c.beta, skip, c.y.as<float>(), M, F));
+        in = c.y.as<float>();
+    }
+    const float* s = t->convs.back().y.as<float>();
+    const float inv_b = 1.0f / (float)B;
+    const float* pi = with_targets ? t->pi.as<float>() : nullptr;
+    if (t->conv_head) {
+        TrainConv& c = t->pol;
+        TG_HIP(launch_conv3x3(st, s, c.wf.as<float>(), c.bias_pad.as<float>(), nullptr, t->logits.as<float>(), M, N, F, c.OP, c.OP, c.O, false));
+        TG_HIP(launch_policy_loss(st, t->logits.as<float>(), nsq * c.OP, true, nsq, c.OP, e->policy_size, B, pi, inv_b,
+                                  t->dlogits.as<float>(), d_logp, t->loss_p_rows.as<float>()));
+    } else {
+        TG_HIP(launch_gemm(st, s, nsq * F, t->fc_wf.as<float>(), t->fc_bias.as<float>(), t->logits.as<float>(), B, nsq * F, t->NP, t->NP,
+                           e->policy_size));
+        TG_HIP(launch_policy_loss(st, t->logits.as<float>(), t->NP, false, nsq, 0, e->policy_size, B, pi, inv_b, t->dlogits.as<float>(),
+                                  d_logp, t->loss_p_rows.as<float>()));
+    }
+    TG_HIP(launch_value_train(st, s, t->wv.as<float>(), P + t->val_b, B, nsq * F, with_targets ? t->zt.as<float>() : nullptr, inv_b,
+                              t->eval.as<float>(), t->dpre.as<float>(), t->loss_z_rows.as<float>()));
+    return TG_OK;
+}
+
+int backward_train(TgEngine* e, int B) {
+    Trainer* t = e->trainer;
+    hipStream_t st = e->stream;
+    const int F = e->cfg.filters, nsq = e->g.nsq, N = e->g.n, M = B * nsq;
+    float* P = t->params.as<float>();
+    float* G = t->grads.as<float>();
+    float* stats = t->stats.as<float>();
+    double* part_d = t->part_d.as<double>();
+    float* part_w = t->part_w.as<float>();
+    const float* s = t->convs.back().y.as<float>();
+    float* dcur = t->d_a.as<float>();
+    float* dtmp = t->d_b.as<float>();
+    float* dz = t->dz.as<float>();
+    float* gskip = t->gskip.as<float>();
+    const float* zero_bias = t->zero_bias.as<float>();
+    // ---- heads: dS = d(policy) + d(value) ----
+    if (t->conv_head) {
+        TrainConv& c = t->pol;
+        const float* dl = t->dlogits.as<float>();
+        TG_HIP(launch_wgrad_conv(st, s, F, F, dl, c.OP, c.O, B, N, part_w, G + c.w));
+        TG_HIP(launch_colsum_acc(st, dl, M, c.OP, c.O, part_d, G + c.b));
+        TG_HIP(launch_conv3x3(st, dl, c.wb.as<float>(), zero_bias, nullptr, dcur, M, N, c.OP, round_up(F, 64), F, F, false));
+    } else {
+        const float* dl = t->dlogits.as<float>();
+        TG_HIP(launch_wgrad_fc(st, s, nsq * F, dl, t->NP, e->policy_size, B, F, nsq, part_w, G + t->fc_w));
+        TG_HIP(launch_colsum_acc(st, dl, B, t->NP, e->policy_size, part_d, G + t->fc_b));
+        TG_HIP(launch_gemm(st, dl, t->NP, t->fc_wb.as<float>(), zero_bias, dcur, B, t->Pp, t->KP, nsq * F, nsq * F));
+    }
+    TG_HIP(launch_value_bwd(st, s, t->dpre.as<float>(), t->wv.as<float>(), B, F, nsq, dcur, part_d, G + t->val_w, G + t->val_b));
+    // ---- tower, last layer first ----
+    for (int l = (int)t->convs.size() - 1; l >= 0; l--) {
+        TrainConv& c = t->convs[l];
+        float* mean = stats + (size_t)c.bn * 2 * F;
+        float* invstd = mean + F;
+        const bool block_end = l >= 2 && (l % 2) == 0;  // conv2: its masked gradient also flows into the skip
+        TG_HIP(launch_bn_bwd(st, dcur, c.y.as<float>(), c.z.as<float>(), mean, invstd, P + c.gamma, M, F, part_d, t->mean_g.as<float>(),
+                             t->mean_gx.as<float>(), G + c.gamma, G + c.beta, dz, block_end ? gskip : nullptr));
+        const float* x = l == 0 ? t->planes.as<float>() : t->convs[l - 1].y.as<float>();
+        TG_HIP(launch_wgrad_conv(st, x, c.in_stride, c.I, dz, F, c.O, B, N, part_w, G + c.w));
+        TG_HIP(launch_colsum_acc(st, dz, M, F, F, part_d, G + c.b));
+        if (l == 0) break;
+        // conv1 (odd l) closes the block: its data gradient joins the gradient that went through the skip
+        const bool block_begin = (l % 2) == 1;
+        float* dst = block_end ? dtmp : dcur;
+        TG_HIP(launch_conv3x3(st, dz, c.wb.as<float>(), zero_bias, block_begin ? gskip : nullptr, dst, M, N, F, round_up(c.I, 64), F, F, false));
+        if (block_end) std::swap(dcur, dtmp);
+    }
+    return TG_OK;
+}
+
+int optimizer_step(TgEngine* e) {
+    Trainer* t = e->trainer;
+    hipStream_t st = e->stream;
+    float gscale = 1.0f;
+    if (t->comm) {
+        int rc = g_rccl.AllReduce(t->grads.p, t->grads.p, t->n_params, NCCL_FLOAT32, NCCL_SUM, t->comm, st);
+        if (rc) return fail(TG_ERR_HIP, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
+        gscale = 1.0f / (float)t->world;
+    }
+    t->adam_t++;
+    const double b1 = t->cfg.beta1, b2 = t->cfg.beta2;
+    float bc1 = (float)(1.0 - std::pow(b1, (double)t->adam_t));
+    float bc2s = (float)std::sqrt(1.0 - std::pow(b2, (double)t->adam_t));
+    TG_HIP(launch_adam(st, t->params.as<float>(), t->grads.as<float>(), t->adam_m.as<float>(), t->adam_v.as<float>(), t->n_params,
+                       t->cfg.learning_rate, t->cfg.beta1, t->cfg.beta2, t->cfg.eps, t->cfg.weight_decay, bc1, bc2s, gscale));
+    TG_HIP(hipMemsetAsync(t->grads.p, 0, t->n_params * 4, st));
+    t->packed = false;
+    return TG_OK;
+}
+
+int need_trainer(TgEngine* e) {
+    if (!e) return fail(TG_ERR_INVALID_ARG, "null engine");
+    if (!e->trainer) return fail(TG_ERR_STATE, "no trainer (tg_train_create)");
+    hipError_t err = hipSetDevice(e->cfg.device);
+    if (err != hipSuccess) return fail(TG_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(err));
+    return TG_OK;
+}
+
+// one chunk already resident on the device: ex_* buffers hold n examples, zt the 8n value targets
+int train_chunk_dev(TgEngine* e, int n, float* loss_p, float* loss_z, int32_t* stepped) {
+    Trainer* t = e->trainer;
+    hipStream_t st = e->stream;
+    const int B = n * 8;
+    TG_HIP(hipMemsetAsync(t->pi.p, 0, (size_t)B * e->policy_size * 4, st));
+    launch_augment(st, t->ex_states.as<uint8_t>(), t->ex_nmoves.as<int32_t>(), t->ex_moves.as<uint16_t>(), t->ex_visits.as<uint32_t>(), n,
+                   e->g.n, e->policy_size, e->legacy5, e->lut5.as<int16_t>(), t->states_aug.as<uint8_t>(), t->pi.as<float>());
+    TG_HIP(hipGetLastError());
+    launch_encode_nhwc(st, t->states_aug.as<uint8_t>(), B, e->g.n, t->planes.as<float>(), e->cin_pad);
+    TG_HIP(hipGetLastError());
+    int rc = forward_train(e, B, true, nullptr);
+    if (rc) return rc;
+    rc = backward_train(e, B);
+    if (rc) return rc;
+    TG_HIP(launch_sum_rows(st, t->loss_p_rows.as<float>(), B, t->loss_sums.as<double>()));
+    TG_HIP(launch_sum_rows(st, t->loss_z_rows.as<float>(), B, t->loss_sums.as<double>() + 1));
+    int did = 0;
+    t->chunk_num++;
+    if (t->chunk_num % t->cfg.chunks_in_step == 0) {  // network.rs:92
+        rc = optimizer_step(e);
+        if (rc) return rc;
+        did = 1;
+    }
+    double sums[2];
+    TG_HIP(hipMemcpyAsync(sums, t->loss_sums.p, 16, hipMemcpyDeviceToHost, st));
+    TG_HIP(hipStreamSynchronize(st));
+    if (loss_p) *loss_p = (float)(sums[0] / B);
+    if (loss_z) *loss_z = (float)(sums[1] / B);
+    if (stepped) *stepped = did;
+    return TG_OK;
+}
+
+int upload_chunk(TgEngine* e, int n, const uint8_t* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
+                 const float* results, const int* order) {
+    Trainer* t = e->trainer;
+    hipStream_t st = e->stream;
+    const size_t sb = e->g.bytes;
+    std::vector<float> z8((size_t)n * 8);
+    for (int i = 0; i < n; i++) {
+        const int s = order ? order[i] : i;
+        if (n_moves[s] < 0 || n_moves[s] > TG_MAX_MOVES) return fail(TG_ERR_INVALID_ARG, "training example: n_moves out of range");
+        for (int k = 0; k < 8; k++) z8[(size_t)i * 8 + k] = results[s];
+        if (order) {
+            TG_HIP(hipMemcpyAsync((uint8_t*)t->ex_states.p + (size_t)i * sb, states + (size_t)s * sb, sb, hipMemcpyHostToDevice, st));
+            TG_HIP(hipMemcpyAsync((int32_t*)t->ex_nmoves.p + i, n_moves + s, 4, hipMemcpyHostToDevice, st));
+            TG_HIP(hipMemcpyAsync((uint16_t*)t->ex_moves.p + (size_t)i * TG_MAX_MOVES, moves + (size_t)s * TG_MAX_MOVES, (size_t)n_moves[s] * 2,
+                                  hipMemcpyHostToDevice, st));
+            TG_HIP(hipMemcpyAsync((uint32_t*)t->ex_visits.p + (size_t)i * TG_MAX_MOVES, visits + (size_t)s * TG_MAX_MOVES,
+                                  (size_t)n_moves[s] * 4, hipMemcpyHostToDevice, st));
+        }
+    }
+    if (!order) {
+        TG_HIP(hipMemcpyAsync(t->ex_states.p, states, (size_t)n * sb, hipMemcpyHostToDevice, st));
+        TG_HIP(hipMemcpyAsync(t->ex_nmoves.p, n_moves, (size_t)n * 4, hipMemcpyHostToDevice, st));
+        TG_HIP(hipMemcpyAsync(t->ex_moves.p, moves, (size_t)n * TG_MAX_MOVES * 2, hipMemcpyHostToDevice, st));
+        TG_HIP(hipMemcpyAsync(t->ex_visits.p, visits, (size_t)n * TG_MAX_MOVES * 4, hipMemcpyHostToDevice, st));
+    }
+    TG_HIP(hipMemcpyAsync(t->zt.p, z8.data(), z8.size() * 4, hipMemcpyHostToDevice, st));
+    TG_HIP(hipStreamSynchronize(st));  // z8 (and the caller's buffers) may go away
+    return TG_OK;
+}
+
+}  // namespace
+}  // namespace tg
+
+using namespace tg;
+
+extern "C" {
+
+int tg_train_create(TgEngine* e, const TgTrainConfig* cfg) {
+    if (!e || !cfg) return fail(TG_ERR_INVALID_ARG, "tg_train_create: null argument");
+    const auto* tensors = net_tensors(e);
+    if (!tensors) return fail(TG_ERR_STATE, "engine has no network (evaluator is not TG_EVAL_RESNET)");
+    if (cfg->chunk_size <= 0 || cfg->chunks_in_step <= 0) return fail(TG_ERR_INVALID_ARG, "chunk_size and chunks_in_step must be positive");
+    const int F = e->cfg.filters, R = e->cfg.res_blocks, nsq = e->g.nsq, N = e->g.n, P = e->policy_size;
+    if (256 % (F / 4) != 0) return fail(TG_ERR_INVALID_ARG, "training needs filters in {32, 64, 128, 256}");
+    TG_HIP(hipSetDevice(e->cfg.device));
+    std::unique_ptr<Trainer> t(new Trainer());
+    t->cfg = *cfg;
+    t->Bmax = cfg->chunk_size * 8;
+    t->conv_head = e->cfg.policy_head == TG_HEAD_CONV;
+    // ---- parameter registry, creation order of net5.rs:29-62 / net6.rs:29-57 ----
+    t->convs.resize(1 + 2 * R);
+    int bn = 0;
+    add_conv(t.get(), t->convs[0], "conv0", "bn0", F, e->cin);
+    add_bn(t.get(), t->convs[0], "bn0", F, bn++);
+    for (int i = 0; i < R; i++) {
+        std::string p = "res" + std::to_string(i);
+        add_conv(t.get(), t->convs[1 + 2 * i], p + ".conv1", "", F, F);
+        add_conv(t.get(), t->convs[2 + 2 * i], p + ".conv2", "", F, F);
+        add_bn(t.get(), t->convs[1 + 2 * i], p + ".bn1", F, bn++);
+        add_bn(t.get(), t->convs[2 + 2 * i], p + ".bn2", F, bn++);
+    }
+    if (t->conv_head) add_conv(t.get(), t->pol, "policy", "", P / nsq, F);
+    else {
+        t->fc_w = add_info(t.get(), "policy.weight", (size_t)P * F * nsq, false);
+        t->fc_b = add_info(t.get(), "policy.bias", P, false);
+    }
+    t->val_w = add_info(t.get(), "value.weight", (size_t)F * nsq, false);
+    t->val_b = add_info(t.get(), "value.bias", 1, false);
+    // ---- upload the tensors ----
+    std::vector<float> hp(t->n_params, 0.0f), hb(t->n_buffers, 0.0f);
+    for (const ParamInfo& pi : t->infos) {
+        auto it = tensors->find(pi.name);
+        if (it == tensors->end()) return fail(TG_ERR_WEIGHTS, "missing tensor " + pi.name);
+        if (it->second.size() != pi.count)
+            return fail(TG_ERR_WEIGHTS, "tensor " + pi.name + " has " + std::to_string(it->second.size()) + " elements, expected " + std::to_string(pi.count));
+        std::memcpy((pi.buffer ? hb.data() : hp.data()) + pi.off, it->second.data(), pi.count * 4);
+    }
+    TG_HIP(t->params.ensure(t->n_params * 4));
+    TG_HIP(t->grads.ensure(t->n_params * 4));
+    TG_HIP(t->adam_m.ensure(t->n_params * 4));
+    TG_HIP(t->adam_v.ensure(t->n_params * 4));
+    TG_HIP(t->bnbuf.ensure(t->n_buffers * 4));
+    TG_HIP(hipMemcpy(t->params.p, hp.data(), t->n_params * 4, hipMemcpyHostToDevice));
+    TG_HIP(hipMemcpy(t->bnbuf.p, hb.data(), t->n_buffers * 4, hipMemcpyHostToDevice));
+    TG_HIP(hipMemset(t->grads.p, 0, t->n_params * 4));
+    TG_HIP(hipMemset(t->adam_m.p, 0, t->n_params * 4));
+    TG_HIP(hipMemset(t->adam_v.p, 0, t->n_params * 4));
+    // ---- per-layer buffers ----
+    const size_t B = (size_t)t->Bmax, M = B * nsq;
+    size_t part_w_floats = 0;
+    int max_op = round_up(F, 64);
+    for (size_t l = 0; l < t->convs.size(); l++) {
+        TrainConv& c = t->convs[l];
+        c.in_stride = l == 0 ? e->cin_pad : F;
+        c.OP = round_up(F, 64);
+        c.out_stride = F;
+        TG_HIP(c.wf.ensure((size_t)9 * c.in_stride * c.OP * 4));
+        TG_HIP(c.bias_pad.ensure((size_t)c.OP * 4));
+        if (l > 0) TG_HIP(c.wb.ensure((size_t)9 * c.out_stride * round_up(c.I, 64) * 4));
+        TG_HIP(c.z.ensure(M * F * 4));
+        TG_HIP(c.y.ensure(M * F * 4));
+        part_w_floats = std::max(part_w_floats, wgrad_conv_workspace((int)B, N, c.I, c.O));
+    }
+    size_t logit_row;
+    if (t->conv_head) {
+        TrainConv& c = t->pol;
+        c.in_stride = F;
+        c.OP = round_up(c.O, 64);
+        c.out_stride = c.OP;
+        max_op = std::max(max_op, c.OP);
+        TG_HIP(c.wf.ensure((size_t)9 * F * c.OP * 4));
+        TG_HIP(c.bias_pad.ensure((size_t)c.OP * 4));
+        TG_HIP(c.wb.ensure((size_t)9 * c.OP * round_up(F, 64) * 4));
+        part_w_floats = std::max(part_w_floats, wgrad_conv_workspace((int)B, N, F, c.O));
+        logit_row = (size_t)nsq * c.OP;
+    } else {
+        const int K = F * nsq;
+        t->NP = (K % 64 == 0) ? round_up(P, 208) : round_up(P, 64);
+        t->Pp = round_up(P, 32);
+        t->KP = round_up(K, 64);
+        if (t->Pp > t->NP) return fail(TG_ERR_INVALID_ARG, "internal: FC padding");
+        max_op = std::max(max_op, std::max(t->NP, t->KP));
+        TG_HIP(t->fc_wf.ensure((size_t)K * t->NP * 4));
+        TG_HIP(t->fc_wb.ensure((size_t)t->Pp * t->KP * 4));
+        TG_HIP(t->fc_bias.ensure((size_t)t->NP * 4));
+        part_w_floats = std::max(part_w_floats, wgrad_fc_workspace((int)B, K, P));
+        logit_row = (size_t)t->NP;
+    }
+    TG_HIP(t->wv.ensure((size_t)F * nsq * 4));
+    TG_HIP(t->zero_bias.ensure((size_t)max_op * 4));
+    TG_HIP(hipMemset(t->zero_bias.p, 0, (size_t)max_op * 4));
+    TG_HIP(t->ex_states.ensure((size_t)cfg->chunk_size * e->g.bytes));
+    TG_HIP(t->ex_nmoves.ensure((size_t)cfg->chunk_size * 4));
+    TG_HIP(t->ex_moves.ensure((size_t)cfg->chunk_size * TG_MAX_MOVES * 2));
+    TG_HIP(t->ex_visits.ensure((size_t)cfg->chunk_size * TG_MAX_MOVES * 4));
+    TG_HIP(hipMemset(t->ex_moves.p, 0, (size_t)cfg->chunk_size * TG_MAX_MOVES * 2));
+    TG_HIP(hipMemset(t->ex_visits.p, 0, (size_t)cfg->chunk_size * TG_MAX_MOVES * 4));
+    TG_HIP(t->states_aug.ensure(B * e->g.bytes));
+    TG_HIP(t->pi.ensure(B * P * 4));
+    TG_HIP(t->zt.ensure(B * 4));
+    TG_HIP(t->planes.ensure(M * e->cin_pad * 4));
+    TG_HIP(t->logits.ensure(B * logit_row * 4));
+    TG_HIP(t->dlogits.ensure(B * logit_row * 4));
+    TG_HIP(hipMemset(t->dlogits.p, 0, B * logit_row * 4));  // padding columns stay zero
+    TG_HIP(t->logp.ensure(B * P * 4));
+    TG_HIP(t->eval.ensure(B * 4));
+    TG_HIP(t->dpre.ensure(B * 4));
+    TG_HIP(t->loss_p_rows.ensure(B * 4));
+    TG_HIP(t->loss_z_rows.ensure(B * 4));
+    TG_HIP(t->loss_sums.ensure(16));
+    TG_HIP(t->d_a.ensure(M * F * 4));
+    TG_HIP(t->d_b.ensure(M * F * 4));
+    TG_HIP(t->dz.ensure(M * F * 4));
+    TG_HIP(t->gskip.ensure(M * F * 4));
+    TG_HIP(t->stats.ensure((size_t)bn * 2 * F * 4));
+    TG_HIP(t->mean_g.ensure((size_t)F * 4));
+    TG_HIP(t->mean_gx.ensure((size_t)F * 4));
+    // double partials: column reductions over up to max(F, logit columns) channels, value weight gradient
+    {
+        int rpb;
+        size_t a = (size_t)col_reduce_blocks((int)M, F, &rpb) * 2 * F;
+        if (t->conv_head) a = std::max(a, (size_t)col_reduce_blocks((int)M, t->pol.OP, &rpb) * 2 * t->pol.OP);
+        else a = std::max(a, (size_t)32 * 2 * t->NP);
+        size_t b = (size_t)32 * ((size_t)F * nsq + 1);
+        TG_HIP(t->part_d.ensure(std::max(a, b) * 8));
+    }
+    TG_HIP(t->part_w.ensure(part_w_floats * 4));
+    delete e->trainer;
+    e->trainer = t.release();
+    return TG_OK;
+}
+
+int tg_train_chunk(TgEngine* e, int n, const void* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
+                   const float* results, float* loss_p, float* loss_z, int32_t* stepped) {
+    int rc = need_trainer(e);
+    if (rc) return rc;
+    if (n <= 0 || n > e->trainer->cfg.chunk_size || !states || !n_moves || !moves || !visits || !results)
+        return fail(TG_ERR_INVALID_ARG, "tg_train_chunk: bad arguments (1 ≤ n ≤ chunk_size)");
+    rc = upload_chunk(e, n, (const uint8_t*)states, n_moves, moves, visits, results, nullptr);
+    if (rc) return rc;
+    return train_chunk_dev(e, n, loss_p, loss_z, stepped);
+}
+
+int tg_train(TgEngine* e, int n, const void* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
+             const float* results, uint64_t seed, float* mean_loss_p, float* mean_loss_z, int32_t* steps) {
+    int rc = need_trainer(e);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!states || !n_moves || !moves || !visits || !results))) return fail(TG_ERR_INVALID_ARG, "tg_train: bad arguments");
+    Trainer* t = e->trainer;
+    // a fresh optimiser per call (network.rs:40-45); gradients left over from an incomplete step of the previous
+    // call stay in place, exactly as the .grad tensors of the reference's VarStore do
+    TG_HIP(hipMemsetAsync(t->adam_m.p, 0, t->n_params * 4, e->stream));
+    TG_HIP(hipMemsetAsync(t->adam_v.p, 0, t->n_params * 4, e->stream));
+    t->adam_t = 0;
+    t->chunk_num = 0;
+    // refs.shuffle (network.rs:49-50): Fisher–Yates driven by Philox(seed; i)
+    std::vector<int> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    for (int i = n - 1; i > 0; i--) {
+        U4 r = philox4x32_10(seed, (uint32_t)i, 0x7261696eu, 0, 0);
+        uint64_t x = ((uint64_t)r.v[0] << 32) | r.v[1];
+        int j = (int)(((unsigned __int128)x * (unsigned __int128)(i + 1)) >> 64);
+        std::swap(order[i], order[j]);
+    }
+    const int cs = t->cfg.chunk_size;
+    double sp = 0.0, sz = 0.0;
+    int chunks = 0, nsteps = 0;
+    for (int off = 0; off + cs <= n; off += cs) {  // chunks_exact: the remainder is dropped
+        rc = upload_chunk(e, cs, (const uint8_t*)states, n_moves, moves, visits, results, order.data() + off);
+        if (rc) return rc;
+        float lp, lz;
+        int32_t did;
+        rc = train_chunk_dev(e, cs, &lp, &lz, &did);
+        if (rc) return rc;
+        sp += lp; sz += lz; chunks++; nsteps += did;
+    }
+    if (mean_loss_p) *mean_loss_p = chunks ? (float)(sp / chunks) : 0.0f;
+    if (mean_loss_z) *mean_loss_z = chunks ? (float)(sz / chunks) : 0.0f;
+    if (steps) *steps = nsteps;
+    return TG_OK;
+}
+
+int tg_train_step(TgEngine* e) {
+    int rc = need_trainer(e);
+    if (rc) return rc;
+    rc = optimizer_step(e);
+    if (rc) return rc;
+    TG_HIP(hipStreamSynchronize(e->stream));
+    return TG_OK;
+}
+
+int tg_train_forward(TgEngine* e, int n, const void* states, float* logp, float* eval) {
+    int rc = need_trainer(e);
+    if (rc) return rc;
+    Trainer* t = e->trainer;
+    if (n <= 0 || n > t->Bmax || !states || !logp || !eval) return fail(TG_ERR_INVALID_ARG, "tg_train_forward: bad arguments (1 ≤ n ≤ 8·chunk_size)");
+    hipStream_t st = e->stream;
+    TG_HIP(hipMemcpyAsync(t->states_aug.p, states, (size_t)n * e->g.bytes, hipMemcpyHostToDevice, st));
+    launch_encode_nhwc(st, t->states_aug.as<uint8_t>(), n, e->g.n, t->planes.as<float>(), e->cin_pad);
+    TG_HIP(hipGetLastError());
+    rc = forward_train(e, n, false, t->logp.as<float>());
+    if (rc) return rc;
+    TG_HIP(hipMemcpyAsync(logp, t->logp.p, (size_t)n * e->policy_size * 4, hipMemcpyDeviceToHost, st));
+    TG_HIP(hipMemcpyAsync(eval, t->eval.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    TG_HIP(hipStreamSynchronize(st));
+    return TG_OK;
+}
+
+static int get_common(TgEngine* e, const char* name, float* out, size_t count, bool grad) {
+    int rc = need_trainer(e);
+    if (rc) return rc;
+    Trainer* t = e->trainer;
+    if (!name || !out) return fail(TG_ERR_INVALID_ARG, "null argument");
+    auto it = t->index.find(name);
+    if (it == t->index.end()) return fail(TG_ERR_INVALID_ARG, std::string("unknown tensor ") + name);
+    const ParamInfo& pi = t->infos[it->second];
+    if (pi.count != count) return fail(TG_ERR_INVALID_ARG, std::string("tensor ") + name + " has " + std::to_string(pi.count) + " elements");
+    if (grad && pi.buffer) return fail(TG_ERR_INVALID_ARG, std::string(name) + " is a buffer and has no gradient");
+    const float* src = (pi.buffer ? t->bnbuf.as<float>() : grad ? t->grads.as<float>() : t->params.as<float>()) + pi.off;
+    TG_HIP(hipStreamSynchronize(e->stream));
+    TG_HIP(hipMemcpy(out, src, count * 4, hipMemcpyDeviceToHost));
+    return TG_OK;
+}
+int tg_train_get_tensor(TgEngine* e, const char* name, float* out, size_t count) { return get_common(e, name, out, count, false); }
+int tg_train_get_grad(TgEngine* e, const char* name, float* out, size_t count) { return get_common(e, name, out, count, true); }
+
+int tg_train_commit(TgEngine* e) {
+    int rc = need_trainer(e);
+    if (rc) return rc;
+    Trainer* t = e->trainer;
+    if (t->comm && t->n_buffers) {  // data parallel: every rank normalised with its own batches → average the running statistics
+        int r = g_rccl.AllReduce(t->bnbuf.p, t->bnbuf.p, t->n_buffers, NCCL_FLOAT32, NCCL_SUM, t->comm, e->stream);
+        if (r) return fail(TG_ERR_HIP, "ncclAllReduce (BN running statistics) failed");
+    }
+    TG_HIP(hipStreamSynchronize(e->stream));
+    std::vector<float> hp(t->n_params), hb(t->n_buffers);
+    TG_HIP(hipMemcpy(hp.data(), t->params.p, t->n_params * 4, hipMemcpyDeviceToHost));
+    TG_HIP(hipMemcpy(hb.data(), t->bnbuf.p, t->n_buffers * 4, hipMemcpyDeviceToHost));
+    if (t->comm) {
+        for (float& v : hb) v /= (float)t->world;
+        TG_HIP(hipMemcpy(t->bnbuf.p, hb.data(), t->n_buffers * 4, hipMemcpyHostToDevice));
+    }
+    for (const ParamInfo& pi : t->infos) {
+        rc = net_set_tensor(e, pi.name.c_str(), (pi.buffer ? hb.data() : hp.data()) + pi.off, pi.count);
+        if (rc) return rc;
+    }
+    return net_finalize(e);
+}
+
+int tg_comm_unique_id(void* id128) {
+    if (!id128) return fail(TG_ERR_INVALID_ARG, "null id");
+    int rc = rccl_load();
+    if (rc) return rc;
+    int r = g_rccl.GetUniqueId(id128);
+    if (r) return fail(TG_ERR_HIP, "ncclGetUniqueId failed");
+    return TG_OK;
+}
+
+int tg_train_comm_init(TgEngine* e, int rank, int world_size, const void* id128) {
+    int rc = need_trainer(e);
+    if (rc) return rc;
+    if (!id128 || world_size < 1 || rank < 0 || rank >= world_size) return fail(TG_ERR_INVALID_ARG, "tg_train_comm_init: bad arguments");
+    rc = rccl_load();
+    if (rc) return rc;
+    Trainer* t = e->trainer;
+    if (t->comm) { g_rccl.CommDestroy(t->comm); t->comm = nullptr; }
+    Id128 id;
+    std::memcpy(id.bytes, id128, 128);
+    int r = g_rccl.CommInitRank(&t->comm, world_size, id, rank);
+    if (r) { t->comm = nullptr; return fail(TG_ERR_HIP, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?")); }
+    t->world = world_size;
+    t->rank = rank;
+    return TG_OK;
+}
+
+}  // extern "C"

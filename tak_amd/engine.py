@@ -57,6 +57,12 @@ class TgSelfPlayStats(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class TgTrainConfig(C.Structure):
+    _fields_ = [("learning_rate", C.c_float), ("weight_decay", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("eps", C.c_float), ("bn_momentum", C.c_float), ("bn_eps", C.c_float), ("chunk_size", C.c_int32),
+                ("chunks_in_step", C.c_int32), ("reserved", C.c_int32)]
+
+
 # every symbol include/takgpu.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "tg_state_bytes", "tg_engine_create", "tg_engine_destroy", "tg_last_error", "tg_sync", "tg_stream",
@@ -67,6 +73,8 @@ ABI_SYMBOLS = [
     "tg_selfplay_create", "tg_selfplay_step", "tg_selfplay_stats", "tg_selfplay_drain",
     "tg_profile_enable", "tg_profile_read", "tg_board_pass_bench",
     "tg_augment_examples",
+    "tg_train_create", "tg_train_chunk", "tg_train", "tg_train_step", "tg_train_forward", "tg_train_get_tensor",
+    "tg_train_get_grad", "tg_train_commit", "tg_comm_unique_id", "tg_train_comm_init",
     "tg_format_move", "tg_parse_move", "tg_format_tps", "tg_parse_tps", "tg_format_example", "tg_parse_example",
 ]
 
@@ -166,6 +174,15 @@ def parse_example(n, line):
     return st, mv[: k.value].copy(), vs[: k.value].copy(), res.value
 
 
+def comm_unique_id():
+    """ncclGetUniqueId on this rank (128 bytes); broadcast it to the other ranks with any host transport."""
+    uid = np.zeros(128, np.uint8)
+    rc = load_library().tg_comm_unique_id(_p(uid))
+    if rc:
+        raise TgError(rc, load_library().tg_last_error().decode())
+    return uid.tobytes()
+
+
 def _mask(active):
     return np.ascontiguousarray(active, np.uint8) if active is not None else None
 
@@ -261,6 +278,66 @@ class Engine:
         pi = np.zeros((k * 8, self.psize), np.float32)
         self._check(self.lib.tg_augment_examples(self.h, k, _p(states), _p(n_moves), _p(moves), _p(visits), _p(out), _p(pi)))
         return out, pi
+
+    # ---- training step (Network::train / train_inner, alpha-tak/src/model/network.rs:37-97) ----
+    def train_create(self, learning_rate=1e-4, weight_decay=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, bn_momentum=0.1,
+                     bn_eps=1e-5, chunk_size=500, chunks_in_step=20):
+        cfg = TgTrainConfig(learning_rate, weight_decay, beta1, beta2, eps, bn_momentum, bn_eps, chunk_size, chunks_in_step, 0)
+        self._check(self.lib.tg_train_create(self.h, C.byref(cfg)))
+        self.chunk_size = chunk_size
+
+    def _examples(self, states, n_moves, moves, visits, results):
+        states, k = self._states(states)
+        n_moves = np.ascontiguousarray(n_moves, np.int32)
+        moves = np.ascontiguousarray(moves, np.uint16).reshape(k, TG_MAX_MOVES)
+        visits = np.ascontiguousarray(visits, np.uint32).reshape(k, TG_MAX_MOVES)
+        results = np.ascontiguousarray(results, np.float32).reshape(k)
+        return states, k, n_moves, moves, visits, results
+
+    def train_chunk(self, states, n_moves, moves, visits, results):
+        """train_inner on one chunk → (loss_p, loss_z, stepped)"""
+        states, k, n_moves, moves, visits, results = self._examples(states, n_moves, moves, visits, results)
+        lp, lz, did = C.c_float(0), C.c_float(0), C.c_int32(0)
+        self._check(self.lib.tg_train_chunk(self.h, k, _p(states), _p(n_moves), _p(moves), _p(visits), _p(results),
+                                            C.byref(lp), C.byref(lz), C.byref(did)))
+        return lp.value, lz.value, bool(did.value)
+
+    def train(self, states, n_moves, moves, visits, results, seed=0):
+        """Network::train over a set of examples → (mean loss_p, mean loss_z, optimiser steps)"""
+        states, k, n_moves, moves, visits, results = self._examples(states, n_moves, moves, visits, results)
+        lp, lz, steps = C.c_float(0), C.c_float(0), C.c_int32(0)
+        self._check(self.lib.tg_train(self.h, k, _p(states), _p(n_moves), _p(moves), _p(visits), _p(results), C.c_uint64(seed),
+                                      C.byref(lp), C.byref(lz), C.byref(steps)))
+        return lp.value, lz.value, steps.value
+
+    def train_step(self):
+        self._check(self.lib.tg_train_step(self.h))
+
+    def train_forward(self, states):
+        """forward_training: (log_softmax policy, eval) with BatchNorm on the batch statistics"""
+        states, k = self._states(states)
+        logp = np.zeros((k, self.psize), np.float32)
+        ev = np.zeros(k, np.float32)
+        self._check(self.lib.tg_train_forward(self.h, k, _p(states), _p(logp), _p(ev)))
+        return logp, ev
+
+    def train_get_tensor(self, name, shape):
+        out = np.zeros(shape, np.float32)
+        self._check(self.lib.tg_train_get_tensor(self.h, name.encode(), _p(out), C.c_size_t(out.size)))
+        return out
+
+    def train_get_grad(self, name, shape):
+        out = np.zeros(shape, np.float32)
+        self._check(self.lib.tg_train_get_grad(self.h, name.encode(), _p(out), C.c_size_t(out.size)))
+        return out
+
+    def train_commit(self):
+        self._check(self.lib.tg_train_commit(self.h))
+
+    def train_comm_init(self, rank, world, unique_id):
+        uid = np.frombuffer(bytes(unique_id), np.uint8).copy()
+        assert uid.size == 128
+        self._check(self.lib.tg_train_comm_init(self.h, rank, world, _p(uid)))
 
     def perft(self, states, depth):
         states, k = self._states(states)

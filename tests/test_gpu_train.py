@@ -1,0 +1,257 @@
+"""GPU parity of the training step (tg_train_*: Network::train / train_inner, alpha-tak/src/model/network.rs:37-97)
+against PyTorch-CPU fp32 autograd of the same network (the ATen ops tch-rs calls; libtorch is not vendored, so
+this is the arithmetic oracle — "parity unpinned" by the reference's own tests, which have none for training).
+
+Tolerances (fp32, reductions over up to 10^5 terms in a different order than ATen's):
+  forward_training outputs  |Δ| ≤ 1e-4 (the north_star tolerance of the forward)
+  losses                    relative 1e-5
+  gradients                 ‖g − g_ref‖₂ ≤ 2e-4·‖g_ref‖₂ per tensor; tensors whose true gradient is zero
+                            (a conv bias in front of a BatchNorm) are compared absolutely against the
+                            network's gradient scale
+  Adam                      given identical gradients, parameters within 2e-7 after a step
+"""
+import numpy as np
+import pytest
+
+import torch_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(n, blocks, filters, head, max_batch=64):
+    import tak_amd
+
+    return tak_amd.Engine(n, res_blocks=blocks, filters=filters, policy_head=tak_amd.HEAD_FC5 if head == "fc5" else tak_amd.HEAD_CONV,
+                          evaluator=tak_amd.EVAL_RESNET, max_batch=max_batch)
+
+
+def _examples(orc, n, count, seed):
+    sts = orc.random_positions(n, count * 3, seed=seed, max_plies=60 if n >= 5 else 14, half_komi=4)
+    sts = sts[orc.result(n, sts) == 0][:count]
+    assert len(sts) == count
+    mv, cnt = orc.movegen(n, sts)
+    rng = np.random.default_rng(seed)
+    visits = np.zeros((count, 512), np.uint32)
+    for i in range(count):
+        visits[i, : cnt[i]] = rng.integers(0, 50, cnt[i])
+        visits[i, rng.integers(cnt[i])] += 1
+    results = rng.choice(np.array([-1.0, 0.0, 1.0], np.float32), count)
+    return sts, cnt.astype(np.int32), mv, visits, results
+
+
+def _targets(orc, n, head, ex):
+    """the 8-fold augmented batch exactly as Example::to_tensors builds it (via the CPU oracle)"""
+    sts, cnt, mv, visits, results = ex
+    a_states, pi = orc.augment(n, orc.HEAD_FC5 if head == "fc5" else orc.HEAD_CONV, sts, cnt, mv, visits)
+    return orc.encode(n, a_states), pi, np.repeat(results, 8), a_states
+
+
+def _shapes(net):
+    return {torch_ref.abi_name(k): tuple(v.shape) for k, v in net.named_parameters()}
+
+
+CASES = [
+    (5, 2, 32, "fc5", 24),
+    (3, 1, 64, "conv", 16),   # (5×5 always uses the legacy FC index in the reference: move_map.rs:21-24)
+    (6, 2, 64, "conv", 12),
+    (4, 1, 32, "conv", 20),
+    (5, 2, 128, "fc5", 10),
+]
+
+
+@pytest.mark.parametrize("n,blocks,filters,head,count", CASES)
+def test_forward_training_vs_torch(orc, n, blocks, filters, head, count):
+    net = torch_ref.make_net(n, blocks, filters, head, seed=n + blocks)
+    e = _engine(n, blocks, filters, head)
+    e.load_state_dict(torch_ref.abi_tensors(net))
+    e.train_create(chunk_size=count)
+    ex = _examples(orc, n, count, seed=3)
+    planes, pi, z, a_states = _targets(orc, n, head, ex)
+    import torch
+
+    net.train()
+    with torch.no_grad():
+        logp_ref, v_ref = net.forward_training(torch.from_numpy(planes))
+    logp, v = e.train_forward(a_states)
+    assert np.abs(logp - logp_ref.numpy()).max() <= 1e-4
+    assert np.abs(v - v_ref.numpy()[:, 0]).max() <= 1e-4
+    # running statistics were updated with momentum 0.1 and the unbiased batch variance, as libtorch does
+    sd = torch_ref.abi_tensors(net)
+    for name in ("bn0.running_mean", "bn0.running_var", f"res{blocks - 1}.bn2.running_mean", f"res{blocks - 1}.bn2.running_var"):
+        got = e.train_get_tensor(name, sd[name].shape)
+        assert np.abs(got - sd[name]).max() <= 1e-5 * max(1.0, np.abs(sd[name]).max()), name
+    e.close()
+
+
+@pytest.mark.parametrize("n,blocks,filters,head,count", CASES)
+def test_chunk_gradients_vs_autograd(orc, n, blocks, filters, head, count):
+    net = torch_ref.make_net(n, blocks, filters, head, seed=10 + n)
+    e = _engine(n, blocks, filters, head)
+    e.load_state_dict(torch_ref.abi_tensors(net))
+    e.train_create(chunk_size=count, chunks_in_step=1000)
+    shapes = _shapes(net)
+    total_sq = 0.0
+    for rep in range(2):  # gradients accumulate over chunks (network.rs:89-96)
+        ex = _examples(orc, n, count, seed=20 + rep)
+        planes, pi, z, _ = _targets(orc, n, head, ex)
+        lp_ref, lz_ref = torch_ref.train_chunk(net, planes, pi, z)
+        lp, lz, stepped = e.train_chunk(*ex)
+        assert not stepped
+        assert abs(lp - lp_ref) <= 1e-5 * abs(lp_ref) and abs(lz - lz_ref) <= 1e-5 * max(abs(lz_ref), 1e-3), (lp, lp_ref, lz, lz_ref)
+    ref = torch_ref.named_grads(net)
+    scale = np.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in ref.values()) / sum(g.size for g in ref.values()))
+    for name, g_ref in ref.items():
+        g = e.train_get_grad(name, shapes[name])
+        err = np.linalg.norm((g - g_ref).astype(np.float64))
+        nrm = np.linalg.norm(g_ref.astype(np.float64))
+        bias_before_bn = name.endswith(".bias") and "conv" in name and not name.startswith("policy")
+        if bias_before_bn:  # true gradient is exactly zero; both sides hold rounding noise
+            assert np.abs(g).max() <= 1e-3 * scale * np.sqrt(count * 8 * n * n), name
+        else:
+            assert err <= 2e-4 * nrm + 1e-12, (name, err, nrm)
+        total_sq += err * err
+    # size-independent property: every row of dLogits sums to zero → so does the policy bias gradient
+    if head == "fc5":
+        gb = e.train_get_grad("policy.bias", shapes["policy.bias"])
+        assert abs(float(gb.astype(np.float64).sum())) <= 1e-5
+    e.close()
+
+
+def test_steps_track_torch_adam(orc):
+    """Three optimiser steps of two chunks each: accumulate, Adam (L2 weight decay), zero_grad, re-pack, next forward."""
+    import torch
+
+    n, blocks, filters, head, count = 5, 2, 32, "fc5", 16
+    net = torch_ref.make_net(n, blocks, filters, head, seed=4)
+    e = _engine(n, blocks, filters, head)
+    e.load_state_dict(torch_ref.abi_tensors(net))
+    lr, wd = 1e-3, 1e-2
+    e.train_create(learning_rate=lr, weight_decay=wd, chunk_size=count, chunks_in_step=2)
+    opt = torch_ref.make_adam(net, lr=lr, wd=wd)
+    shapes = _shapes(net)
+    params = {torch_ref.abi_name(k): v for k, v in net.named_parameters()}
+    for step in range(3):
+        opt.zero_grad()
+        for c in range(2):
+            ex = _examples(orc, n, count, seed=100 + 2 * step + c)
+            planes, pi, z, _ = _targets(orc, n, head, ex)
+            lp_ref, lz_ref = torch_ref.train_chunk(net, planes, pi, z)
+            lp, lz, stepped = e.train_chunk(*ex)
+            assert stepped == (c == 1)
+            assert abs(lp - lp_ref) <= 2e-5 * abs(lp_ref), (step, c, lp, lp_ref)
+        opt.step()
+        for k, p in params.items():
+            d = np.abs(e.train_get_tensor(k, shapes[k]) - p.detach().numpy())
+            # Adam moves every element by at most lr per step; a relative gradient error δ changes the update by ≈ lr·δ
+            # except where |g| is of the order of eps = 1e-8 (conv biases in front of a BatchNorm have zero gradient:
+            # there Adam normalises rounding noise)
+            assert d.max() <= 1.001 * lr, k
+            if not (k.endswith(".bias") and "conv" in k):
+                assert np.quantile(d, 0.999) <= 0.02 * lr, (k, float(np.quantile(d, 0.999)))
+        with torch.no_grad():  # keep the noise-dominated elements from drifting apart
+            for k, p in params.items():
+                p.copy_(torch.from_numpy(e.train_get_tensor(k, shapes[k])))
+    e.close()
+
+
+def test_adam_kernel_exact(orc):
+    """Adam arithmetic alone: same gradients in, same parameters out (one step, from zero moments)."""
+    import torch
+
+    n, blocks, filters, head, count = 5, 1, 32, "fc5", 8
+    net = torch_ref.make_net(n, blocks, filters, head, seed=5)
+    e = _engine(n, blocks, filters, head)
+    e.load_state_dict(torch_ref.abi_tensors(net))
+    lr, wd = 1e-3, 1e-2
+    e.train_create(learning_rate=lr, weight_decay=wd, chunk_size=count, chunks_in_step=1000)
+    shapes = _shapes(net)
+    e.train_chunk(*_examples(orc, n, count, seed=1))
+    opt = torch_ref.make_adam(net, lr=lr, wd=wd)
+    for k, p in net.named_parameters():
+        p.grad = torch.from_numpy(e.train_get_grad(torch_ref.abi_name(k), shapes[torch_ref.abi_name(k)]))
+    opt.step()
+    e.train_step()
+    for k, p in net.named_parameters():
+        got = e.train_get_tensor(torch_ref.abi_name(k), shapes[torch_ref.abi_name(k)])
+        g = p.grad.numpy()
+        # the step is lr·m̂/(√v̂ + eps): float rounding only, except for the few elements where g + wd·p cancels down to
+        # the order of eps = 1e-8 (there the rounding of the sum itself is amplified by up to lr/eps)
+        d = np.abs(got - p.detach().numpy())
+        assert np.quantile(d, 0.999) <= 2e-7 and d.max() <= 1e-2 * lr, (k, float(d.max()))
+        assert np.abs(e.train_get_grad(torch_ref.abi_name(k), shapes[torch_ref.abi_name(k)])).max() == 0.0  # zero_grad
+    e.close()
+
+
+def test_train_driver_and_commit(orc):
+    """Network::train: shuffle, chunks_exact, a step every chunks_in_step chunks; then the trained weights serve
+    tg_policy_eval (BatchNorm folded with the updated running statistics)."""
+    import torch
+
+    n, blocks, filters, head = 5, 2, 32, "fc5"
+    net = torch_ref.make_net(n, blocks, filters, head, seed=6)
+    e = _engine(n, blocks, filters, head)
+    e.load_state_dict(torch_ref.abi_tensors(net))
+    e.train_create(learning_rate=1e-3, chunk_size=8, chunks_in_step=2)
+    ex = _examples(orc, n, 43, seed=9)   # 5 whole chunks, remainder 3 dropped → 2 steps
+    shapes = _shapes(net)
+    before = e.train_get_tensor("policy.weight", shapes["policy.weight"])
+    lp, lz, steps = e.train(*ex, seed=1)
+    assert steps == 2 and np.isfinite(lp) and np.isfinite(lz) and 5.0 < lp < 9.0
+    after = e.train_get_tensor("policy.weight", shapes["policy.weight"])
+    assert 0 < np.abs(after - before).max() <= 2.2e-3  # ≈ lr per step
+    # same seed → same shuffle → bit-identical result on a fresh trainer (deterministic reductions)
+    e2 = _engine(n, blocks, filters, head)
+    e2.load_state_dict(torch_ref.abi_tensors(net))
+    e2.train_create(learning_rate=1e-3, chunk_size=8, chunks_in_step=2)
+    lp2, lz2, _ = e2.train(*ex, seed=1)
+    assert (lp, lz) == (lp2, lz2)
+    assert np.array_equal(after, e2.train_get_tensor("policy.weight", shapes["policy.weight"]))
+    lp3, _, _ = e2.train(*ex, seed=2)
+    assert lp3 != lp2
+    e2.close()
+    # commit → inference path uses the trained parameters and the updated running statistics
+    e.train_commit()
+    sd = net.state_dict()
+    with torch.no_grad():
+        for k in sd:
+            if k.endswith("num_batches_tracked"):
+                continue
+            sd[k].copy_(torch.from_numpy(e.train_get_tensor(torch_ref.abi_name(k), tuple(sd[k].shape))))
+    net.eval()
+    sts = ex[0][:16]
+    p_ref, v_ref = torch_ref.forward(net, orc.encode(n, sts))
+    p, v = e.policy_eval(sts)
+    assert np.abs(p - p_ref).max() <= 1e-4 and np.abs(v - v_ref).max() <= 1e-4
+    e.close()
+
+
+def test_single_rank_communicator(orc):
+    """RCCL wiring with world_size 1: unique id, communicator, all-reduce of the flat gradient buffer = identity."""
+    import tak_amd
+
+    n, blocks, filters, head, count = 5, 1, 32, "fc5", 8
+    net = torch_ref.make_net(n, blocks, filters, head, seed=7)
+    outs = []
+    for use_comm in (False, True):
+        e = _engine(n, blocks, filters, head)
+        e.load_state_dict(torch_ref.abi_tensors(net))
+        e.train_create(learning_rate=1e-3, chunk_size=count, chunks_in_step=1)
+        if use_comm:
+            e.train_comm_init(0, 1, tak_amd.comm_unique_id())
+        e.train_chunk(*_examples(orc, n, count, seed=2))
+        outs.append(e.train_get_tensor("conv0.weight", (filters, 72, 3, 3)))
+        e.close()
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_errors():
+    import tak_amd
+
+    e = _engine(5, 1, 32, "fc5")
+    with pytest.raises(tak_amd.TgError) as ei:
+        e.train_create()
+    assert ei.value.code == -4  # tensors missing
+    with pytest.raises(tak_amd.TgError) as ei:
+        e.train_step()
+    assert ei.value.code == -7  # no trainer
+    e.close()

@@ -55,6 +55,17 @@ class TakNet(nn.Module):
         return p, v[:, 0]
 
 
+    def forward_training(self, x):  # forward_training (net5.rs:113-118 / net6.rs:111-122): log_softmax, BN per self.training
+        s = F.relu(self.bn0(self.conv0(x)))
+        for blk in self.res:
+            s = blk(s)
+        if self.head == "fc5":
+            p = self.policy(s.reshape(s.shape[0], -1))
+        else:
+            p = self.policy(s).reshape(s.shape[0], -1)
+        return torch.log_softmax(p, dim=1), torch.tanh(self.value(s.reshape(s.shape[0], -1)))
+
+
 def make_net(n, res_blocks, filters, head, seed=0, randomize_bn=True):
     torch.manual_seed(seed)
     net = TakNet(n, res_blocks, filters, head)
@@ -88,3 +99,32 @@ def abi_tensors(net):
 def forward(net, planes):
     p, v = net(torch.from_numpy(np.ascontiguousarray(planes, np.float32)))
     return p.numpy(), v.numpy()
+
+
+def abi_name(k):
+    parts = k.split(".")
+    return f"res{parts[1]}." + ".".join(parts[2:]) if parts[0] == "res" else k
+
+
+def train_chunk(net, planes, pi, z):
+    """train_inner (alpha-tak/src/model/network.rs:58-91): BN in training mode, loss_p = −Σπ·logp / B,
+    loss_z = Σ(z − v)² / B, backward (gradients accumulate in .grad).  Returns (loss_p, loss_z)."""
+    net.train()
+    x = torch.from_numpy(np.ascontiguousarray(planes, np.float32))
+    p = torch.from_numpy(np.ascontiguousarray(pi, np.float32))
+    zt = torch.from_numpy(np.ascontiguousarray(z, np.float32))[:, None]
+    logp, v = net.forward_training(x)
+    b = x.shape[0]
+    loss_p = -(p * logp).sum() / b
+    loss_z = (zt - v).square().sum() / b
+    (loss_z + loss_p).backward()
+    return float(loss_p.detach()), float(loss_z.detach())
+
+
+def make_adam(net, lr=1e-4, wd=1e-4):
+    """Adam { wd, ..Default::default() }.build(vs, lr) (network.rs:40-45): torch::optim::Adam with L2 weight decay"""
+    return torch.optim.Adam(net.parameters(), lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+
+
+def named_grads(net):
+    return {abi_name(k): v.grad.detach().numpy().copy() for k, v in net.named_parameters()}

@@ -328,23 +328,32 @@ int upload_chunk(TgEngine* e, int n, const uint8_t* states, const int32_t* n_mov
         const int s = order ? order[i] : i;
         if (n_moves[s] < 0 || n_moves[s] > TG_MAX_MOVES) return fail(TG_ERR_INVALID_ARG, "training example: n_moves out of range");
         for (int k = 0; k < 8; k++) z8[(size_t)i * 8 + k] = results[s];
-        if (order) {
-            TG_HIP(hipMemcpyAsync((uint8_t*)t->ex_states.p + (size_t)i * sb, states + (size_t)s * sb, sb, hipMemcpyHostToDevice, st));
-            TG_HIP(hipMemcpyAsync((int32_t*)t->ex_nmoves.p + i, n_moves + s, 4, hipMemcpyHostToDevice, st));
-            TG_HIP(hipMemcpyAsync((uint16_t*)t->ex_moves.p + (size_t)i * TG_MAX_MOVES, moves + (size_t)s * TG_MAX_MOVES, (size_t)n_moves[s] * 2,
-                                  hipMemcpyHostToDevice, st));
-            TG_HIP(hipMemcpyAsync((uint32_t*)t->ex_visits.p + (size_t)i * TG_MAX_MOVES, visits + (size_t)s * TG_MAX_MOVES,
-                                  (size_t)n_moves[s] * 4, hipMemcpyHostToDevice, st));
+    }
+    // shuffled chunks are gathered on the host first: five copies per chunk, whatever the order
+    std::vector<uint8_t> g_states;
+    std::vector<int32_t> g_nm;
+    std::vector<TgMove> g_moves;
+    std::vector<uint32_t> g_visits;
+    if (order) {
+        g_states.resize((size_t)n * sb);
+        g_nm.resize(n);
+        g_moves.resize((size_t)n * TG_MAX_MOVES);
+        g_visits.resize((size_t)n * TG_MAX_MOVES);
+        for (int i = 0; i < n; i++) {
+            const int s = order[i];
+            std::memcpy(g_states.data() + (size_t)i * sb, states + (size_t)s * sb, sb);
+            g_nm[i] = n_moves[s];
+            std::memcpy(g_moves.data() + (size_t)i * TG_MAX_MOVES, moves + (size_t)s * TG_MAX_MOVES, (size_t)TG_MAX_MOVES * sizeof(TgMove));
+            std::memcpy(g_visits.data() + (size_t)i * TG_MAX_MOVES, visits + (size_t)s * TG_MAX_MOVES, (size_t)TG_MAX_MOVES * 4);
         }
+        states = g_states.data(); n_moves = g_nm.data(); moves = g_moves.data(); visits = g_visits.data();
     }
-    if (!order) {
-        TG_HIP(hipMemcpyAsync(t->ex_states.p, states, (size_t)n * sb, hipMemcpyHostToDevice, st));
-        TG_HIP(hipMemcpyAsync(t->ex_nmoves.p, n_moves, (size_t)n * 4, hipMemcpyHostToDevice, st));
-        TG_HIP(hipMemcpyAsync(t->ex_moves.p, moves, (size_t)n * TG_MAX_MOVES * 2, hipMemcpyHostToDevice, st));
-        TG_HIP(hipMemcpyAsync(t->ex_visits.p, visits, (size_t)n * TG_MAX_MOVES * 4, hipMemcpyHostToDevice, st));
-    }
+    TG_HIP(hipMemcpyAsync(t->ex_states.p, states, (size_t)n * sb, hipMemcpyHostToDevice, st));
+    TG_HIP(hipMemcpyAsync(t->ex_nmoves.p, n_moves, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    TG_HIP(hipMemcpyAsync(t->ex_moves.p, moves, (size_t)n * TG_MAX_MOVES * 2, hipMemcpyHostToDevice, st));
+    TG_HIP(hipMemcpyAsync(t->ex_visits.p, visits, (size_t)n * TG_MAX_MOVES * 4, hipMemcpyHostToDevice, st));
     TG_HIP(hipMemcpyAsync(t->zt.p, z8.data(), z8.size() * 4, hipMemcpyHostToDevice, st));
-    TG_HIP(hipStreamSynchronize(st));  // z8 (and the caller's buffers) may go away
+    TG_HIP(hipStreamSynchronize(st));  // the staging vectors (and the caller's buffers) may go away
     return TG_OK;
 }
 

@@ -139,42 +139,53 @@ __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ a,
     }
 }
 
-// one thread per channel: fixed-order sum of the block partials
+// One 256-thread block per channel: fixed-order (thread-strided, then tree) sum of the block partials.
 __device__ inline double part_sum(const double* part, int nblk, int F, int w, int c) {
+    __shared__ double red[256];
     double s = 0.0;
-    for (int b = 0; b < nblk; b++) s += part[((size_t)b * 2 + w) * F + c];
-    return s;
+    for (int b = threadIdx.x; b < nblk; b += 256) s += part[((size_t)b * 2 + w) * F + c];
+    __syncthreads();
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+        __syncthreads();
+    }
+    return red[0];
 }
-__global__ void k_bn_mean_finalize(const double* __restrict__ part, int nblk, int F, int M, float* __restrict__ mean) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < F) mean[c] = (float)(part_sum(part, nblk, F, 0, c) / (double)M);
+__global__ __launch_bounds__(256) void k_bn_mean_finalize(const double* __restrict__ part, int nblk, int F, int M, float* __restrict__ mean) {
+    const int c = blockIdx.x;
+    double s = part_sum(part, nblk, F, 0, c);
+    if (threadIdx.x == 0) mean[c] = (float)(s / (double)M);
 }
 // biased variance → invstd; running statistics as torch batch_norm(training=True): unbiased variance, momentum
-__global__ void k_bn_var_finalize(const double* __restrict__ part, int nblk, int F, int M, float eps, float momentum,
-                                  const float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ running_mean,
-                                  float* __restrict__ running_var) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= F) return;
+__global__ __launch_bounds__(256) void k_bn_var_finalize(const double* __restrict__ part, int nblk, int F, int M, float eps, float momentum,
+                                                         const float* __restrict__ mean, float* __restrict__ invstd,
+                                                         float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x;
     double var = part_sum(part, nblk, F, 0, c) / (double)M;
+    if (threadIdx.x != 0) return;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
     double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
     running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * (double)mean[c]);
     running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
 }
 // Σg, Σg·x̂ → grad_beta += , grad_gamma += ; the per-row means used by the apply kernel
-__global__ void k_bn_bwd_finalize(const double* __restrict__ part, int nblk, int F, int M, float* __restrict__ mean_g,
-                                  float* __restrict__ mean_gx, float* __restrict__ grad_gamma, float* __restrict__ grad_beta) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= F) return;
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const double* __restrict__ part, int nblk, int F, int M, float* __restrict__ mean_g,
+                                                         float* __restrict__ mean_gx, float* __restrict__ grad_gamma,
+                                                         float* __restrict__ grad_beta) {
+    const int c = blockIdx.x;
     double sg = part_sum(part, nblk, F, 0, c), sgx = part_sum(part, nblk, F, 1, c);
+    if (threadIdx.x != 0) return;
     mean_g[c] = (float)(sg / (double)M);
     mean_gx[c] = (float)(sgx / (double)M);
     grad_beta[c] += (float)sg;
     grad_gamma[c] += (float)sgx;
 }
-__global__ void k_colsum_finalize(const double* __restrict__ part, int nblk, int Fp, int valid, float* __restrict__ grad) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < valid) grad[c] += (float)part_sum(part, nblk, Fp, 0, c);
+__global__ __launch_bounds__(256) void k_colsum_finalize(const double* __restrict__ part, int nblk, int Fp, int valid, float* __restrict__ grad) {
+    const int c = blockIdx.x;
+    double s = part_sum(part, nblk, Fp, 0, c);
+    if (threadIdx.x == 0 && c < valid) grad[c] += (float)s;
 }
 
 // column sums of a wide row-major matrix (FC policy bias gradient): thread = column, block row = row split
@@ -590,9 +601,9 @@ hipError_t launch_bn_stats(hipStream_t st, const float* z, int M, int F, float e
                            float* invstd, float* running_mean, float* running_var) {
     int rpb, nblk = col_reduce_blocks(M, F, &rpb);
     hipLaunchKernelGGL((k_col_reduce<RED_SUM>), dim3(nblk), dim3(256), 0, st, z, nullptr, nullptr, nullptr, nullptr, M, F, rpb, part);
-    hipLaunchKernelGGL(k_bn_mean_finalize, dim3((F + 63) / 64), dim3(64), 0, st, part, nblk, F, M, mean);
+    hipLaunchKernelGGL(k_bn_mean_finalize, dim3(F), dim3(256), 0, st, part, nblk, F, M, mean);
     hipLaunchKernelGGL((k_col_reduce<RED_VAR>), dim3(nblk), dim3(256), 0, st, z, nullptr, nullptr, mean, nullptr, M, F, rpb, part);
-    hipLaunchKernelGGL(k_bn_var_finalize, dim3((F + 63) / 64), dim3(64), 0, st, part, nblk, F, M, eps, momentum, mean, invstd,
+    hipLaunchKernelGGL(k_bn_var_finalize, dim3(F), dim3(256), 0, st, part, nblk, F, M, eps, momentum, mean, invstd,
                        running_mean, running_var);
     return hipGetLastError();
 }
@@ -607,7 +618,7 @@ hipError_t launch_bn_bwd(hipStream_t st, const float* dy, const float* y, const 
                          float* grad_beta, float* dz, float* gskip) {
     int rpb, nblk = col_reduce_blocks(M, F, &rpb);
     hipLaunchKernelGGL((k_col_reduce<RED_BNBWD>), dim3(nblk), dim3(256), 0, st, dy, y, z, mean, invstd, M, F, rpb, part);
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((F + 63) / 64), dim3(64), 0, st, part, nblk, F, M, mean_g, mean_gx, grad_gamma, grad_beta);
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(F), dim3(256), 0, st, part, nblk, F, M, mean_g, mean_gx, grad_gamma, grad_beta);
     size_t total4 = (size_t)M * F / 4;
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(blocks_for(total4)), dim3(256), 0, st, dy, y, z, mean, invstd, gamma, mean_g, mean_gx, dz,
                        gskip, total4, F / 4);
@@ -618,12 +629,12 @@ hipError_t launch_colsum_acc(hipStream_t st, const float* a, int M, int Fp, int 
         const int splits = 32;
         int rps = (M + splits - 1) / splits;
         hipLaunchKernelGGL(k_colsum_wide, dim3((Fp + 255) / 256, splits), dim3(256), 0, st, a, M, Fp, Fp, rps, part);
-        hipLaunchKernelGGL(k_colsum_finalize, dim3((Fp + 63) / 64), dim3(64), 0, st, part, splits, Fp, valid, grad);
+        hipLaunchKernelGGL(k_colsum_finalize, dim3(valid), dim3(256), 0, st, part, splits, Fp, valid, grad);
         return hipGetLastError();
     }
     int rpb, nblk = col_reduce_blocks(M, Fp, &rpb);
     hipLaunchKernelGGL((k_col_reduce<RED_SUM>), dim3(nblk), dim3(256), 0, st, a, nullptr, nullptr, nullptr, nullptr, M, Fp, rpb, part);
-    hipLaunchKernelGGL(k_colsum_finalize, dim3((Fp + 63) / 64), dim3(64), 0, st, part, nblk, Fp, valid, grad);
+    hipLaunchKernelGGL(k_colsum_finalize, dim3(valid), dim3(256), 0, st, part, nblk, Fp, valid, grad);
     return hipGetLastError();
 }
 hipError_t launch_policy_loss(hipStream_t st, const float* logits, int row_stride, bool conv_head, int nsq, int ch_stride, int P, int B,

@@ -375,19 +375,21 @@ __global__ void k_value_wgrad_finalize(const double* __restrict__ part, int spli
 // runs over the rows.  v_mfma_f32_16x16x4_f32 consumes 4 rows per instruction (k = lane>>4); a lane loads
 // 16 bytes = 4 consecutive channels of its row from each side and uses component a (G side) × component u
 // (X side) for sub-tile (a,u), whose 16×16 outputs are the channels {4i+a}×{4j+u}: 2 LDS reads feed 16 MFMAs
-// and nothing is transposed.  A workgroup = 3 waves owning a 64(co)×64(ci) block for its row range:
-//   CONV: wave w handles taps 3w..3w+2 (the X tile is shared, taps are LDS row offsets or the zero row);
-//   FC:   wave w handles ci block 3·tile+w (X tile = 192 channels).
+// and nothing is transposed.  A workgroup = 4 waves (one per SIMD) owning a 64(co)×64(ci) block for its rows:
+//   CONV: wave w owns G sub-tile a = w for all 9 taps × 4 X sub-tiles (36 accumulator tiles; the X tile is
+//         shared, taps are LDS row offsets or the zero row);
+//   FC:   wave w owns ci block 4·tile+w (X tile = 256 channels), all 16 sub-tiles.
 // Partial blocks (one per row split) go to a workspace; k_wgrad_reduce_* sums them in fixed order into the
 // gradient buffer in tch layout — deterministic, and the place where gradients accumulate over chunks.
 // part[((split·ntiles + tile)·nsub + sub)·4096 + co_l·64 + ci_l]
 // ------------------------------------------------------------------------------------------------
 template <bool CONV>
-__global__ __launch_bounds__(192) void k_wgrad(const float* __restrict__ X, int xs, int xvalid, const float* __restrict__ G, int gs,
+__global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ X, int xs, int xvalid, const float* __restrict__ G, int gs,
                                                int gvalid, int R, int n, int nsq, int rows_chunk, int chunks_per_split, int ncob,
                                                float* __restrict__ part) {
-    constexpr int T = CONV ? 3 : 1;
-    constexpr int XC = CONV ? 64 : 192;
+    constexpr int T = CONV ? 9 : 1;      // taps per wave
+    constexpr int NA = CONV ? 1 : 4;     // G sub-tiles per wave
+    constexpr int XC = CONV ? 64 : 256;
     constexpr int XV = XC / 4;           // float4 per staged X row
     constexpr int XLS4 = XV + 1;         // LDS row pitch (f32x4), +1 shifts banks between rows
     constexpr int GLS4 = 17;
@@ -403,15 +405,15 @@ __global__ __launch_bounds__(192) void k_wgrad(const float* __restrict__ X, int 
     const int xc0 = cib * XC, gc0 = cob * 64;
     const int split = blockIdx.x;
 
-    f32x4 acc[T][4][4];
+    f32x4 acc[T][NA][4];
 #pragma unroll
     for (int t = 0; t < T; t++)
 #pragma unroll
-        for (int a = 0; a < 4; a++)
+        for (int a = 0; a < NA; a++)
 #pragma unroll
             for (int u = 0; u < 4; u++) acc[t][a][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int v = tid; v < XLS4; v += 192) Xt[(size_t)rows_chunk * XLS4 + v] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int v = tid; v < XLS4; v += 256) Xt[(size_t)rows_chunk * XLS4 + v] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int row_begin = split * chunks_per_split * rows_chunk;
     for (int ch = 0; ch < chunks_per_split; ch++) {
@@ -420,14 +422,14 @@ __global__ __launch_bounds__(192) void k_wgrad(const float* __restrict__ X, int 
         const int rows = min(rows_chunk, R - r0);
         const int rows_pad = (rows + 3) & ~3;
         __syncthreads();  // the previous chunk has been consumed
-        for (int idx = tid; idx < rows * XV; idx += 192) {
+        for (int idx = tid; idx < rows * XV; idx += 256) {
             int r = idx / XV, v = idx - r * XV;
             int c = xc0 + 4 * v;
             f32x4 val = f32x4{0.f, 0.f, 0.f, 0.f};
             if (c < xvalid) val = *(const f32x4*)(X + (size_t)(r0 + r) * xs + c);
             Xt[r * XLS4 + v] = val;
         }
-        for (int idx = tid; idx < rows_pad * 16; idx += 192) {
+        for (int idx = tid; idx < rows_pad * 16; idx += 256) {
             int r = idx >> 4, v = idx & 15;
             int c = gc0 + 4 * v;
             f32x4 val = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(192) void k_wgrad(const float* __restrict__ X, int 
             Gt[r * GLS4 + v] = val;
         }
         if (CONV) {
-            for (int r = tid; r < rows_pad; r += 192) {
+            for (int r = tid; r < rows_pad; r += 256) {
                 int m = 0;
                 if (r < rows) {
                     int sq = r % nsq;  // r0 is a multiple of nsq
@@ -450,40 +452,47 @@ __global__ __launch_bounds__(192) void k_wgrad(const float* __restrict__ X, int 
             }
         }
         __syncthreads();
-        for (int rr = 0; rr < rows_pad; rr += 4) {
-            const int r = rr + q;
-            const f32x4 g = Gt[r * GLS4 + j];
-            f32x4 x[T];
-            if (CONV) {
+        if (CONV) {
+            for (int rr = 0; rr < rows_pad; rr += 4) {
+                const int r = rr + q;
+                const float g = ((const float*)Gt)[(r * GLS4 + j) * 4 + wave];  // this wave's G sub-tile a = wave: channels {4i + wave}
                 const int m = tmask[r];
+                f32x4 x[T];
 #pragma unroll
                 for (int t = 0; t < T; t++) {
-                    const int tap = wave * 3 + t;
-                    const int sh = (tap / 3 - 1) * n + (tap % 3 - 1);
-                    const int row = ((m >> tap) & 1) ? r + sh : rows_chunk;
+                    const int sh = (t / 3 - 1) * n + (t % 3 - 1);
+                    const int row = ((m >> t) & 1) ? r + sh : rows_chunk;
                     x[t] = Xt[row * XLS4 + j];
                 }
-            } else {
-                x[0] = r < rows ? Xt[r * XLS4 + wave * 16 + j] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < T; t++)
+#pragma unroll
+                    for (int u = 0; u < 4; u++) acc[t][0][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(g, x[t][u], acc[t][0][u], 0, 0, 0);
             }
+        } else {
+            for (int rr = 0; rr < rows_pad; rr += 4) {
+                const int r = rr + q;
+                const f32x4 g = Gt[r * GLS4 + j];
+                const f32x4 x = r < rows ? Xt[r * XLS4 + wave * 16 + j] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < T; t++)
+                for (int a = 0; a < NA; a++)
 #pragma unroll
-                for (int a = 0; a < 4; a++)
-#pragma unroll
-                    for (int u = 0; u < 4; u++) acc[t][a][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[a], x[t][u], acc[t][a][u], 0, 0, 0);
+                    for (int u = 0; u < 4; u++) acc[0][a][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[a], x[u], acc[0][a][u], 0, 0, 0);
+            }
         }
     }
     // lane (j, q), register v of sub-tile (a,u): co_l = 16q + 4v + a, ci_l = 4j + u
     const int ntiles = gridDim.y;
+    constexpr int NSUB = CONV ? 9 : 4;
 #pragma unroll
     for (int t = 0; t < T; t++) {
-        float* dst = part + (((size_t)split * ntiles + tile) * (3 * T) + (size_t)(wave * T + t)) * 4096;
+        const int sub = CONV ? t : wave;
+        float* dst = part + (((size_t)split * ntiles + tile) * NSUB + sub) * 4096;
 #pragma unroll
-        for (int a = 0; a < 4; a++)
+        for (int a = 0; a < NA; a++)
 #pragma unroll
             for (int v = 0; v < 4; v++) {
-                const int co_l = 16 * q + 4 * v + a;
+                const int co_l = 16 * q + 4 * v + (CONV ? wave : a);
                 f32x4 o = f32x4{acc[t][a][0][v], acc[t][a][1][v], acc[t][a][2][v], acc[t][a][3][v]};
                 *(f32x4*)(dst + co_l * 64 + 4 * j) = o;
             }
@@ -508,19 +517,19 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_conv(const float* __restri
     for (int sp = 0; sp < splits; sp++) s += part[(size_t)sp * total + idx];
     grad[((size_t)co * I + ci) * 9 + tap] += s;
 }
-// policy FC: grad[p·K + c·nsq + sq] += Σ_split part[…],  k = (3·cit + w)·64 + ci_l = sq·F + c
+// policy FC: grad[p·K + c·nsq + sq] += Σ_split part[…],  k = (4·cit + w)·64 + ci_l = sq·F + c
 __global__ __launch_bounds__(256) void k_wgrad_reduce_fc(const float* __restrict__ part, int splits, int ncit, int ncob, int P, int F,
                                                          int nsq, float* __restrict__ grad) {
     size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int ntiles = ncit * ncob;
-    size_t total = (size_t)ntiles * 3 * 4096;
+    size_t total = (size_t)ntiles * 4 * 4096;
     if (idx >= total) return;
     int ci_l = (int)(idx & 63), co_l = (int)((idx >> 6) & 63);
     size_t t = idx >> 12;
-    int w = (int)(t % 3);
-    int tile = (int)(t / 3);
+    int w = (int)(t & 3);
+    int tile = (int)(t >> 2);
     int cit = tile / ncob, cob = tile - cit * ncob;
-    int p = cob * 64 + co_l, k = (cit * 3 + w) * 64 + ci_l;
+    int p = cob * 64 + co_l, k = (cit * 4 + w) * 64 + ci_l;
     const int K = F * nsq;
     if (p >= P || k >= K) return;
     float s = 0.0f;
@@ -683,7 +692,7 @@ hipError_t launch_wgrad_conv(hipStream_t st, const float* X, int xs, int I, cons
     size_t lds = ((size_t)(rows_chunk + 1) * 17 + (size_t)rows_pad * 17) * 16 + (size_t)rows_pad * 4;
     const int xvalid = xs < ncib * 64 ? xs : ncib * 64;  // columns that exist in memory
     const int gvalid = gs < ncob * 64 ? gs : ncob * 64;
-    hipLaunchKernelGGL((k_wgrad<true>), dim3(splits, ncib * ncob), dim3(192), lds, st, X, xs, xvalid, G, gs, gvalid, B * nsq, n, nsq,
+    hipLaunchKernelGGL((k_wgrad<true>), dim3(splits, ncib * ncob), dim3(256), lds, st, X, xs, xvalid, G, gs, gvalid, B * nsq, n, nsq,
                        rows_chunk, cps, ncob, part);
     size_t total = (size_t)ncib * ncob * 9 * 4096;
     hipLaunchKernelGGL(k_wgrad_reduce_conv, dim3(blocks_for(total)), dim3(256), 0, st, part, splits, ncib, ncob, O, I, grad);
@@ -696,20 +705,20 @@ static void wgrad_plan_fc(int B, int* cps, int* splits) {
     *splits = (chunks + *cps - 1) / *cps;
 }
 size_t wgrad_fc_workspace(int B, int K, int P) {
-    int ncit = (K + 191) / 192, ncob = (P + 63) / 64, cps, splits;
+    int ncit = (K + 255) / 256, ncob = (P + 63) / 64, cps, splits;
     wgrad_plan_fc(B, &cps, &splits);
-    return (size_t)splits * ncit * ncob * 3 * 4096;
+    return (size_t)splits * ncit * ncob * 4 * 4096;
 }
 hipError_t launch_wgrad_fc(hipStream_t st, const float* S, int K, const float* G, int gs, int P, int B, int F, int nsq, float* part,
                            float* grad) {
-    int ncit = (K + 191) / 192, ncob = (P + 63) / 64, cps, splits;
+    int ncit = (K + 255) / 256, ncob = (P + 63) / 64, cps, splits;
     wgrad_plan_fc(B, &cps, &splits);
     const int rows_chunk = 32;
-    size_t lds = ((size_t)(rows_chunk + 1) * 49 + (size_t)rows_chunk * 17) * 16 + (size_t)rows_chunk * 4;
+    size_t lds = ((size_t)(rows_chunk + 1) * 65 + (size_t)rows_chunk * 17) * 16 + (size_t)rows_chunk * 4;
     const int gvalid = gs < ncob * 64 ? gs : ncob * 64;
-    hipLaunchKernelGGL((k_wgrad<false>), dim3(splits, ncit * ncob), dim3(192), lds, st, S, K, K, G, gs, gvalid, B, 1, 1, rows_chunk, cps,
+    hipLaunchKernelGGL((k_wgrad<false>), dim3(splits, ncit * ncob), dim3(256), lds, st, S, K, K, G, gs, gvalid, B, 1, 1, rows_chunk, cps,
                        ncob, part);
-    size_t total = (size_t)ncit * ncob * 3 * 4096;
+    size_t total = (size_t)ncit * ncob * 4 * 4096;
     hipLaunchKernelGGL(k_wgrad_reduce_fc, dim3(blocks_for(total)), dim3(256), 0, st, part, splits, ncit, ncob, P, F, nsq, grad);
     return hipGetLastError();
 }

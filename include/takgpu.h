@@ -389,6 +389,36 @@ int tg_comm_unique_id(void* id128);
 int tg_train_comm_init(TgEngine* e, int rank, int world_size, const void* id128);
 
 /* ---------------------------------------------------------------------------------------
+ * Pit (replaces `pit`, train/src/pit.rs:15-96): the new network against the old one,
+ * `pairs` openings × both colours, all 2·pairs games concurrently — one engine handle per weight set, each
+ * holding one tree per game (the reference gives each side its own `Player`).  The side to move searches
+ * `rollouts` leaves (reference: ROLLOUTS 50 × BATCH_SIZE 16), the waiting side `idle_rollouts` (the batch a
+ * `Player` keeps in flight, player.rs:65-66), moves are pick_move(exploit = true).  Openings: a1, a random far
+ * corner, `random_plies` random Flat/Cap placements (pit.rs:33-63), drawn from Philox(seed).  Not reproduced:
+ * `Player`'s virtual-loss batching inside one tree (one leaf per tree per iteration here) and the early exit
+ * of pit.rs:20-23 (all games run at once).  The caller applies the gate (main.rs:102: win_rate > 0.55).
+ * ------------------------------------------------------------------------------------- */
+typedef struct TgPitConfig {
+    int32_t pairs;          /* PIT_GAMES 128 */
+    int32_t rollouts;       /* ROLLOUTS × BATCH_SIZE = 800 leaves per move */
+    int32_t idle_rollouts;  /* 16 */
+    int32_t random_plies;   /* RANDOM_PLIES 2 */
+    int32_t komi;           /* Game::with_komi(2) */
+    int32_t max_plies;      /* safety cap on the game length, 0 = none */
+    int32_t arena_nodes;    /* per-game tree arena of both engines, 0 = 16384 */
+    int32_t reserved;
+    uint64_t seed;
+} TgPitConfig;
+typedef struct TgPitResult {
+    uint32_t wins, losses, draws; /* from the new network's point of view (PitResult, pit.rs:98-103) */
+    uint32_t unfinished;          /* games cut by max_plies */
+    uint32_t plies;               /* lock-step plies played */
+    uint32_t reserved;
+    double win_rate;              /* wins / (wins + losses), pit.rs:105-110 */
+} TgPitResult;
+int tg_pit(TgEngine* e_new, TgEngine* e_old, const TgPitConfig* cfg, TgPitResult* out);
+
+/* ---------------------------------------------------------------------------------------
  * Text formats at the edge of the path (host only).  PTN moves / TPS positions follow takparse 0.5.5's
  * Display + FromStr as used by tak/src/game.rs:79 and tak/src/tps.rs:7-96; the example line follows
  * alpha-tak/src/example.rs:81-133 ("{tps};{w_stones};{w_caps};{b_stones};{b_caps};{half_komi};{result};

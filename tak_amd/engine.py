@@ -63,6 +63,20 @@ class TgTrainConfig(C.Structure):
                 ("chunks_in_step", C.c_int32), ("reserved", C.c_int32)]
 
 
+class TgPitConfig(C.Structure):
+    _fields_ = [("pairs", C.c_int32), ("rollouts", C.c_int32), ("idle_rollouts", C.c_int32), ("random_plies", C.c_int32),
+                ("komi", C.c_int32), ("max_plies", C.c_int32), ("arena_nodes", C.c_int32), ("reserved", C.c_int32),
+                ("seed", C.c_uint64)]
+
+
+class TgPitResult(C.Structure):
+    _fields_ = [("wins", C.c_uint32), ("losses", C.c_uint32), ("draws", C.c_uint32), ("unfinished", C.c_uint32),
+                ("plies", C.c_uint32), ("reserved", C.c_uint32), ("win_rate", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
 # every symbol include/takgpu.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "tg_state_bytes", "tg_engine_create", "tg_engine_destroy", "tg_last_error", "tg_sync", "tg_stream",
@@ -74,7 +88,7 @@ ABI_SYMBOLS = [
     "tg_profile_enable", "tg_profile_read", "tg_board_pass_bench",
     "tg_augment_examples",
     "tg_train_create", "tg_train_chunk", "tg_train", "tg_train_step", "tg_train_forward", "tg_train_get_tensor",
-    "tg_train_get_grad", "tg_train_commit", "tg_comm_unique_id", "tg_train_comm_init",
+    "tg_train_get_grad", "tg_train_commit", "tg_comm_unique_id", "tg_train_comm_init", "tg_pit",
     "tg_format_move", "tg_parse_move", "tg_format_tps", "tg_parse_tps", "tg_format_example", "tg_parse_example",
 ]
 
@@ -181,6 +195,16 @@ def comm_unique_id():
     if rc:
         raise TgError(rc, load_library().tg_last_error().decode())
     return uid.tobytes()
+
+
+def pit(new, old, pairs=128, rollouts=800, idle_rollouts=16, random_plies=2, komi=2, max_plies=0, arena_nodes=0, seed=0):
+    """`pit(new, old)` of train/src/pit.rs on two engines (one per weight set) → dict(wins, losses, draws, win_rate, …)"""
+    cfg = TgPitConfig(pairs, rollouts, idle_rollouts, random_plies, komi, max_plies, arena_nodes, 0, seed)
+    res = TgPitResult()
+    rc = load_library().tg_pit(new.h, old.h, C.byref(cfg), C.byref(res))
+    if rc:
+        raise TgError(rc, load_library().tg_last_error().decode())
+    return res.as_dict()
 
 
 def _mask(active):

@@ -1,0 +1,103 @@
+"""Pit (tg_pit ≙ `pit`, train/src/pit.rs:15-96): the GPU match against a CPU replay of the same loop on the oracle's
+scalar MCTS (two trees per game, one per network), with the deterministic test evaluators so that whole games are
+bit-identical; plus the symmetry property that two identical networks split every pair of games."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RNG_PIT_CORNER, RNG_PIT_RANDOM = 8, 9
+
+
+def _oracle_pit(orc, n, evals, pairs, rollouts, idle, random_plies, komi, seed, max_plies=0):
+    head = orc.HEAD_FC5 if n == 5 else orc.HEAD_CONV
+    op = np.stack([orc.new_game(n, half_komi=2 * komi) for _ in range(pairs)])
+    for ply in range(2 + random_plies):
+        if ply == 0:
+            mv = np.zeros(pairs, np.uint16)
+        elif ply == 1:
+            mv = np.array([n * n - 1 if orc.philox(seed, p, 0, 1 | (RNG_PIT_CORNER << 16), 0)[0] & 1 else (n - 1) * n for p in range(pairs)], np.uint16)
+        else:
+            lm, lc = orc.movegen(n, op)
+            mv = np.zeros(pairs, np.uint16)
+            for p in range(pairs):
+                ok = [int(m) for m in lm[p, : lc[p]] if (m >> 8) == 0 and ((m >> 6) & 3) != 1]
+                r = orc.philox(seed, p, 0, ply | (RNG_PIT_RANDOM << 16), 0)
+                x = (int(r[0]) << 32) | int(r[1])
+                mv[p] = ok[(x * len(ok)) >> 64]
+        op, status = orc.play(n, op, mv)
+        assert not status.any()
+    G = 2 * pairs
+    states = np.repeat(op, 2, axis=0)
+    trees = [orc.Search(n, head=head, evaluator=ev, seed=seed) for ev in evals]
+    for t in trees:
+        t.reset(states)
+    alive = np.ones(G, bool)
+    wins = losses = draws = plies = 0
+    sb = states.shape[1]
+    while True:
+        res = orc.result(n, states)
+        for g in range(G):
+            if alive[g] and res[g] != 0:
+                alive[g] = False
+                if res[g] in (5, 6):
+                    draws += 1
+                elif (res[g] in (1, 2)) == (g % 2 == 0):
+                    wins += 1
+                else:
+                    losses += 1
+        if not alive.any() or (max_plies and plies >= max_plies):
+            break
+        to_move = states[:, sb - 16 + 1]
+        new_to_move = alive & ((to_move == 0) == (np.arange(G) % 2 == 0))
+        act = [new_to_move, alive & ~new_to_move]
+        roots = []
+        for k in range(2):
+            trees[k].run(rollouts, act[k].astype(np.uint8))
+            trees[k].run(idle, act[1 - k].astype(np.uint8))
+            roots.append(trees[k].root())
+        chosen = np.zeros(G, np.uint16)
+        for g in range(G):
+            if alive[g]:
+                r = roots[0 if act[0][g] else 1]
+                v = r["visits"][g, : r["counts"][g]]
+                best = len(v) - 1 - int(np.argmax(v[::-1]))  # the LAST maximum (play.rs:54-57)
+                chosen[g] = r["moves"][g, best]
+        for t in trees:
+            t.play(chosen, alive.astype(np.uint8))
+        states = trees[0].states()
+        plies += 1
+    return dict(wins=wins, losses=losses, draws=draws, plies=plies, unfinished=int(alive.sum()))
+
+
+@pytest.mark.parametrize("n,pairs,rollouts", [(4, 6, 40), (5, 5, 30)])
+def test_pit_matches_oracle_replay(orc, n, pairs, rollouts):
+    import tak_amd
+
+    head = tak_amd.HEAD_FC5 if n == 5 else tak_amd.HEAD_CONV
+    new = tak_amd.Engine(n, evaluator=tak_amd.EVAL_HASH, max_batch=64, policy_head=head)
+    old = tak_amd.Engine(n, evaluator=tak_amd.EVAL_DUMMY, max_batch=64, policy_head=head)
+    kw = dict(pairs=pairs, rollouts=rollouts, idle_rollouts=4, random_plies=2, komi=2, seed=11, max_plies=60)
+    got = tak_amd.pit(new, old, arena_nodes=1 << 14, **kw)
+    want = _oracle_pit(orc, n, (orc.EVAL_HASH, orc.EVAL_DUMMY), kw["pairs"], kw["rollouts"], kw["idle_rollouts"], 2, 2, 11, max_plies=60)
+    for k in ("wins", "losses", "draws", "plies", "unfinished"):
+        assert got[k] == want[k], (got, want)
+    assert got["wins"] + got["losses"] + got["draws"] + got["unfinished"] == 2 * pairs
+    if got["wins"] + got["losses"]:
+        assert abs(got["win_rate"] - got["wins"] / (got["wins"] + got["losses"])) < 1e-12
+    new.close()
+    old.close()
+
+
+def test_identical_networks_split_every_pair(orc):
+    import tak_amd
+
+    a = tak_amd.Engine(5, evaluator=tak_amd.EVAL_HASH, max_batch=64)
+    b = tak_amd.Engine(5, evaluator=tak_amd.EVAL_HASH, max_batch=64)
+    r = tak_amd.pit(a, b, pairs=16, rollouts=24, idle_rollouts=24, seed=3, max_plies=80)
+    # same evaluator, same budget on both sides → the two games of a pair are the same game with the roles swapped
+    assert r["wins"] == r["losses"] and r["draws"] % 2 == 0 and r["unfinished"] % 2 == 0
+    with pytest.raises(tak_amd.TgError):
+        tak_amd.pit(a, a)
+    a.close()
+    b.close()

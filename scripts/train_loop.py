@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=500)
     ap.add_argument("--chunks-in-step", type=int, default=4)
     ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--pit-pairs", type=int, default=0, help="> 0: gate every round with tg_pit (train/src/main.rs:98-106)")
+    ap.add_argument("--pit-rollouts", type=int, default=64)
     args = ap.parse_args()
 
     import tak_amd
@@ -36,8 +38,13 @@ def main():
     head = "fc5" if args.board == 5 else "conv"
     net = torch_ref.make_net(args.board, args.blocks, args.filters, head, seed=0, randomize_bn=False)
     eng = tak_amd.Engine(args.board, res_blocks=args.blocks, filters=args.filters, evaluator=tak_amd.EVAL_RESNET, max_batch=args.games)
-    eng.load_state_dict(torch_ref.abi_tensors(net))
+    tensors = torch_ref.abi_tensors(net)
+    eng.load_state_dict(tensors)
     eng.train_create(chunk_size=args.chunk, chunks_in_step=args.chunks_in_step)
+    old = None
+    if args.pit_pairs:
+        old = tak_amd.Engine(args.board, res_blocks=args.blocks, filters=args.filters, evaluator=tak_amd.EVAL_RESNET, max_batch=2 * args.pit_pairs)
+        old.load_state_dict(tensors)
     eng.selfplay_create(args.games, arena_nodes=1 << 13, seed=0, rollouts=args.rollouts, max_examples=4 * args.examples)
     report = []
     for rnd in range(args.rounds):
@@ -56,12 +63,28 @@ def main():
         t0 = time.perf_counter()
         eng.train_commit()
         t_commit = time.perf_counter() - t0
+        gate = None
+        if old is not None:  # training_loop: keep the new network only if it beats the old one (WIN_RATE_THRESHOLD 0.55)
+            t0 = time.perf_counter()
+            gate = tak_amd.pit(eng, old, pairs=args.pit_pairs, rollouts=args.pit_rollouts, idle_rollouts=16, seed=rnd, max_plies=200)
+            gate["seconds"] = time.perf_counter() - t0
+            new_tensors = {k: eng.train_get_tensor(k, v.shape) for k, v in tensors.items()}
+            if gate["win_rate"] > 0.55:
+                tensors = new_tensors
+                old.load_state_dict(tensors)
+            else:  # drop the trained copy: back to the old parameters, fresh trainer
+                eng.load_state_dict(tensors)
+                eng.train_create(chunk_size=args.chunk, chunks_in_step=args.chunks_in_step)
+            gate["accepted"] = gate["win_rate"] > 0.55
+            eng.selfplay_create(args.games, arena_nodes=1 << 13, seed=rnd + 1, rollouts=args.rollouts, max_examples=4 * args.examples)
         chunks = args.examples // args.chunk
         report.append({"round": rnd, "selfplay_s": t_sp, "examples": int(len(hdr)), "train_s": t_tr, "chunks": chunks, "steps": steps,
                        "ms_per_chunk": 1e3 * t_tr / max(chunks, 1), "positions_per_s": chunks * args.chunk * 8 / t_tr,
-                       "loss_p": lp, "loss_z": lz, "commit_s": t_commit, "stats": eng.selfplay_stats()})
+                       "loss_p": lp, "loss_z": lz, "commit_s": t_commit, "pit": gate, "stats": eng.selfplay_stats()})
         print(json.dumps(report[-1]), flush=True)
     eng.close()
+    if old is not None:
+        old.close()
 
 
 if __name__ == "__main__":

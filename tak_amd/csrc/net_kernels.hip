@@ -649,6 +649,53 @@ __global__ __launch_bounds__(256) void k_softmax(const float* __restrict__ logit
     }
 }
 
+// Conv policy head (net6.rs:98-103): the logits sit in NHWC ([sq][ch_stride]) and the probabilities leave in the
+// reference's order p = ch·N² + sq.  One block per position: the row is read once, coalesced, into LDS (pitch
+// ch_stride + 1 so that the transposed read-out is bank-conflict free), exp is evaluated once per output.
+__global__ __launch_bounds__(256) void k_softmax_conv(const float* __restrict__ logits, int nsq, int ch_stride, int C,
+                                                      float* __restrict__ policy) {
+    extern __shared__ float row[];  // nsq × (ch_stride + 1)
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int pitch = ch_stride + 1;
+    const int vpr = ch_stride >> 2;
+    const f32x4* x4 = (const f32x4*)(logits + (size_t)b * nsq * ch_stride);
+    float mx = -INFINITY;
+    for (int idx = tid; idx < nsq * vpr; idx += 256) {
+        int sq = idx / vpr, v = idx - sq * vpr;
+        f32x4 x = x4[idx];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            int ch = 4 * v + t;
+            row[sq * pitch + ch] = x[t];
+            if (ch < C) mx = fmaxf(mx, x[t]);
+        }
+    }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    const int P = C * nsq;
+    float s = 0.0f;
+    for (int p = tid; p < P; p += 256) {
+        int ch = p / nsq, sq = p - ch * nsq;
+        float e = expf(row[sq * pitch + ch] - mx);
+        row[sq * pitch + ch] = e;
+        s += e;
+    }
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    const float inv = 1.0f / s;
+    float* o = policy + (size_t)b * P;
+    for (int p = tid; p < P; p += 256) {
+        int ch = p / nsq, sq = p - ch * nsq;
+        o[p] = row[sq * pitch + ch] * inv;
+    }
+}
+
 // NCHW planes (the reference tensor layout) → NHWC rows padded to Cpad channels
 __global__ void k_nchw_to_nhwc(const float* __restrict__ src, int B, int C, int nsq, int Cpad, float* __restrict__ dst) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -776,6 +823,10 @@ hipError_t launch_value_head(hipStream_t st, const float* act, const float* wv, 
 
 hipError_t launch_softmax(hipStream_t st, const float* logits, int row_stride, bool conv_head, int nsq, int ch_stride, int P,
                           int B, float* policy) {
+    if (conv_head && (ch_stride & 3) == 0 && (size_t)nsq * (ch_stride + 1) * 4 <= 64 * 1024) {
+        hipLaunchKernelGGL(k_softmax_conv, dim3(B), dim3(256), (size_t)nsq * (ch_stride + 1) * 4, st, logits, nsq, ch_stride, P / nsq, policy);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_softmax, dim3(B), dim3(256), 0, st, logits, row_stride, conv_head ? 1 : 0, nsq, ch_stride, P, policy);
     return hipGetLastError();
 }

@@ -39,3 +39,26 @@ def reduce_time_and_count(dist, dt_local, count_local, device="cpu"):
     c = torch.tensor([float(count_local)], dtype=torch.float64, device=device)
     dist.all_reduce(c, op=dist.ReduceOp.SUM)
     return float(t.item()), int(c.item())
+
+
+def training_shard(n_examples, rank, world, chunk_size):
+    """[begin, end) of a rank's examples for data-parallel training: every rank gets the same number of WHOLE chunks
+    (the gradient all-reduce inside tg_train_chunk's optimiser step must be entered equally often on every rank);
+    the remainder is dropped, as Network::train's chunks_exact does (alpha-tak/src/model/network.rs:53)."""
+    chunks = n_examples // chunk_size
+    per_rank = chunks // world
+    begin = rank * per_rank * chunk_size
+    return begin, begin + per_rank * chunk_size
+
+
+def broadcast_unique_id(dist, make_id, device="cpu"):
+    """Rank 0 creates the 128-byte RCCL unique id (tak_amd.comm_unique_id), every rank receives it."""
+    import torch
+
+    if dist is None:
+        return make_id()
+    buf = torch.zeros(128, dtype=torch.uint8, device=device)
+    if dist.get_rank() == 0:
+        buf.copy_(torch.frombuffer(bytearray(make_id()), dtype=torch.uint8))
+    dist.broadcast(buf, src=0)
+    return bytes(buf.cpu().numpy().tobytes())

@@ -63,3 +63,34 @@ def test_two_rank_sharding_equals_single_process(orc):
     for sh in shards:
         union.update(keyed(sh["hdr"], sh["states"], sh["moves"], sh["visits"]))
     assert union == single
+
+
+DP_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from tak_amd import dist as tdist
+rank, world, _ = tdist.env_rank()
+dist = tdist.init("gloo", rank, world)
+uid = tdist.broadcast_unique_id(dist, lambda: bytes((7 * i + 3) % 256 for i in range(128)) if rank == 0 else b"")
+b, e = tdist.training_shard(10_345, rank, world, 500)
+np.savez(os.path.join({out!r}, f"dp{{rank}}.npz"), uid=np.frombuffer(uid, np.uint8), shard=np.array([b, e]))
+dist.destroy_process_group()
+"""
+
+
+def test_data_parallel_host_plumbing():
+    """The host side of data-parallel training (config C5): the RCCL unique id reaches every rank, and the ranks
+    train on disjoint shards of equally many whole chunks."""
+    with tempfile.TemporaryDirectory() as tmp:
+        script = os.path.join(tmp, "dp_worker.py")
+        open(script, "w").write(DP_WORKER.format(root=ROOT, out=tmp))
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", OMP_NUM_THREADS="1")
+        procs = [subprocess.Popen([sys.executable, script], env=dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r))) for r in range(2)]
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+        out = [np.load(os.path.join(tmp, f"dp{r}.npz")) for r in range(2)]
+    want = bytes((7 * i + 3) % 256 for i in range(128))
+    assert out[0]["uid"].tobytes() == want and out[1]["uid"].tobytes() == want
+    (b0, e0), (b1, e1) = out[0]["shard"], out[1]["shard"]
+    assert (b0, e0, b1, e1) == (0, 5000, 5000, 10000)  # 20 whole chunks of 500 → 10 per rank, 345 dropped

@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--cpu-games", type=int, default=256)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
+                    help="tower arithmetic: exact f32 MFMA (default, the parity path) or split-bf16 (3 bf16 MFMAs per product)")
     ap.add_argument("--profile-every", type=int, default=8, help="time the tower convs of every k-th forward (0 = off)")
     args = ap.parse_args()
 
@@ -119,6 +121,8 @@ def main():
     eng = tak_amd.Engine(args.board, res_blocks=args.blocks, filters=args.filters,
                          policy_head=tak_amd.HEAD_FC5 if args.head == "fc5" else tak_amd.HEAD_CONV,
                          evaluator=tak_amd.EVAL_RESNET, max_batch=args.games, device=local_rank)
+    if args.precision != "f32":
+        eng.set_precision(args.precision)
     eng.load_state_dict(tensors)
     steps_total = args.steps + args.warmup
     eng.selfplay_create(args.games, arena_nodes=args.arena, seed=args.seed, rollouts=args.rollouts,

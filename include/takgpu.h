@@ -223,6 +223,14 @@ int tg_perft(TgEngine* e, int n, const void* states, int depth, uint64_t* counts
 int tg_net_set_tensor(TgEngine* e, const char* name, const float* data, size_t count);
 /* Fold BN (eval mode, eps 1e-5) into the convs, re-layout for the MFMA kernels, upload. */
 int tg_net_finalize(TgEngine* e);
+/* Arithmetic of the residual tower (call before tg_net_finalize).
+ * TG_PRECISION_F32 (default): f32 operands on v_mfma_f32_16x16x4_f32 — exact f32 fmaf chains.
+ * TG_PRECISION_BF16X3: every f32 operand is carried as hi + lo bf16 halves and a product is the sum of three bf16
+ *   MFMAs (hi·hi + lo·hi + hi·lo) accumulated in f32 — 16 mantissa bits per operand, 3/16 of the f32 MFMA time.
+ *   Measured deviation from the f32 forward ≤ 1e-5 relative on the policy and ≤ 3e-6 on the eval, inside the 1e-4 the
+ *   reference comparison allows; supported for 5×5 (64 / 128 filters) and 6×6 (128 filters).  Heads stay f32. */
+typedef enum TgPrecision { TG_PRECISION_F32 = 0, TG_PRECISION_BF16X3 = 1 } TgPrecision;
+int tg_net_set_precision(TgEngine* e, int precision);
 
 /* Network::policy_eval (net5.rs:120-130 / net6.rs:124-138): n states → policy n×P
  * (full softmax, not masked) and eval n (tanh).  n = 0 is allowed (returns TG_OK). */

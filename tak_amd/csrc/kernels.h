@@ -34,6 +34,17 @@ struct TowerParams {
 bool tower_supported(int n, int F, int cin_pad);
 hipError_t launch_tower(hipStream_t st, const float* in, const TowerParams& T, float* out, int B, int n);
 hipError_t launch_tower_states(hipStream_t st, const uint8_t* states, const TowerParams& T, float* out, int B, int n);
+// net_s3_kernels.hip — split-bf16 ("bf16x3") tower
+struct TowerS3Params {
+    const void* w[48];    // per layer: [chunk = tap·KC + kc][cout][q][hi 8 bf16 | lo 8 bf16]
+    const float* b[48];   // per layer: bias[F]
+    int nlayers;
+    int cin_pad;          // channels per row of NHWC f32 input planes (planes entry only)
+    int F;
+};
+bool tower_s3_supported(int n, int F);
+hipError_t launch_tower_s3(hipStream_t st, const float* planes, const TowerS3Params& T, float* out, int B, int n);
+hipError_t launch_tower_s3_states(hipStream_t st, const uint8_t* states, const TowerS3Params& T, float* out, int B, int n);
 hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp, const float* bias, float* out, int M, int K,
                        int NP, int out_stride, int n_valid);
 hipError_t launch_value_head(hipStream_t st, const float* act, const float* wv, float bv, int B, int len, float* eval);

@@ -32,6 +32,10 @@ struct Net {
     DevBuf x, y, logits, planes_nhwc, planes_nchw;
     bool fused = false;  // whole tower in one launch (k_tower)
     TowerParams tower;
+    int precision = TG_PRECISION_F32;  // tg_net_set_precision
+    bool s3 = false;                   // split-bf16 tower in use
+    TowerS3Params tower_s3;
+    std::vector<DevBuf> s3_w;
     // measurement hooks (tg_profile_*)
     int prof_every = 0;
     uint64_t prof_counter = 0;
@@ -151,6 +155,42 @@ hipError_t upload_conv(const Folded& f, int O, int I, int Ipad, ConvLayer& L) {
     return hipMemcpy(L.b.p, bp.data(), bp.size() * 4, hipMemcpyHostToDevice);
 }
 
+uint16_t f32_to_bf16(float x) {  // round to nearest even, as v_cvt_pk_bf16_f32
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+float bf16_to_f32(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float x;
+    std::memcpy(&x, &u, 4);
+    return x;
+}
+
+// OIHW (BN folded) → [chunk = tap·KC + kc][cout][q][hi 8 | lo 8] bf16, channel = 32·kc + 8q + j, zero padded
+hipError_t upload_conv_s3(const Folded& f, int O, int I, int KC, DevBuf& buf) {
+    std::vector<uint16_t> w((size_t)9 * KC * O * 64, 0);
+    for (int tap = 0; tap < 9; tap++)
+        for (int kc = 0; kc < KC; kc++)
+            for (int o = 0; o < O; o++)
+                for (int q = 0; q < 4; q++)
+                    for (int j = 0; j < 8; j++) {
+                        int c = 32 * kc + 8 * q + j;
+                        if (c >= I) continue;
+                        float v = f.w[((size_t)o * I + c) * 9 + tap];
+                        uint16_t hi = f32_to_bf16(v);
+                        uint16_t lo = f32_to_bf16(v - bf16_to_f32(hi));
+                        size_t base = ((((size_t)tap * KC + kc) * O + o) * 4 + q) * 16;
+                        w[base + j] = hi;
+                        w[base + 8 + j] = lo;
+                    }
+    hipError_t e = buf.ensure(w.size() * 2);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(buf.p, w.data(), w.size() * 2, hipMemcpyHostToDevice);
+}
+
 }  // namespace
 
 int net_finalize(TgEngine* e) {
@@ -222,6 +262,29 @@ int net_finalize(TgEngine* e) {
             T.w[2 + 2 * i] = n->res2[i].w.as<float>(); T.b[2 + 2 * i] = n->res2[i].b.as<float>();
         }
     }
+    n->s3 = false;
+    if (n->precision == TG_PRECISION_BF16X3) {
+        if (!tower_s3_supported(e->g.n, F) || 1 + 2 * R > 48 || n->cin > 96)
+            return fail(TG_ERR_INVALID_ARG, "TG_PRECISION_BF16X3 supports 5x5 with 64 or 128 filters and 6x6 with 128 filters");
+        TowerS3Params& T = n->tower_s3;
+        T.nlayers = 1 + 2 * R; T.cin_pad = n->cin_pad; T.F = F;
+        n->s3_w.clear();
+        n->s3_w.resize(T.nlayers);
+        Folded g;
+        if (!fold_conv_bn(n, "conv0", "bn0", F, n->cin, g, err)) return fail(TG_ERR_WEIGHTS, err);
+        TG_HIP(upload_conv_s3(g, F, n->cin, 3, n->s3_w[0]));
+        T.w[0] = n->s3_w[0].p; T.b[0] = n->conv0.b.as<float>();
+        for (int i = 0; i < R; i++) {
+            std::string p = "res" + std::to_string(i);
+            if (!fold_conv_bn(n, p + ".conv1", p + ".bn1", F, F, g, err)) return fail(TG_ERR_WEIGHTS, err);
+            TG_HIP(upload_conv_s3(g, F, F, F / 32, n->s3_w[1 + 2 * i]));
+            if (!fold_conv_bn(n, p + ".conv2", p + ".bn2", F, F, g, err)) return fail(TG_ERR_WEIGHTS, err);
+            TG_HIP(upload_conv_s3(g, F, F, F / 32, n->s3_w[2 + 2 * i]));
+            T.w[1 + 2 * i] = n->s3_w[1 + 2 * i].p; T.b[1 + 2 * i] = n->res1[i].b.as<float>();
+            T.w[2 + 2 * i] = n->s3_w[2 + 2 * i].p; T.b[2 + 2 * i] = n->res2[i].b.as<float>();
+        }
+        n->s3 = true;
+    }
     size_t mb = (size_t)e->cfg.max_batch;
     TG_HIP(n->x.ensure(mb * nsq * F * 4));
     TG_HIP(n->y.ensure(mb * nsq * F * 4));
@@ -239,12 +302,12 @@ int net_forward_dev(TgEngine* e, int nb, const float* d_planes, float* d_policy,
     return net_forward_impl(e, nb, d_planes, nullptr, d_policy, d_eval);
 }
 
-bool net_takes_states(const TgEngine* e) { return net_ready(e) && e->net->fused; }
+bool net_takes_states(const TgEngine* e) { return net_ready(e) && (e->net->fused || e->net->s3); }
 
 int net_forward_states_dev(TgEngine* e, int nb, const uint8_t* d_states, float* d_policy, float* d_eval) {
     if (!net_ready(e)) return fail(TG_ERR_STATE, "network weights not finalized (tg_net_finalize)");
     if (nb <= 0) return TG_OK;
-    if (e->net->fused) return net_forward_impl(e, nb, nullptr, d_states, d_policy, d_eval);
+    if (e->net->fused || e->net->s3) return net_forward_impl(e, nb, nullptr, d_states, d_policy, d_eval);
     launch_encode_nhwc(e->stream, d_states, nb, e->g.n, e->net->planes_nhwc.as<float>(), e->net->cin_pad);
     TG_HIP(hipGetLastError());
     return net_forward_impl(e, nb, e->net->planes_nhwc.as<float>(), nullptr, d_policy, d_eval);
@@ -270,10 +333,15 @@ static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const ui
         chain = &n->ev_chains.back();
         n->conv_rows = M;
         // algorithmic FLOPs of one timed launch: one F→F conv (per-layer path) or the whole tower (fused)
-        n->conv_flops = n->fused ? 2ll * M * 9 * ((long long)n->cin * F + 2ll * n->R * F * F) : 2ll * M * 9 * F * F;
+        n->conv_flops = (n->fused || n->s3) ? 2ll * M * 9 * ((long long)n->cin * F + 2ll * n->R * F * F) : 2ll * M * 9 * F * F;
         chain->push_back(prof_event(n, st));
     }
-    if (n->fused) {
+    if (n->s3) {
+        if (chain) chain->push_back(prof_event(n, st));
+        if (d_states) TG_HIP(launch_tower_s3_states(st, d_states, n->tower_s3, x, nb, N));
+        else TG_HIP(launch_tower_s3(st, d_planes, n->tower_s3, x, nb, N));
+        if (chain) chain->push_back(prof_event(n, st));
+    } else if (n->fused) {
         if (chain) chain->push_back(prof_event(n, st));
         if (d_states) TG_HIP(launch_tower_states(st, d_states, n->tower, x, nb, N));
         else TG_HIP(launch_tower(st, d_planes, n->tower, x, nb, N));
@@ -335,6 +403,13 @@ extern "C" {
 
 int tg_net_set_tensor(TgEngine* e, const char* name, const float* data, size_t count) { return net_set_tensor(e, name, data, count); }
 int tg_net_finalize(TgEngine* e) { return net_finalize(e); }
+int tg_net_set_precision(TgEngine* e, int precision) {
+    if (!e || !e->net) return fail(TG_ERR_STATE, "engine has no network (evaluator is not TG_EVAL_RESNET)");
+    if (precision != TG_PRECISION_F32 && precision != TG_PRECISION_BF16X3) return fail(TG_ERR_INVALID_ARG, "unknown precision");
+    e->net->precision = precision;
+    e->net->ready = false;  // takes effect at the next tg_net_finalize
+    return TG_OK;
+}
 int tg_profile_enable(TgEngine* e, int sample_every) { return net_profile_enable(e, sample_every); }
 int tg_profile_read(TgEngine* e, TgProfile* out) { return net_profile_read(e, out); }
 

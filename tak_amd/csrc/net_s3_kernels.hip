@@ -1,0 +1,277 @@
+// net_s3_kernels.hip — the residual tower on the bf16 matrix cores with split operands ("bf16x3").
+//
+// Every f32 value x is carried as two bf16 numbers, hi = bf16(x) and lo = bf16(x − hi) (16 mantissa bits together),
+// and a product a·w is evaluated as a_hi·w_hi + a_lo·w_hi + a_hi·w_lo by three v_mfma_f32_16x16x32_bf16 into an f32
+// accumulator (bf16×bf16 products are exact in f32; only the a_lo·w_lo term, ≈ 2⁻¹⁶ relative, is dropped).  The bf16
+// pipe runs 16× the f32 MFMA rate per MAC, so three passes cost 3/16 of the exact-f32 tower.  Deviation from the f32
+// forward on the BASELINE networks: policy ≤ 1e-8 absolute / 1e-5 relative, eval ≤ 3e-6 (tests/test_gpu_net.py) —
+// well inside the 1e-4 of BASELINE.json's north_star; plain bf16 (one pass) would miss it by 10×.
+// This is the throughput variant of SURVEY.md §7 step 5; the exact-f32 tower (net_kernels.hip) stays the default.
+//
+// Structure = k_tower: a workgroup keeps PW whole positions in LDS for all 1+2R layers, one launch.  LDS row of a
+// board square: per 8 channels 16 B of hi then 16 B of lo (so the row has the byte size of the f32 row, +16 B pad);
+// an MFMA B operand (32 k × 16 rows) is two ds_read_b128 per lane (its row, channels 8q..8q+7 of the chunk), the A
+// operand (16 output channels × 32 k) two 16-B global loads of the pre-split weights [chunk][cout][q][hi|lo].
+// A wave owns CTW = 2 channel tiles × RTW row tiles, so every activation fragment feeds 6 MFMAs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "board.cuh"
+#include "conv_mainloop.cuh"
+#include "kernels.h"
+
+namespace tg {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {  // (bf16(a), bf16(b)), round to nearest even
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float bf16_lo_f32(uint32_t pk) { return __uint_as_float(pk << 16); }
+__device__ __forceinline__ float bf16_hi_f32(uint32_t pk) { return __uint_as_float(pk & 0xffff0000u); }
+
+// 4 floats → their hi and lo halves, packed as 4 bf16 each
+__device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& lo) {
+    hi[0] = pk_bf16(v[0], v[1]);
+    hi[1] = pk_bf16(v[2], v[3]);
+    lo[0] = pk_bf16(v[0] - bf16_lo_f32(hi[0]), v[1] - bf16_hi_f32(hi[0]));
+    lo[1] = pk_bf16(v[2] - bf16_lo_f32(hi[1]), v[3] - bf16_hi_f32(hi[1]));
+}
+__device__ __forceinline__ f32x4 join4(const u32x2& hi, const u32x2& lo) {
+    f32x4 v;
+    v[0] = bf16_lo_f32(hi[0]) + bf16_lo_f32(lo[0]);
+    v[1] = bf16_hi_f32(hi[0]) + bf16_hi_f32(lo[0]);
+    v[2] = bf16_lo_f32(hi[1]) + bf16_lo_f32(lo[1]);
+    v[3] = bf16_hi_f32(hi[1]) + bf16_hi_f32(lo[1]);
+    return v;
+}
+
+__device__ __forceinline__ bf16x8 as_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+
+// One layer for NT row tiles × 2 channel tiles.  lds4: image in 16-byte slots, row pitch LS4, chunk kc of a row at
+// slot kc·8 + 2q (hi) and +1 (lo).  wp: this lane's weight slot pair of chunk 0 (channel tile 0), tile 1 at +t1,
+// next chunk at +wstride (all in 16-byte units).
+template <int NT, int KC>
+__device__ __forceinline__ void s3_mainloop(const u32x4* __restrict__ lds4, const u32x4* __restrict__ wp, int t1, int wstride, int LS4,
+                                            int rows, int n, int rho0, int q, const int* vmask, f32x4 (&acc)[NT][2]) {
+    const int zero4 = rows * LS4 + 2 * q;
+    const int base0 = rho0 * LS4 + 2 * q;
+    u32x4 wh0 = wp[0], wl0 = wp[1], wh1 = wp[t1], wl1 = wp[t1 + 1];
+    int kk = 0;
+    constexpr int total = 9 * KC;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; tap++) {
+        const int sh = ((tap / 3 - 1) * n + (tap % 3 - 1)) * LS4;
+        int aoff[NT];
+#pragma unroll
+        for (int j = 0; j < NT; j++) aoff[j] = ((vmask[j] >> tap) & 1) ? base0 + j * 16 * LS4 + sh : zero4;
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) {
+            const int kn = kk + 1 < total ? kk + 1 : kk;
+            const u32x4* wn = wp + (size_t)kn * wstride;
+            const u32x4 nh0 = wn[0], nl0 = wn[1], nh1 = wn[t1], nl1 = wn[t1 + 1];
+            u32x4 ah[NT], al[NT];
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                ah[j] = lds4[aoff[j] + kc * 8];
+                al[j] = lds4[aoff[j] + kc * 8 + 1];
+            }
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wh0), as_bf(ah[j]), acc[j][0], 0, 0, 0);
+                acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wh1), as_bf(ah[j]), acc[j][1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wh0), as_bf(al[j]), acc[j][0], 0, 0, 0);
+                acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wh1), as_bf(al[j]), acc[j][1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wl0), as_bf(ah[j]), acc[j][0], 0, 0, 0);
+                acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wl1), as_bf(ah[j]), acc[j][1], 0, 0, 0);
+            }
+            wh0 = nh0; wl0 = nl0; wh1 = nh1; wl1 = nl1;
+            kk++;
+        }
+    }
+}
+
+// RTW: row tiles of a full row group; NRG row groups × NCG channel groups (of 2 tiles) = 8 waves.
+template <int RTW, int KC0, int KC, bool FROM_STATES>
+__global__ __launch_bounds__(512) void k_tower_s3(const void* __restrict__ in, TowerS3Params T, float* __restrict__ out, int B, int n,
+                                                  int PW, int NCG) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    u32x4* lds4 = (u32x4*)lds;
+    const int tid = threadIdx.x;
+    const int nsq = n * n;
+    const int pos0 = blockIdx.x * PW;
+    const int npos = min(PW, B - pos0);
+    const int rows = npos * nsq;
+    const int F = T.F;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int cg = wave % NCG, rg = wave / NCG;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int ch0 = cg * 32;
+
+    // ---- stage the input: CP0 = 32·KC0 channels per row, hi/lo split ----
+    constexpr int CP0 = 32 * KC0;
+    int LS4 = (CP0 >> 2) + 1;
+    if (FROM_STATES) {
+        const Geom geo = make_geom(n);
+        const uint8_t* states = (const uint8_t*)in;
+        const int C = input_channels(n);
+        for (int p = wave; p < npos; p += 8) {  // one wave encodes one position at a time, lane = square
+            WState ws;
+            ws_load(ws, states + (size_t)(pos0 + p) * geo.bytes, geo);
+            const float fcd = fcd_value(ws, geo);
+            const RowMask m = ws_row_mask(ws, geo);
+            if (lane < nsq) {
+                u32x4* row = lds4 + (size_t)(p * nsq + lane) * LS4;
+                for (int g8 = 0; g8 < (CP0 >> 3); g8++) {
+                    float4 a = row_mask_value(m, 2 * g8, C, fcd), b = row_mask_value(m, 2 * g8 + 1, C, fcd);
+                    u32x2 h0, l0, h1, l1;
+                    split4(f32x4{a.x, a.y, a.z, a.w}, h0, l0);
+                    split4(f32x4{b.x, b.y, b.z, b.w}, h1, l1);
+                    row[2 * g8] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+                    row[2 * g8 + 1] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+                }
+            }
+        }
+    } else {
+        const float* planes = (const float*)in;  // NHWC f32 rows of T.cin_pad channels
+        const int cin = T.cin_pad;
+        const int groups = CP0 >> 3;
+        for (int idx = tid; idx < rows * groups; idx += 512) {
+            int r = idx / groups, g8 = idx - r * groups;
+            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = a;
+            const float* src = planes + ((size_t)pos0 * nsq + r) * cin + 8 * g8;
+            if (8 * g8 < cin) a = *(const f32x4*)src;
+            if (8 * g8 + 4 < cin) b = *(const f32x4*)(src + 4);
+            u32x2 h0, l0, h1, l1;
+            split4(a, h0, l0);
+            split4(b, h1, l1);
+            lds4[r * LS4 + 2 * g8] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+            lds4[r * LS4 + 2 * g8 + 1] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+        }
+    }
+    for (int idx = tid; idx < LS4; idx += 512) lds4[rows * LS4 + idx] = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+
+    const int rho0 = rg * RTW * 16 + r16;
+    int vmask[RTW];
+    conv_tap_masks<RTW>(rows, n, nsq, rho0, vmask);
+    const bool short_group = (rg * RTW + RTW - 1) * 16 >= rows && RTW > 1;
+
+    f32x4 acc[RTW][2];
+#pragma unroll
+    for (int j = 0; j < RTW; j++) acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int layer = 0; layer < T.nlayers; layer++) {
+        // this lane's weight slots: [chunk][cout][q][hi|lo] in 16-byte units → ((chunk·F + cout)·4 + q)·2
+        const u32x4* wp = (const u32x4*)T.w[layer] + ((size_t)(ch0 + r16) * 4 + q) * 2;
+        const int t1 = 16 * 4 * 2, wstride = F * 4 * 2;
+        if (short_group) {
+            f32x4 (&acs)[RTW - 1][2] = *reinterpret_cast<f32x4 (*)[RTW - 1][2]>(&acc[0][0]);
+            if (layer == 0) s3_mainloop<RTW - 1, KC0>(lds4, wp, t1, wstride, LS4, rows, n, rho0, q, vmask, acs);
+            else s3_mainloop<RTW - 1, KC>(lds4, wp, t1, wstride, LS4, rows, n, rho0, q, vmask, acs);
+        } else {
+            if (layer == 0) s3_mainloop<RTW, KC0>(lds4, wp, t1, wstride, LS4, rows, n, rho0, q, vmask, acc);
+            else s3_mainloop<RTW, KC>(lds4, wp, t1, wstride, LS4, rows, n, rho0, q, vmask, acc);
+        }
+        // ---- epilogue: lane holds out[row rho0 + 16j][ch0 + 16t + 4q .. +3] ----
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const f32x4 bv = *(const f32x4*)&T.b[layer][ch0 + 16 * t + 4 * q];
+#pragma unroll
+            for (int j = 0; j < RTW; j++) {
+                f32x4 v = acc[j][t] + bv;
+                v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f);
+                acc[j][t] = v;
+            }
+        }
+        if (layer + 1 == T.nlayers) {
+#pragma unroll
+            for (int j = 0; j < RTW; j++)
+                if (rho0 + j * 16 < rows) {
+                    float* o = out + ((size_t)pos0 * nsq + rho0 + j * 16) * F + ch0 + 4 * q;
+                    *(f32x4*)o = acc[j][0];
+                    *(f32x4*)(o + 16) = acc[j][1];
+                }
+            break;
+        }
+        __syncthreads();  // every wave has finished reading the previous image
+        const int LS4n = (F >> 2) + 1;
+        const bool conv1 = (layer & 1) == 1;  // next layer is conv2 of the same block: it starts from the block input
+        // 8-byte slot of (row, channel c = ch0 + 16t + 4q): chunk c>>5, group (c&31)>>3, half (c&7)>>2
+        f32x4 nxt[RTW][2];
+#pragma unroll
+        for (int j = 0; j < RTW; j++)
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                nxt[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (conv1 && rho0 + j * 16 < rows) {
+                    const int c = ch0 + 16 * t + 4 * q;
+                    const u32x2* p = (const u32x2*)(lds4 + (size_t)(rho0 + j * 16) * LS4n + (c >> 3) * 2) + ((c & 7) >> 2);
+                    nxt[j][t] = join4(p[0], p[2]);  // hi slot, lo slot (+16 B)
+                }
+            }
+        LS4 = LS4n;
+#pragma unroll
+        for (int j = 0; j < RTW; j++)
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+                if (rho0 + j * 16 < rows) {
+                    const int c = ch0 + 16 * t + 4 * q;
+                    u32x2 hi, lo;
+                    split4(acc[j][t], hi, lo);
+                    u32x2* p = (u32x2*)(lds4 + (size_t)(rho0 + j * 16) * LS4 + (c >> 3) * 2) + ((c & 7) >> 2);
+                    p[0] = hi;
+                    p[2] = lo;
+                }
+        if (layer == 0)
+            for (int idx = tid; idx < LS4; idx += 512) lds4[rows * LS4 + idx] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < RTW; j++) { acc[j][0] = nxt[j][0]; acc[j][1] = nxt[j][1]; }
+        __syncthreads();
+    }
+}
+
+template <int RTW, int KC0, int KC, bool FROM_STATES>
+static hipError_t launch_s3_t(hipStream_t st, const void* in, const TowerS3Params& T, float* out, int B, int n, int PW, int NCG) {
+    int cmax = 32 * KC0 > T.F ? 32 * KC0 : T.F;
+    size_t lds = (size_t)(PW * n * n + 1) * (cmax + 4) * sizeof(float);
+    static size_t configured = 0;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_tower_s3<RTW, KC0, KC, FROM_STATES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    hipLaunchKernelGGL((k_tower_s3<RTW, KC0, KC, FROM_STATES>), dim3((B + PW - 1) / PW), dim3(512), lds, st, in, T, out, B, n, PW, NCG);
+    return hipGetLastError();
+}
+
+bool tower_s3_supported(int n, int F) { return (n == 5 && (F == 64 || F == 128)) || (n == 6 && F == 128); }
+
+template <bool FROM_STATES>
+static hipError_t launch_s3(hipStream_t st, const void* in, const TowerS3Params& T, float* out, int B, int n) {
+    // 5×5, F = 64: 16 positions = 25 row tiles = 4 row groups (7,6,6,6) × 2 channel groups
+    if (n == 5 && T.F == 64) return launch_s3_t<7, 3, 2, FROM_STATES>(st, in, T, out, B, n, 16, 2);
+    // 5×5, F = 128: 8 positions = 13 row tiles = 2 row groups (7,6) × 4 channel groups
+    if (n == 5 && T.F == 128) return launch_s3_t<7, 3, 4, FROM_STATES>(st, in, T, out, B, n, 8, 4);
+    // 6×6, F = 128: 4 positions = 9 row tiles = 2 row groups (5,4) × 4 channel groups
+    if (n == 6 && T.F == 128) return launch_s3_t<5, 3, 4, FROM_STATES>(st, in, T, out, B, n, 4, 4);
+    return hipErrorInvalidValue;
+}
+hipError_t launch_tower_s3(hipStream_t st, const float* planes, const TowerS3Params& T, float* out, int B, int n) {
+    return launch_s3<false>(st, planes, T, out, B, n);
+}
+hipError_t launch_tower_s3_states(hipStream_t st, const uint8_t* states, const TowerS3Params& T, float* out, int B, int n) {
+    return launch_s3<true>(st, states, T, out, B, n);
+}
+
+}  // namespace tg

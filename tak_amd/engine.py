@@ -81,7 +81,7 @@ class TgPitResult(C.Structure):
 ABI_SYMBOLS = [
     "tg_state_bytes", "tg_engine_create", "tg_engine_destroy", "tg_last_error", "tg_sync", "tg_stream",
     "tg_input_channels", "tg_policy_size", "tg_movegen", "tg_play", "tg_result", "tg_encode", "tg_move_index",
-    "tg_perft", "tg_net_set_tensor", "tg_net_finalize", "tg_policy_eval", "tg_forward_mcts", "tg_policy_eval_dev",
+    "tg_perft", "tg_net_set_tensor", "tg_net_finalize", "tg_net_set_precision", "tg_policy_eval", "tg_forward_mcts", "tg_policy_eval_dev",
     "tg_search_create", "tg_search_reset", "tg_search_run", "tg_search_apply_dirichlet", "tg_search_apply_noise",
     "tg_search_root", "tg_search_play", "tg_search_states", "tg_search_dump", "tg_search_counters",
     "tg_selfplay_create", "tg_selfplay_step", "tg_selfplay_stats", "tg_selfplay_drain",
@@ -373,6 +373,10 @@ class Engine:
     def set_tensor(self, name, array):
         a = np.ascontiguousarray(array, np.float32)
         self._check(self.lib.tg_net_set_tensor(self.h, name.encode(), _p(a), C.c_size_t(a.size)))
+
+    def set_precision(self, precision):
+        """"f32" (exact, default) or "bf16x3" (split-bf16 tower); takes effect at the next load_state_dict / finalize"""
+        self._check(self.lib.tg_net_set_precision(self.h, {"f32": 0, "bf16x3": 1}[precision]))
 
     def load_state_dict(self, tensors):
         """tensors: {name: array} with the names of include/takgpu.h (tch layouts)."""

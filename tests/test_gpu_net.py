@@ -65,6 +65,39 @@ def test_config_topologies_vs_torch(orc, n, blocks, filters, head, batch):
     e.close()
 
 
+@pytest.mark.parametrize("n,blocks,filters,head,batch", [
+    (5, 6, 64, "fc5", 300),     # C2
+    (6, 10, 128, "conv", 70),   # C3
+    (5, 10, 128, "fc5", 77),    # C5 network
+])
+def test_bf16x3_tower_within_tolerance(orc, n, blocks, filters, head, batch):
+    """The split-bf16 tower (TG_PRECISION_BF16X3): same 1e-4 gate as the exact path, and its measured deviation."""
+    net = torch_ref.make_net(n, blocks, filters, head, seed=n * 100 + blocks)
+    sts = orc.random_positions(n, batch, seed=5, max_plies=80, half_komi=4)
+    p_ref, v_ref = torch_ref.forward(net, orc.encode(n, sts))
+    e = _engine(n, blocks, filters, head, max_batch=128)
+    e.set_precision("bf16x3")
+    e.load_state_dict(torch_ref.abi_tensors(net))
+    p, v = e.policy_eval(sts)
+    assert np.abs(p - p_ref).max() <= TOL and np.abs(v - v_ref).max() <= TOL
+    # observed: ≈ 1e-5 relative on the policy, a few 1e-6 on the eval (16 mantissa bits per operand)
+    assert (np.abs(p - p_ref) / p_ref).max() < 1e-4, (np.abs(p - p_ref) / p_ref).max()
+    assert np.abs(v - v_ref).max() < 2e-5, np.abs(v - v_ref).max()
+    # batch independence and the planes entry point
+    p1, v1 = e.policy_eval(sts[3:4])
+    assert np.array_equal(p1[0], p[3]) and v1[0] == v[3]
+    p2, v2 = e.forward_mcts(orc.encode(n, sts))
+    assert np.array_equal(p, p2) and np.array_equal(v, v2)
+    # back to the exact path on the same engine
+    e.set_precision("f32")
+    e.load_state_dict(torch_ref.abi_tensors(net))
+    pf, vf = e.policy_eval(sts)
+    assert np.abs(pf - p_ref).max() <= TOL and not np.array_equal(pf, p)
+    print(f"bf16x3 vs torch: policy rel {(np.abs(p - p_ref) / p_ref).max():.2e}, eval abs {np.abs(v - v_ref).max():.2e}; "
+          f"f32: policy rel {(np.abs(pf - p_ref) / p_ref).max():.2e}, eval abs {np.abs(vf - v_ref).max():.2e}")
+    e.close()
+
+
 def test_weight_errors():
     import tak_amd
 

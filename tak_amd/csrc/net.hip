@@ -36,6 +36,8 @@ struct Net {
     bool s3 = false;                   // split-bf16 tower in use
     TowerS3Params tower_s3;
     std::vector<DevBuf> s3_w;
+    DevBuf s3_fc;          // policy FC weights, split
+    bool s3_fc_on = false; // FC head on the split path (tower writes split activations)
     // measurement hooks (tg_profile_*)
     int prof_every = 0;
     uint64_t prof_counter = 0;
@@ -284,6 +286,29 @@ int net_finalize(TgEngine* e) {
             T.w[2 + 2 * i] = n->s3_w[2 + 2 * i].p; T.b[2 + 2 * i] = n->res2[i].b.as<float>();
         }
         n->s3 = true;
+        n->s3_fc_on = false;
+        if (e->cfg.policy_head == TG_HEAD_FC5 && fc_s3_supported(F * nsq, n->policy_np)) {
+            // Linear [P, F·nsq] → split bf16 fragments, k = sq·F + c (the order of the activations)
+            const size_t K = (size_t)F * nsq;
+            const int NP = n->policy_np;
+            auto w = find(n, "policy.weight", (size_t)P * K, err);
+            if (!w) return fail(TG_ERR_WEIGHTS, err);
+            std::vector<uint16_t> ws((size_t)(K / 32) * NP * 64, 0);
+            for (int o = 0; o < P; o++)
+                for (size_t k = 0; k < K; k++) {
+                    int sq = (int)(k / F), c = (int)(k % F);
+                    float v = (*w)[(size_t)o * K + (size_t)c * nsq + sq];
+                    uint16_t hi = f32_to_bf16(v), lo = f32_to_bf16(v - bf16_to_f32(hi));
+                    // [chunk][column block of 208][q][hi|lo][column][8 bf16]: the LDS plane layout of k_fc_s3
+                    const size_t cb = (size_t)o / 208, col = (size_t)o % 208, q = (k & 31) >> 3;
+                    size_t slot = ((((k >> 5) * (size_t)(NP / 208) + cb) * 4 + q) * 2) * 208 + col;
+                    ws[slot * 8 + (k & 7)] = hi;
+                    ws[(slot + 208) * 8 + (k & 7)] = lo;
+                }
+            TG_HIP(n->s3_fc.ensure(ws.size() * 2));
+            TG_HIP(hipMemcpy(n->s3_fc.p, ws.data(), ws.size() * 2, hipMemcpyHostToDevice));
+            n->s3_fc_on = true;
+        }
     }
     size_t mb = (size_t)e->cfg.max_batch;
     TG_HIP(n->x.ensure(mb * nsq * F * 4));
@@ -338,8 +363,8 @@ static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const ui
     }
     if (n->s3) {
         if (chain) chain->push_back(prof_event(n, st));
-        if (d_states) TG_HIP(launch_tower_s3_states(st, d_states, n->tower_s3, x, nb, N));
-        else TG_HIP(launch_tower_s3(st, d_planes, n->tower_s3, x, nb, N));
+        if (d_states) TG_HIP(launch_tower_s3_states(st, d_states, n->tower_s3, x, nb, N, n->s3_fc_on));
+        else TG_HIP(launch_tower_s3(st, d_planes, n->tower_s3, x, nb, N, n->s3_fc_on));
         if (chain) chain->push_back(prof_event(n, st));
     } else if (n->fused) {
         if (chain) chain->push_back(prof_event(n, st));
@@ -364,12 +389,16 @@ static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const ui
         const ConvLayer& L = n->policy_conv;
         TG_HIP(launch_conv3x3(st, x, L.w.as<float>(), L.b.as<float>(), nullptr, logits, M, N, F, L.cout_pad, L.cout_pad, L.cout, false));
         TG_HIP(launch_softmax(st, logits, nsq * L.cout_pad, true, nsq, L.cout_pad, e->policy_size, nb, d_policy));
+    } else if (n->s3 && n->s3_fc_on) {
+        TG_HIP(launch_fc_s3(st, x, n->s3_fc.p, n->policy_b.as<float>(), logits, nb, nsq * F, n->policy_np, n->policy_np, e->policy_size));
+        TG_HIP(launch_softmax(st, logits, n->policy_np, false, nsq, 0, e->policy_size, nb, d_policy));
     } else {
         TG_HIP(launch_gemm(st, x, nsq * F, n->policy_w.as<float>(), n->policy_b.as<float>(), logits, nb, nsq * F, n->policy_np,
                            n->policy_np, e->policy_size));
         TG_HIP(launch_softmax(st, logits, n->policy_np, false, nsq, 0, e->policy_size, nb, d_policy));
     }
-    TG_HIP(launch_value_head(st, x, n->value_w.as<float>(), n->value_b, nb, nsq * F, d_eval));
+    if (n->s3 && n->s3_fc_on) TG_HIP(launch_value_head_s3(st, x, n->value_w.as<float>(), n->value_b, nb, nsq * F, d_eval));
+    else TG_HIP(launch_value_head(st, x, n->value_w.as<float>(), n->value_b, nb, nsq * F, d_eval));
     if (chain) chain->push_back(prof_event(n, st));
     return TG_OK;
 }

@@ -102,7 +102,7 @@ __device__ __forceinline__ void s3_mainloop(const u32x4* __restrict__ lds4, cons
 }
 
 // RTW: row tiles of a full row group; NRG row groups × NCG channel groups (of 2 tiles) = 8 waves.
-template <int RTW, int KC0, int KC, bool FROM_STATES>
+template <int RTW, int KC0, int KC, bool FROM_STATES, bool OUT_SPLIT>
 __global__ __launch_bounds__(512) void k_tower_s3(const void* __restrict__ in, TowerS3Params T, float* __restrict__ out, int B, int n,
                                                   int PW, int NCG) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(512) void k_tower_s3(const void* __restrict__ in, T
                 acc[j][t] = v;
             }
         }
-        if (layer + 1 == T.nlayers) {
+        if (layer + 1 == T.nlayers && !OUT_SPLIT) {
 #pragma unroll
             for (int j = 0; j < RTW; j++)
                 if (rho0 + j * 16 < rows) {
@@ -238,40 +238,206 @@ __global__ __launch_bounds__(512) void k_tower_s3(const void* __restrict__ in, T
 #pragma unroll
         for (int j = 0; j < RTW; j++) { acc[j][0] = nxt[j][0]; acc[j][1] = nxt[j][1]; }
         __syncthreads();
+        if (OUT_SPLIT && layer + 1 == T.nlayers) {
+            // the image now holds the final activations in the split row layout k_fc_s3 reads: copy it out, 16 B per lane
+            const int spr = F >> 2;  // slots per row without the pad
+            u32x4* o = (u32x4*)out + (size_t)pos0 * nsq * spr;
+            for (int idx = tid; idx < rows * spr; idx += 512) {
+                int r = idx / spr, v = idx - r * spr;
+                o[idx] = lds4[r * LS4 + v];
+            }
+            break;
+        }
     }
 }
 
-template <int RTW, int KC0, int KC, bool FROM_STATES>
+// ------------------------------------------------------------------------------------------------
+// Policy FC (net5.rs:56-61,108) on split operands: logits[M][N] = S[M][K]·W[K][N] + b with S in the split row
+// layout the tower writes.  Workgroup = 128 positions × 208 outputs (13 tiles), 8 waves = 4 position pairs × 2
+// output halves (7 + 6 tiles): a wave's weight fragment (LDS) feeds 2 position tiles × 3 MFMAs.  Weights are staged
+// global → LDS per K-step of 64, double buffered, in planes [chunk][q][hi|lo][208] of 16-byte slots (a quarter-wave
+// reads 16 consecutive slots: conflict free); the activations are the MFMA B operand straight from global.
+// ------------------------------------------------------------------------------------------------
+constexpr int FS_CT = 13;
+constexpr int FS_COLS = FS_CT * 16;               // 208
+constexpr int FS_SLOTS = 2 * 4 * 2 * FS_COLS;     // 3328 slots per K-step of 64
+
+__global__ __launch_bounds__(512) void k_fc_s3(const u32x4* __restrict__ A, const u32x4* __restrict__ Wp, const float* __restrict__ bias,
+                                               float* __restrict__ out, int M, int K, int NP, int out_stride, int n_valid) {
+    __shared__ u32x4 wl[2][FS_SLOTS];  // 106.5 KB
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int pp = wave & 3, oh = wave >> 2;
+    const int t0 = oh * 7, NT = oh ? 6 : 7;
+    const int n0 = blockIdx.y * FS_COLS;
+    const int rpitch = K >> 2;  // slots per activation row
+    int row[2];
+    bool row_ok[2];
+    const u32x4* ap[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        row[p] = blockIdx.x * 128 + pp * 32 + p * 16 + r16;
+        row_ok[p] = row[p] < M;
+        ap[p] = A + (size_t)(row_ok[p] ? row[p] : 0) * rpitch + 2 * q;
+    }
+    const int nsteps = K / 64;
+    // staging: the global layout [chunk][column block][q][hi|lo][208] is the LDS plane layout, so both the global read
+    // and the LDS write of a K-step are linear in the thread index (coalesced, bank-conflict free)
+    const int ncb = NP / FS_COLS;
+    auto stage_load = [&](int step, u32x4 (&r)[7]) {
+#pragma unroll
+        for (int u = 0; u < 7; u++) {
+            int idx = u * 512 + tid;
+            if (idx < FS_SLOTS) {
+                int c = idx / (FS_COLS * 8), rem = idx - c * (FS_COLS * 8);
+                r[u] = Wp[((size_t)(step * 2 + c) * ncb + blockIdx.y) * (FS_COLS * 8) + rem];
+            }
+        }
+    };
+    auto stage_store = [&](int buf, const u32x4 (&r)[7]) {
+#pragma unroll
+        for (int u = 0; u < 7; u++) {
+            int idx = u * 512 + tid;
+            if (idx < FS_SLOTS) wl[buf][idx] = r[u];
+        }
+    };
+    f32x4 acc[2][7];
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int j = 0; j < 7; j++) acc[p][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 stg[7];
+    stage_load(0, stg);
+    stage_store(0, stg);
+    const u32x4 zero = u32x4{0u, 0u, 0u, 0u};
+    // the activation fragments of a whole K-step (2 chunks × 2 position tiles × hi/lo) are loaded one step ahead:
+    // 84 MFMAs (≥ 1300 cycles) cover an Infinity-Cache / HBM round trip
+    u32x4 ac[2][2][2], an[2][2][2];  // [chunk][position tile][hi, lo]
+    auto load_a = [&](int step, u32x4 (&a)[2][2][2]) {
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                a[c][p][0] = row_ok[p] ? ap[p][(step * 2 + c) * 8] : zero;
+                a[c][p][1] = row_ok[p] ? ap[p][(step * 2 + c) * 8 + 1] : zero;
+            }
+    };
+    load_a(0, ac);
+    __syncthreads();
+    for (int step = 0; step < nsteps; step++) {
+        const int buf = step & 1;
+        if (step + 1 < nsteps) {
+            stage_load(step + 1, stg);
+            load_a(step + 1, an);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const u32x4* wh = &wl[buf][((c * 4 + q) * 2 + 0) * FS_COLS + t0 * 16 + r16];
+            const u32x4* wo = &wl[buf][((c * 4 + q) * 2 + 1) * FS_COLS + t0 * 16 + r16];
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                if (j < NT) {
+                    const u32x4 w_h = wh[j * 16], w_l = wo[j * 16];
+#pragma unroll
+                    for (int p = 0; p < 2; p++) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w_h), as_bf(ac[c][p][0]), acc[p][j], 0, 0, 0);
+#pragma unroll
+                    for (int p = 0; p < 2; p++) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w_h), as_bf(ac[c][p][1]), acc[p][j], 0, 0, 0);
+#pragma unroll
+                    for (int p = 0; p < 2; p++) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w_l), as_bf(ac[c][p][0]), acc[p][j], 0, 0, 0);
+                }
+            }
+        }
+        if (step + 1 < nsteps) {
+            stage_store(buf ^ 1, stg);
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int p = 0; p < 2; p++) { ac[c][p][0] = an[c][p][0]; ac[c][p][1] = an[c][p][1]; }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+        if (row_ok[p]) {
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                const int nn = n0 + (t0 + j) * 16 + 4 * q;
+                if (j < NT && nn < n_valid) {
+                    f32x4 v = acc[p][j] + *(const f32x4*)&bias[nn];
+                    float* o = out + (size_t)row[p] * out_stride + nn;
+                    if (nn + 3 < n_valid) *(f32x4*)o = v;
+                    else for (int t = 0; t < 4; t++) if (nn + t < n_valid) o[t] = v[t];
+                }
+            }
+        }
+}
+
+// value head on the split activations: Linear(F·N² → 1) + tanh; wv in NHWC order (f32)
+__global__ __launch_bounds__(256) void k_value_head_s3(const u32x4* __restrict__ act, const float* __restrict__ wv, float bv, int B, int len,
+                                                       float* __restrict__ eval) {
+    int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    int lane = threadIdx.x & 63;
+    const u32x4* a = act + (size_t)b * (len >> 2);
+    const f32x4* w = (const f32x4*)wv;
+    float s = 0.0f;
+    for (int g = lane; g < (len >> 3); g += 64) {
+        const u32x4 hi = a[2 * g], lo = a[2 * g + 1];
+        const f32x4 w0 = w[2 * g], w1 = w[2 * g + 1];
+        const f32x4 x0 = join4(u32x2{hi[0], hi[1]}, u32x2{lo[0], lo[1]}), x1 = join4(u32x2{hi[2], hi[3]}, u32x2{lo[2], lo[3]});
+#pragma unroll
+        for (int t = 0; t < 4; t++) s = fmaf(x0[t], w0[t], s);
+#pragma unroll
+        for (int t = 0; t < 4; t++) s = fmaf(x1[t], w1[t], s);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) eval[b] = tanhf(s + bv);
+}
+
+template <int RTW, int KC0, int KC, bool FROM_STATES, bool OUT_SPLIT>
 static hipError_t launch_s3_t(hipStream_t st, const void* in, const TowerS3Params& T, float* out, int B, int n, int PW, int NCG) {
     int cmax = 32 * KC0 > T.F ? 32 * KC0 : T.F;
     size_t lds = (size_t)(PW * n * n + 1) * (cmax + 4) * sizeof(float);
     static size_t configured = 0;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_tower_s3<RTW, KC0, KC, FROM_STATES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_tower_s3<RTW, KC0, KC, FROM_STATES, OUT_SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    hipLaunchKernelGGL((k_tower_s3<RTW, KC0, KC, FROM_STATES>), dim3((B + PW - 1) / PW), dim3(512), lds, st, in, T, out, B, n, PW, NCG);
+    hipLaunchKernelGGL((k_tower_s3<RTW, KC0, KC, FROM_STATES, OUT_SPLIT>), dim3((B + PW - 1) / PW), dim3(512), lds, st, in, T, out, B, n, PW, NCG);
     return hipGetLastError();
 }
 
 bool tower_s3_supported(int n, int F) { return (n == 5 && (F == 64 || F == 128)) || (n == 6 && F == 128); }
 
-template <bool FROM_STATES>
+template <bool FROM_STATES, bool OUT_SPLIT>
 static hipError_t launch_s3(hipStream_t st, const void* in, const TowerS3Params& T, float* out, int B, int n) {
     // 5×5, F = 64: 16 positions = 25 row tiles = 4 row groups (7,6,6,6) × 2 channel groups
-    if (n == 5 && T.F == 64) return launch_s3_t<7, 3, 2, FROM_STATES>(st, in, T, out, B, n, 16, 2);
+    if (n == 5 && T.F == 64) return launch_s3_t<7, 3, 2, FROM_STATES, OUT_SPLIT>(st, in, T, out, B, n, 16, 2);
     // 5×5, F = 128: 8 positions = 13 row tiles = 2 row groups (7,6) × 4 channel groups
-    if (n == 5 && T.F == 128) return launch_s3_t<7, 3, 4, FROM_STATES>(st, in, T, out, B, n, 8, 4);
+    if (n == 5 && T.F == 128) return launch_s3_t<7, 3, 4, FROM_STATES, OUT_SPLIT>(st, in, T, out, B, n, 8, 4);
     // 6×6, F = 128: 4 positions = 9 row tiles = 2 row groups (5,4) × 4 channel groups
-    if (n == 6 && T.F == 128) return launch_s3_t<5, 3, 4, FROM_STATES>(st, in, T, out, B, n, 4, 4);
+    if (n == 6 && T.F == 128) return launch_s3_t<5, 3, 4, FROM_STATES, OUT_SPLIT>(st, in, T, out, B, n, 4, 4);
     return hipErrorInvalidValue;
 }
-hipError_t launch_tower_s3(hipStream_t st, const float* planes, const TowerS3Params& T, float* out, int B, int n) {
-    return launch_s3<false>(st, planes, T, out, B, n);
+hipError_t launch_tower_s3(hipStream_t st, const float* planes, const TowerS3Params& T, float* out, int B, int n, bool out_split) {
+    return out_split ? launch_s3<false, true>(st, planes, T, out, B, n) : launch_s3<false, false>(st, planes, T, out, B, n);
 }
-hipError_t launch_tower_s3_states(hipStream_t st, const uint8_t* states, const TowerS3Params& T, float* out, int B, int n) {
-    return launch_s3<true>(st, states, T, out, B, n);
+hipError_t launch_tower_s3_states(hipStream_t st, const uint8_t* states, const TowerS3Params& T, float* out, int B, int n, bool out_split) {
+    return out_split ? launch_s3<true, true>(st, states, T, out, B, n) : launch_s3<true, false>(st, states, T, out, B, n);
+}
+bool fc_s3_supported(int K, int NP) { return K % 64 == 0 && NP % FS_COLS == 0; }
+hipError_t launch_fc_s3(hipStream_t st, const float* act_split, const void* Wp, const float* bias, float* out, int M, int K, int NP,
+                        int out_stride, int n_valid) {
+    dim3 grid((M + 127) / 128, NP / FS_COLS);
+    hipLaunchKernelGGL(k_fc_s3, grid, dim3(512), 0, st, (const u32x4*)act_split, (const u32x4*)Wp, bias, out, M, K, NP, out_stride, n_valid);
+    return hipGetLastError();
+}
+hipError_t launch_value_head_s3(hipStream_t st, const float* act_split, const float* wv, float bv, int B, int len, float* eval) {
+    hipLaunchKernelGGL(k_value_head_s3, dim3((B + 3) / 4), dim3(256), 0, st, (const u32x4*)act_split, wv, bv, B, len, eval);
+    return hipGetLastError();
 }
 
 }  // namespace tg

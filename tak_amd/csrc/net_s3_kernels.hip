@@ -279,7 +279,7 @@ __global__ __launch_bounds__(512) void k_fc_s3(const u32x4* __restrict__ A, cons
     for (int p = 0; p < 2; p++) {
         row[p] = blockIdx.x * 128 + pp * 32 + p * 16 + r16;
         row_ok[p] = row[p] < M;
-        ap[p] = A + (size_t)(row_ok[p] ? row[p] : 0) * rpitch + 2 * q;
+        ap[p] = A + (size_t)(row_ok[p] ? row[p] : M - 1) * rpitch + 2 * q;  // rows past the end load a valid row; never stored
     }
     const int nsteps = K / 64;
     // staging: the global layout [chunk][column block][q][hi|lo][208] is the LDS plane layout, so both the global read
@@ -288,11 +288,12 @@ __global__ __launch_bounds__(512) void k_fc_s3(const u32x4* __restrict__ A, cons
     auto stage_load = [&](int step, u32x4 (&r)[7]) {
 #pragma unroll
         for (int u = 0; u < 7; u++) {
+            // every load is unconditional (a clamped index for the idle tail of the last round): exec-masked loads
+            // make hipcc fall back to s_waitcnt vmcnt(0) right behind them
             int idx = u * 512 + tid;
-            if (idx < FS_SLOTS) {
-                int c = idx / (FS_COLS * 8), rem = idx - c * (FS_COLS * 8);
-                r[u] = Wp[((size_t)(step * 2 + c) * ncb + blockIdx.y) * (FS_COLS * 8) + rem];
-            }
+            idx = idx < FS_SLOTS ? idx : FS_SLOTS - 1;
+            int c = idx / (FS_COLS * 8), rem = idx - c * (FS_COLS * 8);
+            r[u] = Wp[((size_t)(step * 2 + c) * ncb + blockIdx.y) * (FS_COLS * 8) + rem];
         }
     };
     auto stage_store = [&](int buf, const u32x4 (&r)[7]) {
@@ -310,7 +311,6 @@ __global__ __launch_bounds__(512) void k_fc_s3(const u32x4* __restrict__ A, cons
     u32x4 stg[7];
     stage_load(0, stg);
     stage_store(0, stg);
-    const u32x4 zero = u32x4{0u, 0u, 0u, 0u};
     // the activation fragments of a whole K-step (2 chunks × 2 position tiles × hi/lo) are loaded one step ahead:
     // 84 MFMAs (≥ 1300 cycles) cover an Infinity-Cache / HBM round trip
     u32x4 ac[2][2][2], an[2][2][2];  // [chunk][position tile][hi, lo]
@@ -319,42 +319,48 @@ __global__ __launch_bounds__(512) void k_fc_s3(const u32x4* __restrict__ A, cons
         for (int c = 0; c < 2; c++)
 #pragma unroll
             for (int p = 0; p < 2; p++) {
-                a[c][p][0] = row_ok[p] ? ap[p][(step * 2 + c) * 8] : zero;
-                a[c][p][1] = row_ok[p] ? ap[p][(step * 2 + c) * 8 + 1] : zero;
+                a[c][p][0] = ap[p][(step * 2 + c) * 8];
+                a[c][p][1] = ap[p][(step * 2 + c) * 8 + 1];
             }
     };
     load_a(0, ac);
     __syncthreads();
     for (int step = 0; step < nsteps; step++) {
         const int buf = step & 1;
-        if (step + 1 < nsteps) {
-            stage_load(step + 1, stg);
-            load_a(step + 1, an);
-        }
+        const int nx = step + 1 < nsteps ? step + 1 : step;  // the last step reloads itself (unused)
+        stage_load(nx, stg);
+        load_a(nx, an);
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             const u32x4* wh = &wl[buf][((c * 4 + q) * 2 + 0) * FS_COLS + t0 * 16 + r16];
             const u32x4* wo = &wl[buf][((c * 4 + q) * 2 + 1) * FS_COLS + t0 * 16 + r16];
+            // all weight fragments of the chunk are requested before the first MFMA (the tile-7 slot of the 6-tile waves
+            // reads a valid, unused address)
+            u32x4 w_h[7], w_l[7];
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                const int jj = j < NT ? j : 0;
+                w_h[j] = wh[jj * 16];
+                w_l[j] = wo[jj * 16];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 7; j++) {
                 if (j < NT) {
-                    const u32x4 w_h = wh[j * 16], w_l = wo[j * 16];
 #pragma unroll
-                    for (int p = 0; p < 2; p++) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w_h), as_bf(ac[c][p][0]), acc[p][j], 0, 0, 0);
+                    for (int p = 0; p < 2; p++) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w_h[j]), as_bf(ac[c][p][0]), acc[p][j], 0, 0, 0);
 #pragma unroll
-                    for (int p = 0; p < 2; p++) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w_h), as_bf(ac[c][p][1]), acc[p][j], 0, 0, 0);
+                    for (int p = 0; p < 2; p++) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w_h[j]), as_bf(ac[c][p][1]), acc[p][j], 0, 0, 0);
 #pragma unroll
-                    for (int p = 0; p < 2; p++) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w_l), as_bf(ac[c][p][0]), acc[p][j], 0, 0, 0);
+                    for (int p = 0; p < 2; p++) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w_l[j]), as_bf(ac[c][p][0]), acc[p][j], 0, 0, 0);
                 }
             }
         }
-        if (step + 1 < nsteps) {
-            stage_store(buf ^ 1, stg);
+        stage_store(buf ^ 1, stg);  // (after the last step: into the buffer nobody reads any more)
 #pragma unroll
-            for (int c = 0; c < 2; c++)
+        for (int c = 0; c < 2; c++)
 #pragma unroll
-                for (int p = 0; p < 2; p++) { ac[c][p][0] = an[c][p][0]; ac[c][p][1] = an[c][p][1]; }
-        }
+            for (int p = 0; p < 2; p++) { ac[c][p][0] = an[c][p][0]; ac[c][p][1] = an[c][p][1]; }
         __syncthreads();
     }
 #pragma unroll

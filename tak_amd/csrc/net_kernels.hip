@@ -158,7 +158,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_pos(const float* __restric
     f32x4* lds4 = (f32x4*)lds;  // every access below is a whole 16-byte slot → ds_read_b128 / ds_write_b128
     const int tid = threadIdx.x;
     const int nsq = n * n;
-    const int LS4 = (Cpad + LDS_PAD) >> 2;
+    const int LS4 = (Cpad + LDS_PAD16) >> 2;
     const int pos0 = blockIdx.x * PW;
     const int npos = min(PW, B - pos0);
     const int rows = npos * nsq;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
 
     // ---- stage the input planes (row pitch cin_pad + 4) ----
     int Cpad = T.cin_pad;
-    int LS4 = (Cpad + LDS_PAD) >> 2;
+    int LS4 = (Cpad + LDS_PAD16) >> 2;
     if (FROM_STATES) {
         const Geom geo = make_geom(n);
         const uint8_t* states = (const uint8_t*)in;
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
             break;
         }
         __syncthreads();  // every wave has finished reading the previous image
-        const int LS4n = (F + LDS_PAD) >> 2;
+        const int LS4n = (F + LDS_PAD16) >> 2;
         const bool conv1 = (layer & 1) == 1;  // next layer is conv2 of the same block: it starts from the block input
         f32x4 nxt[RTW];
 #pragma unroll
@@ -735,7 +735,7 @@ template <int RTW, int NWAVES>
 static hipError_t launch_conv_pos_t(hipStream_t st, const float* in, const float* Wp, const float* bias, const float* res,
                                     float* out, int B, int n, int Cpad, int CoutP, int out_stride, int cout_valid, bool relu,
                                     int PW, int CTW) {
-    size_t lds = (size_t)(PW * n * n + 1) * (Cpad + LDS_PAD) * sizeof(float);
+    size_t lds = (size_t)(PW * n * n + 1) * (Cpad + LDS_PAD16) * sizeof(float);
     static size_t configured = 0;
     if (lds > configured) {
         hipError_t e = hipFuncSetAttribute((const void*)k_conv_pos<RTW, NWAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -770,7 +770,7 @@ hipError_t launch_conv3x3(hipStream_t st, const float* in, const float* Wp, cons
 template <int RTW, int NWAVES, int CH0, int CH, bool FROM_STATES>
 static hipError_t launch_tower_t(hipStream_t st, const float* in, const TowerParams& T, float* out, int B, int n, int PW, int CTW) {
     int cmax = T.cin_pad > T.F ? T.cin_pad : T.F;
-    size_t lds = (size_t)(PW * n * n + 1) * (cmax + LDS_PAD) * sizeof(float);
+    size_t lds = (size_t)(PW * n * n + 1) * (cmax + LDS_PAD16) * sizeof(float);
     static size_t configured = 0;
     if (lds > configured) {
         hipError_t e = hipFuncSetAttribute((const void*)k_tower<RTW, NWAVES, CH0, CH, FROM_STATES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -20,6 +20,10 @@
 #include "conv_mainloop.cuh"
 #include "kernels.h"
 
+#ifndef S3_PROBE
+#define S3_PROBE 0  // scripts/probes/tower_s3_probe.hip builds variants with parts of the kernel removed
+#endif
+
 namespace tg {
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -73,13 +77,30 @@ __device__ __forceinline__ void s3_mainloop(const u32x4* __restrict__ lds4, cons
         for (int kc = 0; kc < KC; kc++) {
             const int kn = kk + 1 < total ? kk + 1 : kk;
             const u32x4* wn = wp + (size_t)kn * wstride;
+#if S3_PROBE == 2 || S3_PROBE == 5 || S3_PROBE == 6
+            const u32x4 nh0 = wh0, nl0 = wl0, nh1 = wh1, nl1 = wl1;
+            (void)wn;
+#else
             const u32x4 nh0 = wn[0], nl0 = wn[1], nh1 = wn[t1], nl1 = wn[t1 + 1];
+#endif
             u32x4 ah[NT], al[NT];
 #pragma unroll
             for (int j = 0; j < NT; j++) {
+#if S3_PROBE == 3 || S3_PROBE == 6
+                ah[j] = wh0 ^ u32x4{(uint32_t)j, (uint32_t)kc, 0u, 0u};
+                al[j] = wl0 ^ u32x4{(uint32_t)j, (uint32_t)kc, 0u, 0u};
+#else
                 ah[j] = lds4[aoff[j] + kc * 8];
                 al[j] = lds4[aoff[j] + kc * 8 + 1];
+#endif
             }
+#if S3_PROBE == 4 || S3_PROBE == 5 || S3_PROBE == 6
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                acc[j][0][0] += __uint_as_float(ah[j][0] ^ wh0[0] ^ wl0[1]);
+                acc[j][1][0] += __uint_as_float(al[j][0] ^ wh1[0] ^ wl1[1]);
+            }
+#else
 #pragma unroll
             for (int j = 0; j < NT; j++) {
                 acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wh0), as_bf(ah[j]), acc[j][0], 0, 0, 0);
@@ -95,6 +116,7 @@ __device__ __forceinline__ void s3_mainloop(const u32x4* __restrict__ lds4, cons
                 acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wl0), as_bf(ah[j]), acc[j][0], 0, 0, 0);
                 acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wl1), as_bf(ah[j]), acc[j][1], 0, 0, 0);
             }
+#endif
             wh0 = nh0; wl0 = nl0; wh1 = nh1; wl1 = nl1;
             kk++;
         }
@@ -214,7 +236,7 @@ __global__ __launch_bounds__(512) void k_tower_s3(const void* __restrict__ in, T
 #pragma unroll
             for (int t = 0; t < 2; t++) {
                 nxt[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (conv1 && rho0 + j * 16 < rows) {
+                if (S3_PROBE != 1 && conv1 && rho0 + j * 16 < rows) {
                     const int c = ch0 + 16 * t + 4 * q;
                     const u32x2* p = (const u32x2*)(lds4 + (size_t)(rho0 + j * 16) * LS4n + (c >> 3) * 2) + ((c & 7) >> 2);
                     nxt[j][t] = join4(p[0], p[2]);  // hi slot, lo slot (+16 B)
@@ -225,7 +247,7 @@ __global__ __launch_bounds__(512) void k_tower_s3(const void* __restrict__ in, T
         for (int j = 0; j < RTW; j++)
 #pragma unroll
             for (int t = 0; t < 2; t++)
-                if (rho0 + j * 16 < rows) {
+                if (S3_PROBE != 1 && rho0 + j * 16 < rows) {
                     const int c = ch0 + 16 * t + 4 * q;
                     u32x2 hi, lo;
                     split4(acc[j][t], hi, lo);

@@ -9,12 +9,18 @@
 // This is the throughput variant of SURVEY.md §7 step 5; the exact-f32 tower (net_kernels.hip) stays the default.
 //
 // Structure = k_tower: a workgroup keeps PW whole positions in LDS for all 1+2R layers, one launch.  LDS row of a
-// board square: per 8 channels 16 B of hi then 16 B of lo (so the row has the byte size of the f32 row, +16 B pad);
-// an MFMA B operand (32 k × 16 rows) is two ds_read_b128 per lane (its row, channels 8q..8q+7 of the chunk), the A
-// operand (16 output channels × 32 k) two 16-B global loads of the pre-split weights [chunk][cout][q][hi|lo].
+// board square: per chunk of 32 channels eight 16-byte slots — hi of the channel groups q = 0..3, then lo of q = 0..3 —
+// and 32 B of padding per row (the f32 row size + 32 B).  An MFMA B operand (32 k × 16 rows) is two ds_read_b128 per
+// lane (its row, slots q and 4+q of the chunk): ds_read_b128 is served in lane groups that pair 8 rows of one q with 8
+// rows of the next (MI355X_MICROARCH.md §LDS); with this pitch the rows of a group fall on the even 16-byte bank groups
+// and neighbouring q on the odd ones, so the reads are conflict free (hi|lo interleaved per q at pitch +16 B was 2-way on
+// every read and LDS-bound).  The A operand (16 output channels × 32 k) is two 16-B global loads of the pre-split
+// weights [chunk][cout][q][hi|lo].
 // A wave owns CTW = 2 channel tiles × RTW row tiles, so every activation fragment feeds 6 MFMAs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <algorithm>
 
 #include "board.cuh"
 #include "conv_mainloop.cuh"
@@ -57,13 +63,16 @@ __device__ __forceinline__ f32x4 join4(const u32x2& hi, const u32x2& lo) {
 __device__ __forceinline__ bf16x8 as_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
 
 // One layer for NT row tiles × 2 channel tiles.  lds4: image in 16-byte slots, row pitch LS4, chunk kc of a row at
-// slot kc·8 + 2q (hi) and +1 (lo).  wp: this lane's weight slot pair of chunk 0 (channel tile 0), tile 1 at +t1,
+// slot kc·8 + q (hi) and kc·8 + 4 + q (lo).  wp: this lane's weight slot pair of chunk 0 (channel tile 0), tile 1 at +t1,
 // next chunk at +wstride (all in 16-byte units).
 template <int NT, int KC>
 __device__ __forceinline__ void s3_mainloop(const u32x4* __restrict__ lds4, const u32x4* __restrict__ wp, int t1, int wstride, int LS4,
-                                            int rows, int n, int rho0, int q, const int* vmask, f32x4 (&acc)[NT][2]) {
-    const int zero4 = rows * LS4 + 2 * q;
-    const int base0 = rho0 * LS4 + 2 * q;
+                                            int zrow, int zshift, int n, int rho0, int q, const int* vmask, f32x4 (&acc)[NT][2]) {
+    // A tap that leaves the board reads zeros.  zshift = 1: from a zero REGION addressed like the image (row zrow + tap
+    // shift, zrow ≡ this lane's row mod 16), so that the masked lanes keep the bank pattern of the others — a single zero row
+    // (zshift = 0) costs ≈ 7 LDS cycles per ds_read_b128 instead of 4 in the bank model of MI355X_MICROARCH.md §LDS.
+    const int zero4 = zrow * LS4 + q;
+    const int base0 = rho0 * LS4 + q;
     u32x4 wh0 = wp[0], wl0 = wp[1], wh1 = wp[t1], wl1 = wp[t1 + 1];
     int kk = 0;
     constexpr int total = 9 * KC;
@@ -72,7 +81,7 @@ __device__ __forceinline__ void s3_mainloop(const u32x4* __restrict__ lds4, cons
         const int sh = ((tap / 3 - 1) * n + (tap % 3 - 1)) * LS4;
         int aoff[NT];
 #pragma unroll
-        for (int j = 0; j < NT; j++) aoff[j] = ((vmask[j] >> tap) & 1) ? base0 + j * 16 * LS4 + sh : zero4;
+        for (int j = 0; j < NT; j++) aoff[j] = ((vmask[j] >> tap) & 1) ? base0 + j * 16 * LS4 + sh : zero4 + sh * zshift;
 #pragma unroll
         for (int kc = 0; kc < KC; kc++) {
             const int kn = kk + 1 < total ? kk + 1 : kk;
@@ -91,7 +100,7 @@ __device__ __forceinline__ void s3_mainloop(const u32x4* __restrict__ lds4, cons
                 al[j] = wl0 ^ u32x4{(uint32_t)j, (uint32_t)kc, 0u, 0u};
 #else
                 ah[j] = lds4[aoff[j] + kc * 8];
-                al[j] = lds4[aoff[j] + kc * 8 + 1];
+                al[j] = lds4[aoff[j] + kc * 8 + 4];
 #endif
             }
 #if S3_PROBE == 4 || S3_PROBE == 5 || S3_PROBE == 6
@@ -126,7 +135,7 @@ __device__ __forceinline__ void s3_mainloop(const u32x4* __restrict__ lds4, cons
 // RTW: row tiles of a full row group; NRG row groups × NCG channel groups (of 2 tiles) = 8 waves.
 template <int RTW, int KC0, int KC, bool FROM_STATES, bool OUT_SPLIT>
 __global__ __launch_bounds__(512) void k_tower_s3(const void* __restrict__ in, TowerS3Params T, float* __restrict__ out, int B, int n,
-                                                  int PW, int NCG) {
+                                                  int PW, int NCG, int pad0) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     u32x4* lds4 = (u32x4*)lds;
     const int tid = threadIdx.x;
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(512) void k_tower_s3(const void* __restrict__ in, T
 
     // ---- stage the input: CP0 = 32·KC0 channels per row, hi/lo split ----
     constexpr int CP0 = 32 * KC0;
-    int LS4 = (CP0 >> 2) + 1;
+    int LS4 = (CP0 >> 2) + pad0;  // pad0 = 2 (conflict free) when the input image fits, else 1
     if (FROM_STATES) {
         const Geom geo = make_geom(n);
         const uint8_t* states = (const uint8_t*)in;
@@ -159,8 +168,8 @@ __global__ __launch_bounds__(512) void k_tower_s3(const void* __restrict__ in, T
                     u32x2 h0, l0, h1, l1;
                     split4(f32x4{a.x, a.y, a.z, a.w}, h0, l0);
                     split4(f32x4{b.x, b.y, b.z, b.w}, h1, l1);
-                    row[2 * g8] = u32x4{h0[0], h0[1], h1[0], h1[1]};
-                    row[2 * g8 + 1] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+                    row[(g8 >> 2) * 8 + (g8 & 3)] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+                    row[(g8 >> 2) * 8 + 4 + (g8 & 3)] = u32x4{l0[0], l0[1], l1[0], l1[1]};
                 }
             }
         }
@@ -177,11 +186,20 @@ __global__ __launch_bounds__(512) void k_tower_s3(const void* __restrict__ in, T
             u32x2 h0, l0, h1, l1;
             split4(a, h0, l0);
             split4(b, h1, l1);
-            lds4[r * LS4 + 2 * g8] = u32x4{h0[0], h0[1], h1[0], h1[1]};
-            lds4[r * LS4 + 2 * g8 + 1] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+            lds4[r * LS4 + (g8 >> 2) * 8 + (g8 & 3)] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+            lds4[r * LS4 + (g8 >> 2) * 8 + 4 + (g8 & 3)] = u32x4{l0[0], l0[1], l1[0], l1[1]};
         }
     }
-    for (int idx = tid; idx < LS4; idx += 512) lds4[rows * LS4 + idx] = u32x4{0u, 0u, 0u, 0u};
+    // zero rows: a region [zb - (n+1), zb + 16 + n + 1) addressed like the image (see s3_mainloop) when it fits next to
+    // the input image (pad0 == 2), else the single row `rows`
+    const int zb = (rows + n + 1 + 15) & ~15;
+    const int zlo = zb - (n + 1), zcount = 16 + 2 * (n + 1);
+    const bool zregion0 = pad0 == 2;
+    if (zregion0) {
+        for (int idx = tid; idx < zcount * LS4; idx += 512) lds4[zlo * LS4 + idx] = u32x4{0u, 0u, 0u, 0u};
+    } else {
+        for (int idx = tid; idx < LS4; idx += 512) lds4[rows * LS4 + idx] = u32x4{0u, 0u, 0u, 0u};
+    }
     __syncthreads();
 
     const int rho0 = rg * RTW * 16 + r16;
@@ -197,13 +215,15 @@ __global__ __launch_bounds__(512) void k_tower_s3(const void* __restrict__ in, T
         // this lane's weight slots: [chunk][cout][q][hi|lo] in 16-byte units → ((chunk·F + cout)·4 + q)·2
         const u32x4* wp = (const u32x4*)T.w[layer] + ((size_t)(ch0 + r16) * 4 + q) * 2;
         const int t1 = 16 * 4 * 2, wstride = F * 4 * 2;
+        const bool zregion = layer > 0 || zregion0;
+        const int zrow = zregion ? zb + r16 : rows, zshift = zregion ? 1 : 0;
         if (short_group) {
             f32x4 (&acs)[RTW - 1][2] = *reinterpret_cast<f32x4 (*)[RTW - 1][2]>(&acc[0][0]);
-            if (layer == 0) s3_mainloop<RTW - 1, KC0>(lds4, wp, t1, wstride, LS4, rows, n, rho0, q, vmask, acs);
-            else s3_mainloop<RTW - 1, KC>(lds4, wp, t1, wstride, LS4, rows, n, rho0, q, vmask, acs);
+            if (layer == 0) s3_mainloop<RTW - 1, KC0>(lds4, wp, t1, wstride, LS4, zrow, zshift, n, rho0, q, vmask, acs);
+            else s3_mainloop<RTW - 1, KC>(lds4, wp, t1, wstride, LS4, zrow, zshift, n, rho0, q, vmask, acs);
         } else {
-            if (layer == 0) s3_mainloop<RTW, KC0>(lds4, wp, t1, wstride, LS4, rows, n, rho0, q, vmask, acc);
-            else s3_mainloop<RTW, KC>(lds4, wp, t1, wstride, LS4, rows, n, rho0, q, vmask, acc);
+            if (layer == 0) s3_mainloop<RTW, KC0>(lds4, wp, t1, wstride, LS4, zrow, zshift, n, rho0, q, vmask, acc);
+            else s3_mainloop<RTW, KC>(lds4, wp, t1, wstride, LS4, zrow, zshift, n, rho0, q, vmask, acc);
         }
         // ---- epilogue: lane holds out[row rho0 + 16j][ch0 + 16t + 4q .. +3] ----
 #pragma unroll
@@ -227,9 +247,9 @@ __global__ __launch_bounds__(512) void k_tower_s3(const void* __restrict__ in, T
             break;
         }
         __syncthreads();  // every wave has finished reading the previous image
-        const int LS4n = (F >> 2) + 1;
+        const int LS4n = (F >> 2) + 2;
         const bool conv1 = (layer & 1) == 1;  // next layer is conv2 of the same block: it starts from the block input
-        // 8-byte slot of (row, channel c = ch0 + 16t + 4q): chunk c>>5, group (c&31)>>3, half (c&7)>>2
+        // 8-byte half-slot of (row, channel c = ch0 + 16t + 4q): chunk c>>5, slot (c&31)>>3 (hi) / 4 + that (lo), half (c&7)>>2
         f32x4 nxt[RTW][2];
 #pragma unroll
         for (int j = 0; j < RTW; j++)
@@ -238,8 +258,8 @@ __global__ __launch_bounds__(512) void k_tower_s3(const void* __restrict__ in, T
                 nxt[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (S3_PROBE != 1 && conv1 && rho0 + j * 16 < rows) {
                     const int c = ch0 + 16 * t + 4 * q;
-                    const u32x2* p = (const u32x2*)(lds4 + (size_t)(rho0 + j * 16) * LS4n + (c >> 3) * 2) + ((c & 7) >> 2);
-                    nxt[j][t] = join4(p[0], p[2]);  // hi slot, lo slot (+16 B)
+                    const u32x2* p = (const u32x2*)(lds4 + (size_t)(rho0 + j * 16) * LS4n + (c >> 5) * 8 + ((c & 31) >> 3)) + ((c & 7) >> 2);
+                    nxt[j][t] = join4(p[0], p[8]);  // hi slot, lo slot (+4 slots = 64 B)
                 }
             }
         LS4 = LS4n;
@@ -251,12 +271,12 @@ __global__ __launch_bounds__(512) void k_tower_s3(const void* __restrict__ in, T
                     const int c = ch0 + 16 * t + 4 * q;
                     u32x2 hi, lo;
                     split4(acc[j][t], hi, lo);
-                    u32x2* p = (u32x2*)(lds4 + (size_t)(rho0 + j * 16) * LS4 + (c >> 3) * 2) + ((c & 7) >> 2);
+                    u32x2* p = (u32x2*)(lds4 + (size_t)(rho0 + j * 16) * LS4 + (c >> 5) * 8 + ((c & 31) >> 3)) + ((c & 7) >> 2);
                     p[0] = hi;
-                    p[2] = lo;
+                    p[8] = lo;
                 }
-        if (layer == 0)
-            for (int idx = tid; idx < LS4; idx += 512) lds4[rows * LS4 + idx] = u32x4{0u, 0u, 0u, 0u};
+        if (layer == 0)  // the zero region in the pitch of the F-channel image (it lies behind the image rows)
+            for (int idx = tid; idx < zcount * LS4; idx += 512) lds4[zlo * LS4 + idx] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int j = 0; j < RTW; j++) { acc[j][0] = nxt[j][0]; acc[j][1] = nxt[j][1]; }
         __syncthreads();
@@ -301,7 +321,7 @@ __global__ __launch_bounds__(512) void k_fc_s3(const u32x4* __restrict__ A, cons
     for (int p = 0; p < 2; p++) {
         row[p] = blockIdx.x * 128 + pp * 32 + p * 16 + r16;
         row_ok[p] = row[p] < M;
-        ap[p] = A + (size_t)(row_ok[p] ? row[p] : M - 1) * rpitch + 2 * q;  // rows past the end load a valid row; never stored
+        ap[p] = A + (size_t)(row_ok[p] ? row[p] : M - 1) * rpitch + q;  // rows past the end load a valid row; never stored
     }
     const int nsteps = K / 64;
     // staging: the global layout [chunk][column block][q][hi|lo][208] is the LDS plane layout, so both the global read
@@ -342,7 +362,7 @@ __global__ __launch_bounds__(512) void k_fc_s3(const u32x4* __restrict__ A, cons
 #pragma unroll
             for (int p = 0; p < 2; p++) {
                 a[c][p][0] = ap[p][(step * 2 + c) * 8];
-                a[c][p][1] = ap[p][(step * 2 + c) * 8 + 1];
+                a[c][p][1] = ap[p][(step * 2 + c) * 8 + 4];
             }
     };
     load_a(0, ac);
@@ -411,7 +431,7 @@ __global__ __launch_bounds__(256) void k_value_head_s3(const u32x4* __restrict__
     const f32x4* w = (const f32x4*)wv;
     float s = 0.0f;
     for (int g = lane; g < (len >> 3); g += 64) {
-        const u32x4 hi = a[2 * g], lo = a[2 * g + 1];
+        const u32x4 hi = a[(g >> 2) * 8 + (g & 3)], lo = a[(g >> 2) * 8 + 4 + (g & 3)];
         const f32x4 w0 = w[2 * g], w1 = w[2 * g + 1];
         const f32x4 x0 = join4(u32x2{hi[0], hi[1]}, u32x2{lo[0], lo[1]}), x1 = join4(u32x2{hi[2], hi[3]}, u32x2{lo[2], lo[3]});
 #pragma unroll
@@ -426,15 +446,20 @@ __global__ __launch_bounds__(256) void k_value_head_s3(const u32x4* __restrict__
 
 template <int RTW, int KC0, int KC, bool FROM_STATES, bool OUT_SPLIT>
 static hipError_t launch_s3_t(hipStream_t st, const void* in, const TowerS3Params& T, float* out, int B, int n, int PW, int NCG) {
-    int cmax = 32 * KC0 > T.F ? 32 * KC0 : T.F;
-    size_t lds = (size_t)(PW * n * n + 1) * (cmax + 4) * sizeof(float);
+    // rows of C·4 + 32 B are bank-conflict free; the 96-channel input image of the 16-position workgroup only fits with + 16 B
+    const size_t rows = (size_t)PW * n * n;
+    const size_t zrows = ((rows + n + 1 + 15) & ~(size_t)15) + 16 + n + 1;  // image + zero region (k_tower_s3)
+    size_t lds = zrows * (T.F + 8) * sizeof(float);
+    int pad0 = 2;
+    if (zrows * (32 * KC0 + 8) * sizeof(float) > 160 * 1024) pad0 = 1;  // input image: + 16 B pitch and the single zero row
+    lds = std::max(lds, (pad0 == 2 ? zrows : rows + 1) * (32 * KC0 + 4 * pad0) * sizeof(float));
     static size_t configured = 0;
     if (lds > configured) {
         hipError_t e = hipFuncSetAttribute((const void*)k_tower_s3<RTW, KC0, KC, FROM_STATES, OUT_SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    hipLaunchKernelGGL((k_tower_s3<RTW, KC0, KC, FROM_STATES, OUT_SPLIT>), dim3((B + PW - 1) / PW), dim3(512), lds, st, in, T, out, B, n, PW, NCG);
+    hipLaunchKernelGGL((k_tower_s3<RTW, KC0, KC, FROM_STATES, OUT_SPLIT>), dim3((B + PW - 1) / PW), dim3(512), lds, st, in, T, out, B, n, PW, NCG, pad0);
     return hipGetLastError();
 }
 

@@ -36,7 +36,7 @@ hipError_t launch_tower(hipStream_t st, const float* in, const TowerParams& T, f
 hipError_t launch_tower_states(hipStream_t st, const uint8_t* states, const TowerParams& T, float* out, int B, int n);
 // net_s3_kernels.hip — split-bf16 ("bf16x3") tower
 struct TowerS3Params {
-    const void* w[48];    // per layer: [chunk = tap·KC + kc][cout][q][hi 8 bf16 | lo 8 bf16]
+    const void* w[48];    // per layer: [chunk = tap·KC + kc][cout tile][hi|lo][q][cout in tile][8 bf16]
     const float* b[48];   // per layer: bias[F]
     int nlayers;
     int cin_pad;          // channels per row of NHWC f32 input planes (planes entry only)

@@ -171,7 +171,7 @@ float bf16_to_f32(uint16_t h) {
     return x;
 }
 
-// OIHW (BN folded) → [chunk = tap·KC + kc][cout][q][hi 8 | lo 8] bf16, channel = 32·kc + 8q + j, zero padded
+// OIHW (BN folded) → [chunk = tap·KC + kc][cout tile][hi|lo][q][cout][8 bf16], channel = 32·kc + 8q + j, zero padded
 hipError_t upload_conv_s3(const Folded& f, int O, int I, int KC, DevBuf& buf) {
     std::vector<uint16_t> w((size_t)9 * KC * O * 64, 0);
     for (int tap = 0; tap < 9; tap++)
@@ -184,9 +184,10 @@ hipError_t upload_conv_s3(const Folded& f, int O, int I, int KC, DevBuf& buf) {
                         float v = f.w[((size_t)o * I + c) * 9 + tap];
                         uint16_t hi = f32_to_bf16(v);
                         uint16_t lo = f32_to_bf16(v - bf16_to_f32(hi));
-                        size_t base = ((((size_t)tap * KC + kc) * O + o) * 4 + q) * 16;
-                        w[base + j] = hi;
-                        w[base + 8 + j] = lo;
+                        // [chunk][tile of 16 couts][hi|lo][q][cout in tile][8 bf16]
+                        size_t slot = (((((size_t)tap * KC + kc) * (O / 16) + o / 16) * 2) * 4 + q) * 16 + o % 16;
+                        w[slot * 8 + j] = hi;
+                        w[(slot + 64) * 8 + j] = lo;
                     }
     hipError_t e = buf.ensure(w.size() * 2);
     if (e != hipSuccess) return e;

@@ -73,7 +73,7 @@ __device__ __forceinline__ void s3_mainloop(const u32x4* __restrict__ lds4, cons
     // (zshift = 0) costs ≈ 7 LDS cycles per ds_read_b128 instead of 4 in the bank model of MI355X_MICROARCH.md §LDS.
     const int zero4 = zrow * LS4 + q;
     const int base0 = rho0 * LS4 + q;
-    u32x4 wh0 = wp[0], wl0 = wp[1], wh1 = wp[t1], wl1 = wp[t1 + 1];
+    u32x4 wh0 = wp[0], wl0 = wp[64], wh1 = wp[t1], wl1 = wp[t1 + 64];
     int kk = 0;
     constexpr int total = 9 * KC;
 #pragma unroll 1
@@ -90,7 +90,7 @@ __device__ __forceinline__ void s3_mainloop(const u32x4* __restrict__ lds4, cons
             const u32x4 nh0 = wh0, nl0 = wl0, nh1 = wh1, nl1 = wl1;
             (void)wn;
 #else
-            const u32x4 nh0 = wn[0], nl0 = wn[1], nh1 = wn[t1], nl1 = wn[t1 + 1];
+            const u32x4 nh0 = wn[0], nl0 = wn[64], nh1 = wn[t1], nl1 = wn[t1 + 64];
 #endif
             u32x4 ah[NT], al[NT];
 #pragma unroll
@@ -212,9 +212,10 @@ __global__ __launch_bounds__(512) void k_tower_s3(const void* __restrict__ in, T
     for (int j = 0; j < RTW; j++) acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int layer = 0; layer < T.nlayers; layer++) {
-        // this lane's weight slots: [chunk][cout][q][hi|lo] in 16-byte units → ((chunk·F + cout)·4 + q)·2
-        const u32x4* wp = (const u32x4*)T.w[layer] + ((size_t)(ch0 + r16) * 4 + q) * 2;
-        const int t1 = 16 * 4 * 2, wstride = F * 4 * 2;
+        // this lane's weight slots: [chunk][channel tile][hi|lo][q][cout in tile] in 16-byte units — a fragment load is one
+        // contiguous KB per wave
+        const u32x4* wp = (const u32x4*)T.w[layer] + (size_t)(ch0 >> 4) * 128 + q * 16 + r16;
+        const int t1 = 128, wstride = (F >> 4) * 128;
         const bool zregion = layer > 0 || zregion0;
         const int zrow = zregion ? zb + r16 : rows, zshift = zregion ? 1 : 0;
         if (short_group) {

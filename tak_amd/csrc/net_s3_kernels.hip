@@ -21,6 +21,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "board.cuh"
 #include "conv_mainloop.cuh"
@@ -48,6 +49,10 @@ __device__ __forceinline__ float bf16_hi_f32(uint32_t pk) { return __uint_as_flo
 __device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& lo) {
     hi[0] = pk_bf16(v[0], v[1]);
     hi[1] = pk_bf16(v[2], v[3]);
+#if S3_PROBE == 7
+    lo[0] = lo[1] = 0u;
+    return;
+#endif
     lo[0] = pk_bf16(v[0] - bf16_lo_f32(hi[0]), v[1] - bf16_hi_f32(hi[0]));
     lo[1] = pk_bf16(v[2] - bf16_lo_f32(hi[1]), v[3] - bf16_hi_f32(hi[1]));
 }
@@ -132,9 +137,10 @@ __device__ __forceinline__ void s3_mainloop(const u32x4* __restrict__ lds4, cons
     }
 }
 
-// RTW: row tiles of a full row group; NRG row groups × NCG channel groups (of 2 tiles) = 8 waves.
-template <int RTW, int KC0, int KC, bool FROM_STATES, bool OUT_SPLIT>
-__global__ __launch_bounds__(512) void k_tower_s3(const void* __restrict__ in, TowerS3Params T, float* __restrict__ out, int B, int n,
+// RTW: row tiles of a full row group; NRG row groups × NCG channel groups (of 2 tiles) = NW waves.  With NW = 4 two
+// workgroups share a CU (one wave of each per SIMD): they drift apart, so one's epilogue / barrier phases overlap the other's MFMAs.
+template <int RTW, int KC0, int KC, bool FROM_STATES, bool OUT_SPLIT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_tower_s3(const void* __restrict__ in, TowerS3Params T, float* __restrict__ out, int B, int n,
                                                   int PW, int NCG, int pad0) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     u32x4* lds4 = (u32x4*)lds;
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(512) void k_tower_s3(const void* __restrict__ in, T
         const Geom geo = make_geom(n);
         const uint8_t* states = (const uint8_t*)in;
         const int C = input_channels(n);
-        for (int p = wave; p < npos; p += 8) {  // one wave encodes one position at a time, lane = square
+        for (int p = wave; p < npos; p += NW) {  // one wave encodes one position at a time, lane = square
             WState ws;
             ws_load(ws, states + (size_t)(pos0 + p) * geo.bytes, geo);
             const float fcd = fcd_value(ws, geo);
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(512) void k_tower_s3(const void* __restrict__ in, T
         const float* planes = (const float*)in;  // NHWC f32 rows of T.cin_pad channels
         const int cin = T.cin_pad;
         const int groups = CP0 >> 3;
-        for (int idx = tid; idx < rows * groups; idx += 512) {
+        for (int idx = tid; idx < rows * groups; idx += NW * 64) {
             int r = idx / groups, g8 = idx - r * groups;
             f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = a;
             const float* src = planes + ((size_t)pos0 * nsq + r) * cin + 8 * g8;
@@ -196,9 +202,9 @@ __global__ __launch_bounds__(512) void k_tower_s3(const void* __restrict__ in, T
     const int zlo = zb - (n + 1), zcount = 16 + 2 * (n + 1);
     const bool zregion0 = pad0 == 2;
     if (zregion0) {
-        for (int idx = tid; idx < zcount * LS4; idx += 512) lds4[zlo * LS4 + idx] = u32x4{0u, 0u, 0u, 0u};
+        for (int idx = tid; idx < zcount * LS4; idx += NW * 64) lds4[zlo * LS4 + idx] = u32x4{0u, 0u, 0u, 0u};
     } else {
-        for (int idx = tid; idx < LS4; idx += 512) lds4[rows * LS4 + idx] = u32x4{0u, 0u, 0u, 0u};
+        for (int idx = tid; idx < LS4; idx += NW * 64) lds4[rows * LS4 + idx] = u32x4{0u, 0u, 0u, 0u};
     }
     __syncthreads();
 
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(512) void k_tower_s3(const void* __restrict__ in, T
                     p[8] = lo;
                 }
         if (layer == 0)  // the zero region in the pitch of the F-channel image (it lies behind the image rows)
-            for (int idx = tid; idx < zcount * LS4; idx += 512) lds4[zlo * LS4 + idx] = u32x4{0u, 0u, 0u, 0u};
+            for (int idx = tid; idx < zcount * LS4; idx += NW * 64) lds4[zlo * LS4 + idx] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int j = 0; j < RTW; j++) { acc[j][0] = nxt[j][0]; acc[j][1] = nxt[j][1]; }
         __syncthreads();
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(512) void k_tower_s3(const void* __restrict__ in, T
             // the image now holds the final activations in the split row layout k_fc_s3 reads: copy it out, 16 B per lane
             const int spr = F >> 2;  // slots per row without the pad
             u32x4* o = (u32x4*)out + (size_t)pos0 * nsq * spr;
-            for (int idx = tid; idx < rows * spr; idx += 512) {
+            for (int idx = tid; idx < rows * spr; idx += NW * 64) {
                 int r = idx / spr, v = idx - r * spr;
                 o[idx] = lds4[r * LS4 + v];
             }
@@ -445,22 +451,23 @@ __global__ __launch_bounds__(256) void k_value_head_s3(const u32x4* __restrict__
     if (lane == 0) eval[b] = tanhf(s + bv);
 }
 
-template <int RTW, int KC0, int KC, bool FROM_STATES, bool OUT_SPLIT>
+template <int RTW, int KC0, int KC, bool FROM_STATES, bool OUT_SPLIT, int NW>
 static hipError_t launch_s3_t(hipStream_t st, const void* in, const TowerS3Params& T, float* out, int B, int n, int PW, int NCG) {
     // rows of C·4 + 32 B are bank-conflict free; the 96-channel input image of the 16-position workgroup only fits with + 16 B
     const size_t rows = (size_t)PW * n * n;
     const size_t zrows = ((rows + n + 1 + 15) & ~(size_t)15) + 16 + n + 1;  // image + zero region (k_tower_s3)
     size_t lds = zrows * (T.F + 8) * sizeof(float);
     int pad0 = 2;
-    if (zrows * (32 * KC0 + 8) * sizeof(float) > 160 * 1024) pad0 = 1;  // input image: + 16 B pitch and the single zero row
+    const size_t budget = (size_t)160 * 1024 / (NW == 4 ? 2 : 1);        // two 4-wave workgroups per CU
+    if (zrows * (32 * KC0 + 8) * sizeof(float) > budget) pad0 = 1;      // input image: + 16 B pitch and the single zero row
     lds = std::max(lds, (pad0 == 2 ? zrows : rows + 1) * (32 * KC0 + 4 * pad0) * sizeof(float));
     static size_t configured = 0;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_tower_s3<RTW, KC0, KC, FROM_STATES, OUT_SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_tower_s3<RTW, KC0, KC, FROM_STATES, OUT_SPLIT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    hipLaunchKernelGGL((k_tower_s3<RTW, KC0, KC, FROM_STATES, OUT_SPLIT>), dim3((B + PW - 1) / PW), dim3(512), lds, st, in, T, out, B, n, PW, NCG, pad0);
+    hipLaunchKernelGGL((k_tower_s3<RTW, KC0, KC, FROM_STATES, OUT_SPLIT, NW>), dim3((B + PW - 1) / PW), dim3(NW * 64), lds, st, in, T, out, B, n, PW, NCG, pad0);
     return hipGetLastError();
 }
 
@@ -468,12 +475,16 @@ bool tower_s3_supported(int n, int F) { return (n == 5 && (F == 64 || F == 128))
 
 template <bool FROM_STATES, bool OUT_SPLIT>
 static hipError_t launch_s3(hipStream_t st, const void* in, const TowerS3Params& T, float* out, int B, int n) {
-    // 5×5, F = 64: 16 positions = 25 row tiles = 4 row groups (7,6,6,6) × 2 channel groups
-    if (n == 5 && T.F == 64) return launch_s3_t<7, 3, 2, FROM_STATES, OUT_SPLIT>(st, in, T, out, B, n, 16, 2);
+    // 5×5, F = 64: 8 positions = 13 row tiles = 2 row groups (7,6) × 2 channel groups, 4 waves, two workgroups per CU
+    if (n == 5 && T.F == 64) {
+        static const bool wide = getenv("TG_S3_WIDE") != nullptr;  // A/B switch: one 8-wave workgroup of 16 positions per CU
+        if (wide) return launch_s3_t<7, 3, 2, FROM_STATES, OUT_SPLIT, 8>(st, in, T, out, B, n, 16, 2);
+        return launch_s3_t<7, 3, 2, FROM_STATES, OUT_SPLIT, 4>(st, in, T, out, B, n, 8, 2);
+    }
     // 5×5, F = 128: 8 positions = 13 row tiles = 2 row groups (7,6) × 4 channel groups
-    if (n == 5 && T.F == 128) return launch_s3_t<7, 3, 4, FROM_STATES, OUT_SPLIT>(st, in, T, out, B, n, 8, 4);
+    if (n == 5 && T.F == 128) return launch_s3_t<7, 3, 4, FROM_STATES, OUT_SPLIT, 8>(st, in, T, out, B, n, 8, 4);
     // 6×6, F = 128: 4 positions = 9 row tiles = 2 row groups (5,4) × 4 channel groups
-    if (n == 6 && T.F == 128) return launch_s3_t<5, 3, 4, FROM_STATES, OUT_SPLIT>(st, in, T, out, B, n, 4, 4);
+    if (n == 6 && T.F == 128) return launch_s3_t<5, 3, 4, FROM_STATES, OUT_SPLIT, 8>(st, in, T, out, B, n, 4, 4);
     return hipErrorInvalidValue;
 }
 hipError_t launch_tower_s3(hipStream_t st, const float* planes, const TowerS3Params& T, float* out, int B, int n, bool out_split) {

@@ -173,6 +173,39 @@ def test_tree_parity_with_real_network(orc, n, blocks, filters, head):
     ev.close()
 
 
+@pytest.mark.parametrize("n,blocks,filters,head", [(5, 2, 64, "fc5"), (6, 1, 128, "conv")])
+def test_tree_parity_on_the_bf16x3_path(orc, n, blocks, filters, head):
+    # the split-bf16 tower / policy FC inside the lock-step search: same trees as the oracle's MCTS fed by the same
+    # kernels through tg_policy_eval (per-position outputs do not depend on the batch), and a short self-play runs clean
+    import tak_amd
+
+    games = 10
+    net = torch_ref.make_net(n, blocks, filters, head, seed=4)
+    tensors = torch_ref.abi_tensors(net)
+    engines = []
+    for _ in range(2):
+        e = _mk(n, tak_amd.EVAL_RESNET, games, res_blocks=blocks, filters=filters)
+        e.set_precision("bf16x3")
+        e.load_state_dict(tensors)
+        engines.append(e)
+    e, ev = engines
+    e.search_create(games, arena_nodes=1 << 15)
+    s = orc.Search(n, head=orc.HEAD_FC5 if head == "fc5" else orc.HEAD_CONV, py_eval=lambda st: ev.policy_eval(st))
+    sts = _roots(orc, n, games, seed=9, max_plies=30)
+    e.search_reset(sts)
+    s.reset(sts)
+    e.search_run(120)
+    s.run(120)
+    _assert_same_trees(e, s, games)
+    e.selfplay_create(games, arena_nodes=1 << 14, seed=2, rollouts=16, max_examples=4096)
+    e.selfplay_step(6)
+    e.sync()
+    st = e.selfplay_stats()
+    assert st["expansions"] >= 6 * 16 * games * 0.9 and st["plies"] == 6
+    e.close()
+    ev.close()
+
+
 def test_dirichlet_spec_matches_oracle(orc):
     import tak_amd
 

@@ -47,6 +47,7 @@ bool tower_s3_supported(int n, int F);
 hipError_t launch_tower_s3(hipStream_t st, const float* planes, const TowerS3Params& T, float* out, int B, int n, bool out_split);
 hipError_t launch_tower_s3_states(hipStream_t st, const uint8_t* states, const TowerS3Params& T, float* out, int B, int n, bool out_split);
 bool fc_s3_supported(int K, int NP);
+int fc_s3_cols(int NP);
 // Wp: [chunk of 32 k][NP/208 column blocks][q][hi|lo][208 outputs][8 bf16], k = sq·F + c
 hipError_t launch_fc_s3(hipStream_t st, const float* act_split, const void* Wp, const float* bias, float* out, int M, int K, int NP,
                         int out_stride, int n_valid);

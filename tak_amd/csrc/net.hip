@@ -36,7 +36,8 @@ struct Net {
     bool s3 = false;                   // split-bf16 tower in use
     TowerS3Params tower_s3;
     std::vector<DevBuf> s3_w;
-    DevBuf s3_fc;          // policy FC weights, split
+    DevBuf s3_fc, s3_fc_b; // policy FC weights (split) and bias padded to s3_np
+    int s3_np = 0;         // padded outputs of the split FC
     bool s3_fc_on = false; // FC head on the split path (tower writes split activations)
     // measurement hooks (tg_profile_*)
     int prof_every = 0;
@@ -288,33 +289,40 @@ int net_finalize(TgEngine* e) {
         }
         n->s3 = true;
         n->s3_fc_on = false;
-        if (e->cfg.policy_head == TG_HEAD_FC5 && fc_s3_supported(F * nsq, n->policy_np)) {
+        const int s3np = round_up(P, 112);  // column blocks of 112 outputs (k_fc_s3b); TG_S3_FC_WIDE=1 keeps the 208-wide kernel
+        n->s3_np = getenv("TG_S3_FC_WIDE") ? n->policy_np : s3np;
+        if (e->cfg.policy_head == TG_HEAD_FC5 && fc_s3_supported(F * nsq, n->s3_np)) {
             // Linear [P, F·nsq] → split bf16 fragments, k = sq·F + c (the order of the activations)
             const size_t K = (size_t)F * nsq;
-            const int NP = n->policy_np;
+            const int NP = n->s3_np, CB = fc_s3_cols(NP);
             auto w = find(n, "policy.weight", (size_t)P * K, err);
-            if (!w) return fail(TG_ERR_WEIGHTS, err);
+            auto bsrc = w ? find(n, "policy.bias", P, err) : nullptr;
+            if (!bsrc) return fail(TG_ERR_WEIGHTS, err);
             std::vector<uint16_t> ws((size_t)(K / 32) * NP * 64, 0);
             for (int o = 0; o < P; o++)
                 for (size_t k = 0; k < K; k++) {
                     int sq = (int)(k / F), c = (int)(k % F);
                     float v = (*w)[(size_t)o * K + (size_t)c * nsq + sq];
                     uint16_t hi = f32_to_bf16(v), lo = f32_to_bf16(v - bf16_to_f32(hi));
-                    // [chunk][column block of 208][q][hi|lo][column][8 bf16]: the LDS plane layout of k_fc_s3
-                    const size_t cb = (size_t)o / 208, col = (size_t)o % 208, q = (k & 31) >> 3;
-                    size_t slot = ((((k >> 5) * (size_t)(NP / 208) + cb) * 4 + q) * 2) * 208 + col;
+                    // [chunk][column block][q][hi|lo][column][8 bf16]: the LDS plane layout of k_fc_s3 / k_fc_s3b
+                    const size_t cb = (size_t)o / CB, col = (size_t)o % CB, q = (k & 31) >> 3;
+                    size_t slot = ((((k >> 5) * (size_t)(NP / CB) + cb) * 4 + q) * 2) * CB + col;
                     ws[slot * 8 + (k & 7)] = hi;
-                    ws[(slot + 208) * 8 + (k & 7)] = lo;
+                    ws[(slot + CB) * 8 + (k & 7)] = lo;
                 }
             TG_HIP(n->s3_fc.ensure(ws.size() * 2));
             TG_HIP(hipMemcpy(n->s3_fc.p, ws.data(), ws.size() * 2, hipMemcpyHostToDevice));
+            std::vector<float> bp(NP, 0.0f);
+            std::copy(bsrc->begin(), bsrc->end(), bp.begin());
+            TG_HIP(n->s3_fc_b.ensure(bp.size() * 4));
+            TG_HIP(hipMemcpy(n->s3_fc_b.p, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
             n->s3_fc_on = true;
         }
     }
     size_t mb = (size_t)e->cfg.max_batch;
     TG_HIP(n->x.ensure(mb * nsq * F * 4));
     TG_HIP(n->y.ensure(mb * nsq * F * 4));
-    size_t logit_row = e->cfg.policy_head == TG_HEAD_CONV ? (size_t)nsq * n->policy_conv.cout_pad : (size_t)n->policy_np;
+    size_t logit_row = e->cfg.policy_head == TG_HEAD_CONV ? (size_t)nsq * n->policy_conv.cout_pad : (size_t)std::max(n->policy_np, n->s3_np);
     TG_HIP(n->logits.ensure(mb * logit_row * 4));
     TG_HIP(n->planes_nhwc.ensure(mb * nsq * n->cin_pad * 4));
     n->ready = true;
@@ -391,8 +399,8 @@ static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const ui
         TG_HIP(launch_conv3x3(st, x, L.w.as<float>(), L.b.as<float>(), nullptr, logits, M, N, F, L.cout_pad, L.cout_pad, L.cout, false));
         TG_HIP(launch_softmax(st, logits, nsq * L.cout_pad, true, nsq, L.cout_pad, e->policy_size, nb, d_policy));
     } else if (n->s3 && n->s3_fc_on) {
-        TG_HIP(launch_fc_s3(st, x, n->s3_fc.p, n->policy_b.as<float>(), logits, nb, nsq * F, n->policy_np, n->policy_np, e->policy_size));
-        TG_HIP(launch_softmax(st, logits, n->policy_np, false, nsq, 0, e->policy_size, nb, d_policy));
+        TG_HIP(launch_fc_s3(st, x, n->s3_fc.p, n->s3_fc_b.as<float>(), logits, nb, nsq * F, n->s3_np, n->s3_np, e->policy_size));
+        TG_HIP(launch_softmax(st, logits, n->s3_np, false, nsq, 0, e->policy_size, nb, d_policy));
     } else {
         TG_HIP(launch_gemm(st, x, nsq * F, n->policy_w.as<float>(), n->policy_b.as<float>(), logits, nb, nsq * F, n->policy_np,
                            n->policy_np, e->policy_size));

@@ -428,6 +428,111 @@ __global__ __launch_bounds__(512) void k_fc_s3(const u32x4* __restrict__ A, cons
         }
 }
 
+// Variant with small workgroups: NW waves, each 2 position tiles × all CT output tiles (NW·32 positions × CT·16
+// outputs per workgroup).  CT = 7, NW = 4 needs 57 KB of LDS, so two workgroups share a CU and one's staging / barrier
+// phases overlap the other's MFMAs; nothing is loaded twice by a workgroup.
+template <int CT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_fc_s3b(const u32x4* __restrict__ A, const u32x4* __restrict__ Wp, const float* __restrict__ bias,
+                                                    float* __restrict__ out, int M, int K, int NP, int out_stride, int n_valid) {
+    constexpr int COLS = CT * 16, SLOTS = 2 * 4 * 2 * COLS, NT = NW * 64, PER = (SLOTS + NT - 1) / NT;
+    __shared__ u32x4 wl[2][SLOTS];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int n0 = blockIdx.y * COLS;
+    const int rpitch = K >> 2;
+    int row[2];
+    bool row_ok[2];
+    const u32x4* ap[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        row[p] = blockIdx.x * (NW * 32) + wave * 32 + p * 16 + r16;
+        row_ok[p] = row[p] < M;
+        ap[p] = A + (size_t)(row_ok[p] ? row[p] : M - 1) * rpitch + q;
+    }
+    const int nsteps = K / 64;
+    const int ncb = NP / COLS;
+    auto stage_load = [&](int step, u32x4 (&r)[PER]) {
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            int idx = u * NT + tid;
+            idx = idx < SLOTS ? idx : SLOTS - 1;
+            int c = idx / (COLS * 8), rem = idx - c * (COLS * 8);
+            r[u] = Wp[((size_t)(step * 2 + c) * ncb + blockIdx.y) * (COLS * 8) + rem];
+        }
+    };
+    auto stage_store = [&](int buf, const u32x4 (&r)[PER]) {
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            int idx = u * NT + tid;
+            if (idx < SLOTS) wl[buf][idx] = r[u];
+        }
+    };
+    f32x4 acc[2][CT];
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int j = 0; j < CT; j++) acc[p][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 stg[PER];
+    stage_load(0, stg);
+    stage_store(0, stg);
+    u32x4 ac[2][2][2], an[2][2][2];
+    auto load_a = [&](int step, u32x4 (&a)[2][2][2]) {
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                a[c][p][0] = ap[p][(step * 2 + c) * 8];
+                a[c][p][1] = ap[p][(step * 2 + c) * 8 + 4];
+            }
+    };
+    load_a(0, ac);
+    __syncthreads();
+    for (int step = 0; step < nsteps; step++) {
+        const int buf = step & 1;
+        const int nx = step + 1 < nsteps ? step + 1 : step;
+        stage_load(nx, stg);
+        load_a(nx, an);
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const u32x4* wh = &wl[buf][((c * 4 + q) * 2 + 0) * COLS + r16];
+            const u32x4* wo = &wl[buf][((c * 4 + q) * 2 + 1) * COLS + r16];
+            u32x4 w_h[CT], w_l[CT];
+#pragma unroll
+            for (int j = 0; j < CT; j++) { w_h[j] = wh[j * 16]; w_l[j] = wo[j * 16]; }
+#pragma unroll
+            for (int j = 0; j < CT; j++) {
+#pragma unroll
+                for (int p = 0; p < 2; p++) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w_h[j]), as_bf(ac[c][p][0]), acc[p][j], 0, 0, 0);
+#pragma unroll
+                for (int p = 0; p < 2; p++) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w_h[j]), as_bf(ac[c][p][1]), acc[p][j], 0, 0, 0);
+#pragma unroll
+                for (int p = 0; p < 2; p++) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w_l[j]), as_bf(ac[c][p][0]), acc[p][j], 0, 0, 0);
+            }
+        }
+        stage_store(buf ^ 1, stg);
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) { ac[c][p][0] = an[c][p][0]; ac[c][p][1] = an[c][p][1]; }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+        if (row_ok[p]) {
+#pragma unroll
+            for (int j = 0; j < CT; j++) {
+                const int nn = n0 + j * 16 + 4 * q;
+                if (nn < n_valid) {
+                    f32x4 v = acc[p][j] + *(const f32x4*)&bias[nn];
+                    float* o = out + (size_t)row[p] * out_stride + nn;
+                    if (nn + 3 < n_valid) *(f32x4*)o = v;
+                    else for (int t = 0; t < 4; t++) if (nn + t < n_valid) o[t] = v[t];
+                }
+            }
+        }
+}
+
 // value head on the split activations: Linear(F·N² → 1) + tanh; wv in NHWC order (f32)
 __global__ __launch_bounds__(256) void k_value_head_s3(const u32x4* __restrict__ act, const float* __restrict__ wv, float bv, int B, int len,
                                                        float* __restrict__ eval) {
@@ -493,9 +598,15 @@ hipError_t launch_tower_s3(hipStream_t st, const float* planes, const TowerS3Par
 hipError_t launch_tower_s3_states(hipStream_t st, const uint8_t* states, const TowerS3Params& T, float* out, int B, int n, bool out_split) {
     return out_split ? launch_s3<true, true>(st, states, T, out, B, n) : launch_s3<true, false>(st, states, T, out, B, n);
 }
-bool fc_s3_supported(int K, int NP) { return K % 64 == 0 && NP % FS_COLS == 0; }
+bool fc_s3_supported(int K, int NP) { return K % 64 == 0 && (NP % FS_COLS == 0 || NP % 112 == 0); }
+int fc_s3_cols(int NP) { return NP % 112 == 0 ? 112 : FS_COLS; }  // column-block width of the weight layout
 hipError_t launch_fc_s3(hipStream_t st, const float* act_split, const void* Wp, const float* bias, float* out, int M, int K, int NP,
                         int out_stride, int n_valid) {
+    if (NP % 112 == 0) {
+        dim3 grid((M + 127) / 128, NP / 112);
+        hipLaunchKernelGGL((k_fc_s3b<7, 4>), grid, dim3(256), 0, st, (const u32x4*)act_split, (const u32x4*)Wp, bias, out, M, K, NP, out_stride, n_valid);
+        return hipGetLastError();
+    }
     dim3 grid((M + 127) / 128, NP / FS_COLS);
     hipLaunchKernelGGL(k_fc_s3, grid, dim3(512), 0, st, (const u32x4*)act_split, (const u32x4*)Wp, bias, out, M, K, NP, out_stride, n_valid);
     return hipGetLastError();

@@ -489,7 +489,9 @@ __global__ __launch_bounds__(512) void k_fc_lds(const float* __restrict__ A, int
     const int row = blockIdx.x * 128 + wave * 16 + r16;
     const bool row_ok = row < M;
     const int n0 = blockIdx.y * FC_COLS;
-    const f32x4* ap = (const f32x4*)(A + (size_t)(row_ok ? row : 0) * lda) + q;
+    // loads are unconditional (rows past the end read a valid row and are never stored; the idle tail of the staging
+    // round reads a clamped slot): hipcc puts s_waitcnt vmcnt(0) right behind an exec-masked global load
+    const f32x4* ap = (const f32x4*)(A + (size_t)(row_ok ? row : M - 1) * lda) + q;
     const f32x4* wg = (const f32x4*)Wp;  // slot (chunk, col, q) at (chunk*NP + col)*4 + q
     const int nsteps = K / FC_KSTEP;
 
@@ -498,11 +500,10 @@ __global__ __launch_bounds__(512) void k_fc_lds(const float* __restrict__ A, int
 #pragma unroll
         for (int u = 0; u < 7; u++) {
             int idx = u * 512 + tid;
-            if (idx < 4 * FC_PLANE) {
-                int qq = idx / FC_PLANE, rem = idx - qq * FC_PLANE;
-                int c = rem / FC_COLS, col = rem - c * FC_COLS;
-                r[u] = wg[((size_t)(step * 4 + c) * NP + n0 + col) * 4 + qq];
-            }
+            idx = idx < 4 * FC_PLANE ? idx : 4 * FC_PLANE - 1;
+            int qq = idx / FC_PLANE, rem = idx - qq * FC_PLANE;
+            int c = rem / FC_COLS, col = rem - c * FC_COLS;
+            r[u] = wg[((size_t)(step * 4 + c) * NP + n0 + col) * 4 + qq];
         }
     };
     auto stage_store = [&](int buf, const f32x4 (&r)[7]) {
@@ -519,16 +520,16 @@ __global__ __launch_bounds__(512) void k_fc_lds(const float* __restrict__ A, int
     f32x4 stg[7];
     stage_load(0, stg);
     stage_store(0, stg);
-    f32x4 a_cur = row_ok ? ap[0] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 a_cur = ap[0];
     __syncthreads();
     for (int step = 0; step < nsteps; step++) {
         const int buf = step & 1;
-        if (step + 1 < nsteps) stage_load(step + 1, stg);
+        stage_load(step + 1 < nsteps ? step + 1 : step, stg);  // the last step reloads itself (unused)
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const int kc = step * 4 + c;
             const int kn = kc + 1 < nsteps * 4 ? kc + 1 : kc;
-            const f32x4 a_nxt = row_ok ? ap[(size_t)kn * 4] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            const f32x4 a_nxt = ap[(size_t)kn * 4];
             f32x4 w[FC_CT];
 #pragma unroll
             for (int j = 0; j < FC_CT; j++) w[j] = wl[buf][q][c * FC_COLS + j * 16 + r16];
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(512) void k_fc_lds(const float* __restrict__ A, int
                 for (int j = 0; j < FC_CT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j][t], a_cur[t], acc[j], 0, 0, 0);
             a_cur = a_nxt;
         }
-        if (step + 1 < nsteps) stage_store(buf ^ 1, stg);
+        stage_store(buf ^ 1, stg);
         __syncthreads();
     }
     if (row_ok) {

@@ -61,6 +61,8 @@ struct TgEngine {
     TgConfig cfg;
     tg::Geom g;
     hipStream_t stream = nullptr;
+    hipStream_t half_stream[2] = {nullptr, nullptr};  // dual-stream rollouts (search.hip)
+    hipEvent_t half_event[3] = {nullptr, nullptr, nullptr};
     int cin = 0;          // input channels
     int cin_pad = 0;      // channels per NHWC input row (multiple of 16, zero padded)
     int policy_size = 0;  // P
@@ -89,6 +91,9 @@ int net_forward_dev(TgEngine* e, int n, const float* d_planes_nhwc, float* d_pol
 // same from packed states (device); encodes inside the fused tower when the topology allows, else via k_encode
 int net_forward_states_dev(TgEngine* e, int n, const uint8_t* d_states, float* d_policy, float* d_eval);
 bool net_takes_states(const TgEngine* e);  // true when the fused tower encodes in-kernel
+int net_forward_states_at(TgEngine* e, int n, const uint8_t* d_states, float* d_policy, float* d_eval, hipStream_t st, int pos0);
+bool net_profile_due(const TgEngine* e);
+void net_profile_skip(TgEngine* e);
 const std::map<std::string, std::vector<float>>* net_tensors(const TgEngine* e);  // tensors as given to tg_net_set_tensor
 // train.hip
 void trainer_destroy(Trainer* t);

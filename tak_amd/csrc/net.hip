@@ -32,6 +32,7 @@ struct Net {
     DevBuf x, y, logits, planes_nhwc, planes_nchw;
     bool fused = false;  // whole tower in one launch (k_tower)
     TowerParams tower;
+    size_t logit_row = 0;              // floats per position in `logits`
     int precision = TG_PRECISION_F32;  // tg_net_set_precision
     bool s3 = false;                   // split-bf16 tower in use
     TowerS3Params tower_s3;
@@ -323,13 +324,15 @@ int net_finalize(TgEngine* e) {
     TG_HIP(n->x.ensure(mb * nsq * F * 4));
     TG_HIP(n->y.ensure(mb * nsq * F * 4));
     size_t logit_row = e->cfg.policy_head == TG_HEAD_CONV ? (size_t)nsq * n->policy_conv.cout_pad : (size_t)std::max(n->policy_np, n->s3_np);
+    n->logit_row = logit_row;
     TG_HIP(n->logits.ensure(mb * logit_row * 4));
     TG_HIP(n->planes_nhwc.ensure(mb * nsq * n->cin_pad * 4));
     n->ready = true;
     return TG_OK;
 }
 
-static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const uint8_t* d_states, float* d_policy, float* d_eval);
+static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const uint8_t* d_states, float* d_policy, float* d_eval,
+                            hipStream_t st = nullptr, int pos0 = 0);
 
 // planes NHWC [nb][nsq][cin_pad] (device) → policy [nb][P] (softmax, reference order), eval [nb]
 int net_forward_dev(TgEngine* e, int nb, const float* d_planes, float* d_policy, float* d_eval) {
@@ -337,6 +340,19 @@ int net_forward_dev(TgEngine* e, int nb, const float* d_planes, float* d_policy,
 }
 
 bool net_takes_states(const TgEngine* e) { return net_ready(e) && (e->net->fused || e->net->s3); }
+
+// half batch on its own stream (only when the tower encodes from states); see search.hip
+int net_forward_states_at(TgEngine* e, int nb, const uint8_t* d_states, float* d_policy, float* d_eval, hipStream_t st, int pos0) {
+    if (!net_takes_states(e)) return fail(TG_ERR_STATE, "net_forward_states_at needs the fused tower");
+    return net_forward_impl(e, nb, nullptr, d_states, d_policy, d_eval, st, pos0);
+}
+// true when the next forward will be sampled by the profiler (it must then run alone on the GPU to be timed)
+bool net_profile_due(const TgEngine* e) {
+    const Net* n = e->net;
+    return n && n->prof_every > 0 && (n->prof_counter % (uint64_t)n->prof_every) == 0;
+}
+// a forward that was not sampled still advances the sampling counter
+void net_profile_skip(TgEngine* e) { if (e->net && e->net->prof_every > 0) e->net->prof_counter++; }
 
 int net_forward_states_dev(TgEngine* e, int nb, const uint8_t* d_states, float* d_policy, float* d_eval) {
     if (!net_ready(e)) return fail(TG_ERR_STATE, "network weights not finalized (tg_net_finalize)");
@@ -347,18 +363,21 @@ int net_forward_states_dev(TgEngine* e, int nb, const uint8_t* d_states, float* 
     return net_forward_impl(e, nb, e->net->planes_nhwc.as<float>(), nullptr, d_policy, d_eval);
 }
 
-static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const uint8_t* d_states, float* d_policy, float* d_eval) {
+// st / pos0: the stream to launch on (default: the engine stream) and the first position slot of the activation buffers
+// to use — two half batches on two streams work on disjoint slices of the same buffers (search.hip, dual-stream rollouts)
+static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const uint8_t* d_states, float* d_policy, float* d_eval,
+                            hipStream_t st, int pos0) {
     if (!net_ready(e)) return fail(TG_ERR_STATE, "network weights not finalized (tg_net_finalize)");
     if (nb <= 0) return TG_OK;
-    if (nb > e->cfg.max_batch) return fail(TG_ERR_INVALID_ARG, "batch larger than max_batch");
+    if (pos0 < 0 || pos0 + nb > e->cfg.max_batch) return fail(TG_ERR_INVALID_ARG, "batch larger than max_batch");
     Net* n = e->net;
-    hipStream_t st = e->stream;
+    if (!st) st = e->stream;
     const int F = n->F, nsq = e->g.nsq, N = e->g.n;
     const int M = nb * nsq;
-    float* x = n->x.as<float>();
-    float* y = n->y.as<float>();
+    float* x = n->x.as<float>() + (size_t)pos0 * nsq * F;
+    float* y = n->y.as<float>() + (size_t)pos0 * nsq * F;
     std::vector<hipEvent_t>* chain = nullptr;
-    if (n->prof_every > 0 && (n->prof_counter++ % (uint64_t)n->prof_every) == 0) {
+    if (st == e->stream && n->prof_every > 0 && (n->prof_counter++ % (uint64_t)n->prof_every) == 0) {
         if (n->ev_chains.size() >= 256) {  // bound the number of pending events
             TG_HIP(hipStreamSynchronize(st));
             prof_collect(n);
@@ -393,7 +412,7 @@ static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const ui
             if (chain) chain->push_back(prof_event(n, st));
         }
     }
-    float* logits = n->logits.as<float>();
+    float* logits = n->logits.as<float>() + (size_t)pos0 * n->logit_row;
     if (e->cfg.policy_head == TG_HEAD_CONV) {
         const ConvLayer& L = n->policy_conv;
         TG_HIP(launch_conv3x3(st, x, L.w.as<float>(), L.b.as<float>(), nullptr, logits, M, N, F, L.cout_pad, L.cout_pad, L.cout, false));

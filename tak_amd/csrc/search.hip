@@ -3,6 +3,7 @@
 // call), the per-ply schedule of self_play_parallel, result read-back and the tree dump.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "engine.h"
@@ -175,6 +176,86 @@ static int search_iterate(TgEngine* e, const uint8_t* d_active) {
     return TG_OK;
 }
 
+// Rollouts on two streams (opt-in, TG_DUAL_STREAM=1): the games are split into two halves that run the select → network → backup chain
+// independently (they share nothing but read-only weights), so the latency-bound tree kernels of one half overlap the
+// MFMA kernels of the other.  Per-game results do not depend on the batch a position is evaluated in, so trees are
+// identical to the single-stream schedule.  An iteration the profiler samples runs alone on the engine stream.
+static SearchDev half_view(const SearchDev& d, int g0, int count, size_t state_bytes) {
+    SearchDev v = d;
+    v.hot += (size_t)g0 * 2 * d.cap; v.cold += (size_t)g0 * 2 * d.cap;
+    v.sel += g0; v.alloc += g0;
+    v.root_state += (size_t)g0 * state_bytes; v.alive += g0; v.generation += g0;
+    v.path_len += g0; v.path += (size_t)g0 * MAX_DEPTH; v.leaf_kind += g0; v.leaf_hash += g0;
+    v.leaf_state += (size_t)g0 * state_bytes; v.policy += (size_t)g0 * d.P; v.eval += g0;
+    v.counters += (size_t)g0 * 2;
+    v.slot_base += (uint32_t)g0;
+    v.G = count;
+    return v;
+}
+
+static bool dual_stream_ok(TgEngine* e) {
+    // measured on MI355X at C2: no gain (exact f32 4.06 M vs 4.11 M expansions/s single-stream, bf16x3 11.8 M vs 12.4 M) —
+    // the half-batch MFMA kernels fill the chip less well than they overlap; kept opt-in
+    static const bool on = getenv("TG_DUAL_STREAM") != nullptr;
+    Search* s = e->search;
+    return on && e->cfg.evaluator == TG_EVAL_RESNET && !s->d.planes && net_takes_states(e) && s->d.G >= 512;
+}
+
+static int search_iterate_many(TgEngine* e, int iters) {
+    Search* s = e->search;
+    if (iters <= 0) return TG_OK;
+    if (!dual_stream_ok(e)) {
+        for (int i = 0; i < iters; i++) {
+            int rc = search_iterate(e, nullptr);
+            if (rc) return rc;
+        }
+        return TG_OK;
+    }
+    for (int h = 0; h < 2; h++)
+        if (!e->half_stream[h]) TG_HIP(hipStreamCreateWithFlags(&e->half_stream[h], hipStreamNonBlocking));
+    for (int k = 0; k < 3; k++)
+        if (!e->half_event[k]) TG_HIP(hipEventCreateWithFlags(&e->half_event[k], hipEventDisableTiming));
+    const int G = s->d.G;
+    const int g0 = (G / 2 + 15) / 16 * 16;  // whole workgroups of the tower in both halves
+    const SearchDev view[2] = {half_view(s->d, 0, g0, e->g.bytes), half_view(s->d, g0, G - g0, e->g.bytes)};
+    const int first[2] = {0, g0};
+    bool forked = false;
+    auto fork = [&]() -> int {
+        TG_HIP(hipEventRecord(e->half_event[2], e->stream));
+        for (int h = 0; h < 2; h++) TG_HIP(hipStreamWaitEvent(e->half_stream[h], e->half_event[2], 0));
+        forked = true;
+        return TG_OK;
+    };
+    auto join = [&]() -> int {
+        for (int h = 0; h < 2; h++) {
+            TG_HIP(hipEventRecord(e->half_event[h], e->half_stream[h]));
+            TG_HIP(hipStreamWaitEvent(e->stream, e->half_event[h], 0));
+        }
+        forked = false;
+        return TG_OK;
+    };
+    for (int i = 0; i < iters; i++) {
+        if (net_profile_due(e)) {  // timed alone, whole batch, on the engine stream
+            if (forked) { int rc = join(); if (rc) return rc; }
+            int rc = search_iterate(e, nullptr);
+            if (rc) return rc;
+            continue;
+        }
+        if (!forked) { int rc = fork(); if (rc) return rc; }
+        net_profile_skip(e);
+        for (int h = 0; h < 2; h++) {
+            hipStream_t st = e->half_stream[h];
+            launch_select(st, view[h], nullptr);
+            int rc = net_forward_states_at(e, view[h].G, view[h].leaf_state, view[h].policy, view[h].eval, st, first[h]);
+            if (rc) return rc;
+            launch_backup(st, view[h]);
+        }
+        TG_HIP(hipGetLastError());
+    }
+    if (forked) return join();
+    return TG_OK;
+}
+
 static int read_counters(TgEngine* e, unsigned long long* expansions, unsigned long long* evals) {
     Search* s = e->search;
     std::vector<unsigned long long> h((size_t)s->d.G * 2);
@@ -222,10 +303,10 @@ int tg_search_run(TgEngine* e, int iters, const uint8_t* active) {
     const uint8_t* d_active;
     rc = upload_mask(e, active, &d_active);
     if (rc) return rc;
-    for (int i = 0; i < iters; i++) {
-        rc = search_iterate(e, d_active);
-        if (rc) return rc;
-    }
+    if (!d_active) rc = search_iterate_many(e, iters);
+    else
+        for (int i = 0; i < iters && !rc; i++) rc = search_iterate(e, d_active);
+    if (rc) return rc;
     if (active) TG_HIP(hipStreamSynchronize(e->stream));  // the staged mask must outlive the launches
     return TG_OK;
 }
@@ -454,10 +535,8 @@ int tg_selfplay_step(TgEngine* e, int plies) {
         rc = search_iterate(e, s->p.mask);
         if (rc) return rc;
         launch_dirichlet(st, s->d, s->p.mask, s->p.noise_alpha, s->p.noise_ratio);
-        for (int r = 0; r < s->p.rollouts; r++) {                      // (d) :181-210
-            rc = search_iterate(e, nullptr);
-            if (rc) return rc;
-        }
+        rc = search_iterate_many(e, s->p.rollouts);                    // (d) :181-210
+        if (rc) return rc;
         launch_sp_pick(st, s->d, s->p, op);                            // (e) :212-258
         launch_sp_finish(st, s->d, s->p, op);
         launch_reroot(st, s->d, op);

@@ -41,6 +41,11 @@ struct TowerS3Params {
     int nlayers;
     int cin_pad;          // channels per row of NHWC f32 input planes (planes entry only)
     int F;
+    // optional conv policy head computed from the resident image (out_split launches only)
+    const void* head_w;   // [chunk][cout tile][hi|lo][q][cout][8 bf16], head_cout output channels (multiple of 32)
+    const float* head_b;  // bias[head_cout]
+    float* head_out;      // logits [positions][squares][head_cout]
+    int head_cout;
 };
 bool tower_s3_supported(int n, int F);
 // out_split: write the final activations in the split row layout (per 8 channels 16 B hi, 16 B lo) for k_fc_s3

@@ -37,6 +37,8 @@ struct Net {
     bool s3 = false;                   // split-bf16 tower in use
     TowerS3Params tower_s3;
     std::vector<DevBuf> s3_w;
+    DevBuf s3_head;        // conv policy head weights, split (computed inside k_tower_s3)
+    bool s3_head_on = false;
     DevBuf s3_fc, s3_fc_b; // policy FC weights (split) and bias padded to s3_np
     int s3_np = 0;         // padded outputs of the split FC
     bool s3_fc_on = false; // FC head on the split path (tower writes split activations)
@@ -174,8 +176,9 @@ float bf16_to_f32(uint16_t h) {
 }
 
 // OIHW (BN folded) → [chunk = tap·KC + kc][cout tile][hi|lo][q][cout][8 bf16], channel = 32·kc + 8q + j, zero padded
-hipError_t upload_conv_s3(const Folded& f, int O, int I, int KC, DevBuf& buf) {
-    std::vector<uint16_t> w((size_t)9 * KC * O * 64, 0);
+hipError_t upload_conv_s3(const Folded& f, int O, int I, int KC, DevBuf& buf, int OP = 0) {
+    if (!OP) OP = O;  // output channels of the fragment layout (multiple of 16), O of them real
+    std::vector<uint16_t> w((size_t)9 * KC * OP * 64, 0);
     for (int tap = 0; tap < 9; tap++)
         for (int kc = 0; kc < KC; kc++)
             for (int o = 0; o < O; o++)
@@ -187,7 +190,7 @@ hipError_t upload_conv_s3(const Folded& f, int O, int I, int KC, DevBuf& buf) {
                         uint16_t hi = f32_to_bf16(v);
                         uint16_t lo = f32_to_bf16(v - bf16_to_f32(hi));
                         // [chunk][tile of 16 couts][hi|lo][q][cout in tile][8 bf16]
-                        size_t slot = (((((size_t)tap * KC + kc) * (O / 16) + o / 16) * 2) * 4 + q) * 16 + o % 16;
+                        size_t slot = (((((size_t)tap * KC + kc) * (OP / 16) + o / 16) * 2) * 4 + q) * 16 + o % 16;
                         w[slot * 8 + j] = hi;
                         w[(slot + 64) * 8 + j] = lo;
                     }
@@ -290,6 +293,15 @@ int net_finalize(TgEngine* e) {
         }
         n->s3 = true;
         n->s3_fc_on = false;
+        T.head_w = nullptr; T.head_b = nullptr; T.head_out = nullptr; T.head_cout = 0;
+        n->s3_head_on = false;
+        if (e->cfg.policy_head == TG_HEAD_CONV && n->policy_conv.cout_pad % 32 == 0 && !getenv("TG_S3_NO_HEAD")) {
+            const int ch = P / nsq;
+            if (!fold_conv_bn(n, "policy", "", ch, F, g, err)) return fail(TG_ERR_WEIGHTS, err);
+            TG_HIP(upload_conv_s3(g, ch, F, F / 32, n->s3_head, n->policy_conv.cout_pad));
+            T.head_w = n->s3_head.p; T.head_b = n->policy_conv.b.as<float>(); T.head_cout = n->policy_conv.cout_pad;
+            n->s3_head_on = true;
+        }
         const int s3np = round_up(P, 112);  // column blocks of 112 outputs (k_fc_s3b); TG_S3_FC_WIDE=1 keeps the 208-wide kernel
         n->s3_np = getenv("TG_S3_FC_WIDE") ? n->policy_np : s3np;
         if (e->cfg.policy_head == TG_HEAD_FC5 && fc_s3_supported(F * nsq, n->s3_np)) {
@@ -391,8 +403,11 @@ static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const ui
     }
     if (n->s3) {
         if (chain) chain->push_back(prof_event(n, st));
-        if (d_states) TG_HIP(launch_tower_s3_states(st, d_states, n->tower_s3, x, nb, N, n->s3_fc_on));
-        else TG_HIP(launch_tower_s3(st, d_planes, n->tower_s3, x, nb, N, n->s3_fc_on));
+        const bool split_out = n->s3_fc_on || n->s3_head_on;
+        TowerS3Params T3 = n->tower_s3;
+        if (n->s3_head_on) T3.head_out = n->logits.as<float>() + (size_t)pos0 * n->logit_row;
+        if (d_states) TG_HIP(launch_tower_s3_states(st, d_states, T3, x, nb, N, split_out));
+        else TG_HIP(launch_tower_s3(st, d_planes, T3, x, nb, N, split_out));
         if (chain) chain->push_back(prof_event(n, st));
     } else if (n->fused) {
         if (chain) chain->push_back(prof_event(n, st));
@@ -415,7 +430,8 @@ static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const ui
     float* logits = n->logits.as<float>() + (size_t)pos0 * n->logit_row;
     if (e->cfg.policy_head == TG_HEAD_CONV) {
         const ConvLayer& L = n->policy_conv;
-        TG_HIP(launch_conv3x3(st, x, L.w.as<float>(), L.b.as<float>(), nullptr, logits, M, N, F, L.cout_pad, L.cout_pad, L.cout, false));
+        if (!(n->s3 && n->s3_head_on))
+            TG_HIP(launch_conv3x3(st, x, L.w.as<float>(), L.b.as<float>(), nullptr, logits, M, N, F, L.cout_pad, L.cout_pad, L.cout, false));
         TG_HIP(launch_softmax(st, logits, nsq * L.cout_pad, true, nsq, L.cout_pad, e->policy_size, nb, d_policy));
     } else if (n->s3 && n->s3_fc_on) {
         TG_HIP(launch_fc_s3(st, x, n->s3_fc.p, n->s3_fc_b.as<float>(), logits, nb, nsq * F, n->s3_np, n->s3_np, e->policy_size));
@@ -425,7 +441,7 @@ static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const ui
                            n->policy_np, e->policy_size));
         TG_HIP(launch_softmax(st, logits, n->policy_np, false, nsq, 0, e->policy_size, nb, d_policy));
     }
-    if (n->s3 && n->s3_fc_on) TG_HIP(launch_value_head_s3(st, x, n->value_w.as<float>(), n->value_b, nb, nsq * F, d_eval));
+    if (n->s3 && (n->s3_fc_on || n->s3_head_on)) TG_HIP(launch_value_head_s3(st, x, n->value_w.as<float>(), n->value_b, nb, nsq * F, d_eval));
     else TG_HIP(launch_value_head(st, x, n->value_w.as<float>(), n->value_b, nb, nsq * F, d_eval));
     if (chain) chain->push_back(prof_event(n, st));
     return TG_OK;

@@ -295,6 +295,32 @@ __global__ __launch_bounds__(NW * 64) void k_tower_s3(const void* __restrict__ i
                 int r = idx / spr, v = idx - r * spr;
                 o[idx] = lds4[r * LS4 + v];
             }
+            // conv policy head (net6.rs:56,98-103) as one more 3×3 convolution over the resident image: F → head_cout
+            // channels in passes of NCG channel groups, bias only, f32 logits [position][square][head_cout] to global
+            if (T.head_w) {
+                const bool zregion = T.nlayers > 1 || zregion0;
+                const int zrow = zregion ? zb + r16 : rows, zshift = zregion ? 1 : 0;
+                const int hstride = (T.head_cout >> 4) * 128;
+                for (int hc0 = cg * 32; hc0 < T.head_cout; hc0 += NCG * 32) {
+#pragma unroll
+                    for (int j = 0; j < RTW; j++) acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const u32x4* wp = (const u32x4*)T.head_w + (size_t)(hc0 >> 4) * 128 + q * 16 + r16;
+                    if (short_group) {
+                        f32x4 (&acs)[RTW - 1][2] = *reinterpret_cast<f32x4 (*)[RTW - 1][2]>(&acc[0][0]);
+                        s3_mainloop<RTW - 1, KC>(lds4, wp, 128, hstride, LS4, zrow, zshift, n, rho0, q, vmask, acs);
+                    } else {
+                        s3_mainloop<RTW, KC>(lds4, wp, 128, hstride, LS4, zrow, zshift, n, rho0, q, vmask, acc);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        const f32x4 bv = *(const f32x4*)&T.head_b[hc0 + 16 * t + 4 * q];
+#pragma unroll
+                        for (int j = 0; j < RTW; j++)
+                            if (rho0 + j * 16 < rows)
+                                *(f32x4*)&T.head_out[((size_t)pos0 * nsq + rho0 + j * 16) * T.head_cout + hc0 + 16 * t + 4 * q] = acc[j][t] + bv;
+                    }
+                }
+            }
             break;
         }
     }

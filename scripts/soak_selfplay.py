@@ -20,10 +20,20 @@ ap.add_argument("--games", type=int, default=4096)
 ap.add_argument("--rollouts", type=int, default=400)
 ap.add_argument("--plies", type=int, default=200)
 ap.add_argument("--arena", type=int, default=1 << 17)
-ap.add_argument("--evaluator", default="hash")
+ap.add_argument("--evaluator", default="hash", choices=["hash", "dummy", "resnet"])
+ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"])
+ap.add_argument("--blocks", type=int, default=6)
+ap.add_argument("--filters", type=int, default=64)
 args = ap.parse_args()
-ev = tak_amd.EVAL_HASH if args.evaluator == "hash" else tak_amd.EVAL_DUMMY
-e = tak_amd.Engine(args.board, evaluator=ev, max_batch=args.games)
+ev = {"hash": tak_amd.EVAL_HASH, "dummy": tak_amd.EVAL_DUMMY, "resnet": tak_amd.EVAL_RESNET}[args.evaluator]
+e = tak_amd.Engine(args.board, evaluator=ev, max_batch=args.games, res_blocks=args.blocks, filters=args.filters)
+if args.evaluator == "resnet":  # random-init weights (tests/torch_ref.py builds the tch-layout tensors)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch_ref
+
+    if args.precision != "f32":
+        e.set_precision(args.precision)
+    e.load_state_dict(torch_ref.abi_tensors(torch_ref.make_net(args.board, args.blocks, args.filters, "fc5" if args.board == 5 else "conv", seed=0, randomize_bn=False)))
 e.selfplay_create(args.games, arena_nodes=args.arena, seed=1, rollouts=args.rollouts, max_examples=1 << 18)
 t0 = time.time()
 drained = 0

@@ -139,8 +139,9 @@ __device__ __forceinline__ void s3_mainloop(const u32x4* __restrict__ lds4, cons
 
 // RTW: row tiles of a full row group; NRG row groups × NCG channel groups (of 2 tiles) = NW waves.  With NW = 4 two
 // workgroups share a CU (one wave of each per SIMD): they drift apart, so one's epilogue / barrier phases overlap the other's MFMAs.
+// (the second launch bound caps the 4-wave variant at 256 registers so that two of its workgroups fit on a CU)
 template <int RTW, int KC0, int KC, bool FROM_STATES, bool OUT_SPLIT, int NW>
-__global__ __launch_bounds__(NW * 64) void k_tower_s3(const void* __restrict__ in, TowerS3Params T, float* __restrict__ out, int B, int n,
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3(const void* __restrict__ in, TowerS3Params T, float* __restrict__ out, int B, int n,
                                                   int PW, int NCG, int pad0) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     u32x4* lds4 = (u32x4*)lds;

@@ -405,6 +405,7 @@ int tg_train_comm_init(TgEngine* e, int rank, int world_size, const void* id128)
  * corner, `random_plies` random Flat/Cap placements (pit.rs:33-63), drawn from Philox(seed).  Not reproduced:
  * `Player`'s virtual-loss batching inside one tree (one leaf per tree per iteration here) and the early exit
  * of pit.rs:20-23 (all games run at once).  The caller applies the gate (main.rs:102: win_rate > 0.55).
+ * Both engines' search / self-play state is replaced (tg_search_create is called on each).
  * ------------------------------------------------------------------------------------- */
 typedef struct TgPitConfig {
     int32_t pairs;          /* PIT_GAMES 128 */

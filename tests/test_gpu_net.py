@@ -69,6 +69,8 @@ def test_config_topologies_vs_torch(orc, n, blocks, filters, head, batch):
     (5, 6, 64, "fc5", 300),     # C2
     (6, 10, 128, "conv", 70),   # C3
     (5, 10, 128, "fc5", 77),    # C5 network
+    (5, 2, 64, "conv", 45),     # conv head on 5x5 (two head passes of two channel groups)
+    (5, 1, 128, "conv", 9),     # one partial workgroup
 ])
 def test_bf16x3_tower_within_tolerance(orc, n, blocks, filters, head, batch):
     """The split-bf16 tower (TG_PRECISION_BF16X3): same 1e-4 gate as the exact path, and its measured deviation."""

@@ -464,11 +464,32 @@ __device__ inline void ws_encode(const WState& s, const Geom& g, float* out, int
     starting_stones(g.n, st0, cp0);
     float fcd = fcd_value(s, g);
     if (NHWC && (cstride & 3) == 0 && cstride <= 128) {
+        // Every lane builds the ≤128-bit channel mask of its own square; the planes of the position are then written as
+        // one linear run of float4: lane i of a round owns float4 number idx = round·64 + i = (square, channel quad) and
+        // fetches the mask word it needs from the square's lane — 1 KB contiguous per store instruction instead of 25 lanes
+        // writing 16 B each at a pitch of one row (the encode was 64 % of the fused board pass: 3.69 → see DESIGN.md).
         RowMask m = ws_row_mask(s, g);
-        if (lane < g.nsq) {
-            float4* row = (float4*)(out + (size_t)lane * cstride);
-            const int per_sq = cstride >> 2;
-            for (int k = 0; k < per_sq; k++) row[k] = row_mask_value(m, k, C, fcd);
+        const int per_sq = cstride >> 2;
+        const int total = g.nsq * per_sq;
+        float4* dst = (float4*)out;
+        for (int i0 = 0; i0 < total; i0 += 64) {
+            const int idx = i0 + lane;
+            const int ii = idx < total ? idx : total - 1;
+            const int sq = ii / per_sq, k = ii - sq * per_sq;
+            const int c0 = k << 2;
+            // the 32-bit word of the square's mask that holds channels c0..c0+3 (every lane takes part in the shuffles)
+            const uint32_t w0 = (uint32_t)__shfl((int)m.w[0], sq), w1 = (uint32_t)__shfl((int)m.w[1], sq);
+            const uint32_t w2 = (uint32_t)__shfl((int)m.w[2], sq), w3 = (uint32_t)__shfl((int)m.w[3], sq);
+            const uint32_t word = c0 < 32 ? w0 : c0 < 64 ? w1 : c0 < 96 ? w2 : w3;
+            const uint32_t nib = (word >> (c0 & 31)) & 15u;
+            float4 v;
+            v.x = (nib & 1u) ? 1.0f : 0.0f;
+            v.y = (nib & 2u) ? 1.0f : 0.0f;
+            v.z = (nib & 4u) ? 1.0f : 0.0f;
+            v.w = (nib & 8u) ? 1.0f : 0.0f;
+            const int r = C - 1 - c0;  // the fcd plane is the last channel
+            if (r == 0) v.x = fcd; else if (r == 1) v.y = fcd; else if (r == 2) v.z = fcd; else if (r == 3) v.w = fcd;
+            if (idx < total) dst[idx] = v;
         }
         return;
     }

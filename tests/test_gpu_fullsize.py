@@ -115,3 +115,42 @@ def test_board_pass_million_positions(orc):
     ong = orc.result(n, o_states) == 0
     assert (counts.reshape(reps, -1)[:, ong] == orc.movegen(n, o_states)[1][ong][None]).all()
     e.close()
+
+
+def test_training_chunk_full_size_properties(orc):
+    """Config C5's network at the reference chunk size (500 examples × 8 symmetries = 4000 positions): one forward /
+    backward / Adam step through size-independent properties."""
+    import tak_amd
+
+    n, blocks, filters = 5, 10, 128
+    net = torch_ref.make_net(n, blocks, filters, "fc5", seed=0, randomize_bn=False)
+    e = tak_amd.Engine(n, res_blocks=blocks, filters=filters, evaluator=tak_amd.EVAL_RESNET, max_batch=64)
+    e.load_state_dict(torch_ref.abi_tensors(net))
+    e.train_create(chunk_size=500, chunks_in_step=1)
+    sts = orc.random_positions(n, 1500, seed=33, max_plies=60, half_komi=4)
+    sts = sts[orc.result(n, sts) == 0][:500]
+    assert len(sts) == 500
+    mv, cnt = orc.movegen(n, sts)
+    rng = np.random.default_rng(0)
+    visits = np.zeros((500, 512), np.uint32)
+    for i in range(500):
+        visits[i, : cnt[i]] = rng.integers(1, 40, cnt[i])
+    results = rng.choice(np.array([-1.0, 0.0, 1.0], np.float32), 500)
+    w0 = e.train_get_tensor("res9.conv2.weight", (filters, filters, 3, 3))
+    lp, lz, stepped = e.train_chunk(sts, cnt.astype(np.int32), mv, visits, results)
+    assert stepped and np.isfinite(lp) and np.isfinite(lz)
+    # a random-init policy is not far from uniform over 1575 outputs: cross entropy of the order of ln 1575 = 7.36
+    assert 6.5 < lp < 11.0 and 0.0 < lz < 2.5
+    w1 = e.train_get_tensor("res9.conv2.weight", (filters, filters, 3, 3))
+    d = np.abs(w1 - w0)
+    assert 0 < d.max() <= 1.001e-4                      # first Adam step: |Δ| ≤ lr for every element
+    assert np.abs(e.train_get_grad("policy.bias", (1575,))).max() == 0.0  # zero_grad after the step
+    # the eight symmetric images of an example carry the same value target and the same visit mass: forward_training on
+    # the augmented states is invariant under permuting the batch (BatchNorm statistics are order independent up to rounding)
+    a_states, pi = e.augment_examples(sts[:64], cnt[:64].astype(np.int32), mv[:64], visits[:64])
+    assert np.allclose(pi.sum(1), 1.0, atol=1e-5)
+    lp1, v1 = e.train_forward(a_states)
+    perm = rng.permutation(len(a_states))
+    lp2, v2 = e.train_forward(a_states[perm])
+    assert np.abs(lp1[perm] - lp2).max() < 1e-4 and np.abs(v1[perm] - v2).max() < 1e-4
+    e.close()

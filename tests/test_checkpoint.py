@@ -1,0 +1,46 @@
+"""tch VarStore archives (Network::save / load, net5.rs:95-104) ⇄ the ABI tensor names: round trip through the TorchScript
+archive, robustness to the order in which tch creates the variables inside a layer, loud failure on a mismatching file.
+Host logic only (no GPU).  Not a parity test against the reference binary — no file written by tch exists here."""
+import itertools
+import os
+
+import numpy as np
+import pytest
+
+import torch_ref
+
+
+@pytest.mark.parametrize("n,blocks,filters,head", [(5, 2, 32, "fc5"), (6, 1, 32, "conv")])
+def test_round_trip_and_order_robustness(tmp_path, n, blocks, filters, head):
+    from tak_amd import checkpoint
+
+    net = torch_ref.make_net(n, blocks, filters, head, seed=2)
+    tensors = torch_ref.abi_tensors(net)
+    names = checkpoint.tch_names(blocks)
+    assert [a for a, _ in names][:6] == ["conv0.bias", "conv0.weight", "bn0.weight", "bn0.bias", "bn0.running_mean", "bn0.running_var"]
+    assert [t for _, t in names][:6] == ["bias", "weight", "weight__2", "bias__3", "running_mean", "running_var"]
+    assert len(names) == len(tensors)
+    bn_orders = [("weight", "bias", "running_mean", "running_var"), ("running_mean", "running_var", "weight", "bias"),
+                 ("bias", "running_var", "weight", "running_mean")]
+    for i, (conv_order, bn_order) in enumerate(itertools.product([("bias", "weight"), ("weight", "bias")], bn_orders)):
+        path = os.path.join(tmp_path, f"m{i}.model")
+        checkpoint.save_tch_varstore(path, tensors, blocks, conv_order=conv_order, bn_order=bn_order)
+        back = checkpoint.load_tch_varstore(path, blocks)
+        assert set(back) == set(tensors)
+        for k in tensors:
+            assert back[k].shape == tensors[k].shape and np.array_equal(back[k], tensors[k]), (k, conv_order, bn_order)
+
+
+def test_mismatching_archives_fail_loudly(tmp_path):
+    from tak_amd import checkpoint
+
+    net = torch_ref.make_net(5, 2, 32, "fc5", seed=3)
+    tensors = torch_ref.abi_tensors(net)
+    path = os.path.join(tmp_path, "m.model")
+    checkpoint.save_tch_varstore(path, tensors, 2)
+    with pytest.raises(ValueError):
+        checkpoint.load_tch_varstore(path, 3)  # a network of another depth
+    shallow = torch_ref.abi_tensors(torch_ref.make_net(5, 1, 32, "fc5", seed=3))
+    checkpoint.save_tch_varstore(path, shallow, 1)
+    with pytest.raises(ValueError):
+        checkpoint.load_tch_varstore(path, 2)

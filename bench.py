@@ -58,6 +58,7 @@ def cpu_baseline(args, net, seconds_budget=20.0):
         return torch_ref.forward(net, orc.encode(n, states))
 
     sp = orc.SelfPlay(n, args.cpu_games, head=head, py_eval=py_eval, seed=args.seed, rollouts=args.rollouts)
+    sp.set_threads(torch.get_num_threads())  # the per-game MCTS phases under OpenMP, the network under PyTorch's pool
     t0 = time.perf_counter()
     plies = 0
     while True:
@@ -73,7 +74,7 @@ def cpu_baseline(args, net, seconds_budget=20.0):
         "cores": int(torch.get_num_threads()),
         "kind": "port",
         "sample": f"{args.cpu_games} of the {args.games} games, {plies} ply(ies) = {st['expansions']} expansions "
-                  f"in {dt:.1f} s; oracle scalar MCTS (1 thread) + PyTorch-CPU fp32 {args.blocks}x{args.filters} net "
+                  f"in {dt:.1f} s; oracle scalar MCTS (OpenMP over games, {torch.get_num_threads()} threads) + PyTorch-CPU fp32 {args.blocks}x{args.filters} net "
                   f"({torch.get_num_threads()} threads)",
     }
 

@@ -338,6 +338,10 @@ class SelfPlay:
             lib().orc_selfplay_free(self.h)
             self.h = None
 
+    def set_threads(self, threads):
+        """OpenMP threads for the per-game MCTS phases (results are identical for any count)."""
+        lib().orc_selfplay_threads(C.c_void_p(self.h), int(threads))
+
     def step(self, plies=1):
         return lib().orc_selfplay_step(C.c_void_p(self.h), plies)
 

@@ -215,7 +215,10 @@ struct SearchParams {
     float exploration_init = 4.0f;    // mcts.rs:8
 };
 
-struct SearchError { bool nan = false; };
+struct SearchError {
+    bool nan = false;
+    void merge(const SearchError& o) { nan = nan || o.nan; }
+};
 
 inline float exploration_rate(float n, const SearchParams& p) {                          // mcts.rs:10-12
     return logf((1.0f + n + p.exploration_base) / p.exploration_base) + p.exploration_init;
@@ -384,24 +387,36 @@ struct Search {
         alive.assign(roots.size(), 1);
         generation.assign(roots.size(), 0);
     }
+    int threads = 1;  // > 1: the per-game phases run under OpenMP (games are independent; results identical to 1 thread)
+
     // one iteration for every game whose mask byte is non-zero
     void iterate(const uint8_t* active) {
+        const int G = (int)games.size();
+        std::vector<uint8_t> res(G, 0xff);
+        std::vector<Game> leaf(G);
+        std::vector<std::vector<int>> path(G);
+        std::vector<SearchError> errs(G);
+#pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
+        for (int i = 0; i < G; i++) {
+            if (!alive[i] || (active && !active[i])) continue;
+            leaf[i] = games[i];  // games.clone(), self_play.rs:184
+            res[i] = virtual_rollout(nodes[i], leaf[i], path[i], sp, errs[i]);
+        }
         std::vector<int> idx;
         std::vector<Game> for_eval;
-        std::vector<std::vector<int>> paths;
-        for (size_t i = 0; i < games.size(); i++) {
-            if (!alive[i] || (active && !active[i])) continue;
-            Game g = games[i];  // games.clone(), self_play.rs:184
-            std::vector<int> path;
-            uint8_t r = virtual_rollout(nodes[i], g, path, sp, err);
+        for (int i = 0; i < G; i++) {
+            if (res[i] == 0xff) continue;
             expansions++;
-            if (r == TG_ONGOING) { idx.push_back((int)i); for_eval.push_back(g); paths.push_back(path); }
+            err.merge(errs[i]);
+            if (res[i] == TG_ONGOING) { idx.push_back(i); for_eval.push_back(leaf[i]); }
         }
         std::vector<std::vector<float>> policy;
         std::vector<float> eval;
         ev.run(for_eval, policy, eval);
         evals += for_eval.size();
-        for (size_t k = 0; k < idx.size(); k++) devirtualize_path(nodes[idx[k]], paths[k], 0, policy[k], eval[k], n);
+        const int K = (int)idx.size();
+#pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
+        for (int k = 0; k < K; k++) devirtualize_path(nodes[idx[k]], path[idx[k]], 0, policy[k], eval[k], n);
     }
 };
 

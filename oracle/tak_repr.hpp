@@ -94,9 +94,8 @@ inline void legacy5_gen_compositions(int hand, int room, std::vector<uint8_t>& c
     }
 }
 
-inline const std::vector<Move>& legacy5_table() {
-    static std::vector<Move> table;
-    if (!table.empty()) return table;
+inline std::vector<Move> legacy5_build() {
+    std::vector<Move> table;
     const int n = 5;
     for (int x = 0; x < n; x++) for (int y = 0; y < n; y++) for (int p = 0; p < 3; p++) {
         Move m; m.col = (uint8_t)x; m.row = (uint8_t)y; m.piece = (uint8_t)p;
@@ -121,16 +120,20 @@ inline const std::vector<Move>& legacy5_table() {
     }
     return table;
 }
+inline const std::vector<Move>& legacy5_table() {
+    static const std::vector<Move> table = legacy5_build();  // initialised once, thread-safe (C++11 static initialisation)
+    return table;
+}
 
 // returns -1 where the reference panics ("could not map turn to index", move_map.rs:24)
 inline int move_index(const Move& m, int n) {
     if (n == 5) {
-        static std::vector<int> lut;  // keyed by move code
-        if (lut.empty()) {
-            lut.assign(1 << 16, -1);
+        static const std::vector<int> lut = [] {  // keyed by move code; thread-safe one-time initialisation
+            std::vector<int> l(1 << 16, -1);
             const auto& t = legacy5_table();
-            for (size_t i = 0; i < t.size(); i++) lut[encode_move(t[i], 5)] = (int)i;
-        }
+            for (size_t i = 0; i < t.size(); i++) l[encode_move(t[i], 5)] = (int)i;
+            return l;
+        }();
         if (m.col >= 5 || m.row >= 5) return -1;
         if (!m.spread && m.piece > 2) return -1;
         return lut[encode_move(m, 5)];

@@ -27,6 +27,9 @@
 #include "conv_mainloop.cuh"
 #include "kernels.h"
 
+#ifndef FC_PROBE
+#define FC_PROBE 0  // scripts/probes/fc_s3_probe.hip
+#endif
 #ifndef S3_PROBE
 #define S3_PROBE 0  // scripts/probes/tower_s3_probe.hip builds variants with parts of the kernel removed
 #endif
@@ -518,8 +521,8 @@ __global__ __launch_bounds__(NW * 64) void k_fc_s3b(const u32x4* __restrict__ A,
     for (int step = 0; step < nsteps; step++) {
         const int buf = step & 1;
         const int nx = step + 1 < nsteps ? step + 1 : step;
-        stage_load(nx, stg);
-        load_a(nx, an);
+        if (FC_PROBE != 3 && FC_PROBE != 4) stage_load(nx, stg);
+        if (FC_PROBE != 2 && FC_PROBE != 4) load_a(nx, an);
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             const u32x4* wh = &wl[buf][((c * 4 + q) * 2 + 0) * COLS + r16];
@@ -527,6 +530,12 @@ __global__ __launch_bounds__(NW * 64) void k_fc_s3b(const u32x4* __restrict__ A,
             u32x4 w_h[CT], w_l[CT];
 #pragma unroll
             for (int j = 0; j < CT; j++) { w_h[j] = wh[j * 16]; w_l[j] = wo[j * 16]; }
+#if FC_PROBE == 1 || FC_PROBE == 4
+#pragma unroll
+            for (int j = 0; j < CT; j++)
+#pragma unroll
+                for (int p = 0; p < 2; p++) acc[p][j][0] += __uint_as_float(w_h[j][0] ^ w_l[j][1] ^ ac[c][p][0][0] ^ ac[c][p][1][1]);
+#else
 #pragma unroll
             for (int j = 0; j < CT; j++) {
 #pragma unroll
@@ -536,8 +545,9 @@ __global__ __launch_bounds__(NW * 64) void k_fc_s3b(const u32x4* __restrict__ A,
 #pragma unroll
                 for (int p = 0; p < 2; p++) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w_l[j]), as_bf(ac[c][p][0]), acc[p][j], 0, 0, 0);
             }
+#endif
         }
-        stage_store(buf ^ 1, stg);
+        if (FC_PROBE != 3 && FC_PROBE != 4) stage_store(buf ^ 1, stg);
 #pragma unroll
         for (int c = 0; c < 2; c++)
 #pragma unroll

@@ -326,7 +326,10 @@ int upload_chunk(TgEngine* e, int n, const uint8_t* states, const int32_t* n_mov
     std::vector<float> z8((size_t)n * 8);
     for (int i = 0; i < n; i++) {
         const int s = order ? order[i] : i;
-        if (n_moves[s] < 0 || n_moves[s] > TG_MAX_MOVES) return fail(TG_ERR_INVALID_ARG, "training example: n_moves out of range");
+        if (n_moves[s] <= 0 || n_moves[s] > TG_MAX_MOVES) return fail(TG_ERR_INVALID_ARG, "training example: n_moves out of range");
+        uint64_t total = 0;
+        for (int k = 0; k < n_moves[s]; k++) total += visits[(size_t)s * TG_MAX_MOVES + k];
+        if (total == 0) return fail(TG_ERR_INVALID_ARG, "training example without visits (the policy target would be 0/0)");
         for (int k = 0; k < 8; k++) z8[(size_t)i * 8 + k] = results[s];
     }
     // shuffled chunks are gathered on the host first: five copies per chunk, whatever the order

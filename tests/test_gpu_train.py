@@ -255,3 +255,20 @@ def test_errors():
         e.train_step()
     assert ei.value.code == -7  # no trainer
     e.close()
+
+
+def test_example_validation(orc):
+    import tak_amd
+
+    net = torch_ref.make_net(5, 1, 32, "fc5", seed=1)
+    e = _engine(5, 1, 32, "fc5")
+    e.load_state_dict(torch_ref.abi_tensors(net))
+    e.train_create(chunk_size=4)
+    sts, cnt, mv, visits, results = _examples(orc, 5, 4, seed=1)
+    visits[2] = 0
+    with pytest.raises(tak_amd.TgError) as ei:
+        e.train_chunk(sts, cnt, mv, visits, results)
+    assert ei.value.code == -1 and "visits" in str(ei.value)
+    with pytest.raises(tak_amd.TgError):
+        e.train_chunk(np.tile(sts, (2, 1)), np.tile(cnt, 2), np.tile(mv, (2, 1)), np.tile(visits, (2, 1)), np.tile(results, 2))  # > chunk_size
+    e.close()

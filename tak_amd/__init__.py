@@ -11,3 +11,4 @@ from .engine import (  # noqa: F401
     state_bytes, input_channels, policy_size, load_library, build_library, LIB_PATH,
     format_move, parse_move, format_tps, parse_tps, format_example, parse_example, comm_unique_id, pit,
 )
+from .player import Player  # noqa: E402,F401

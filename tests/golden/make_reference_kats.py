@@ -13,7 +13,7 @@ import re
 import sys
 
 REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "reference_kats.json")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_kats.json")
 
 
 def read(rel):

@@ -576,22 +576,30 @@ int tg_selfplay_drain(TgEngine* e, int cap, TgExampleHeader* headers, void* stat
     const unsigned long long ME = (unsigned long long)s->p.max_examples;
     if (total - s->drained > ME) s->drained = total - ME;  // older ones were overwritten in the ring
     const size_t sb = (size_t)e->g.bytes;
-    int k = 0;
-    std::vector<ExampleRec> hdr(1);
-    for (; k < cap && s->drained < total; k++, s->drained++) {
-        size_t o = (size_t)(s->drained % ME);
-        TG_HIP(hipMemcpy(hdr.data(), s->out_hdr.as<ExampleRec>() + o, sizeof(ExampleRec), hipMemcpyDeviceToHost));
-        headers[k].game_id = hdr[0].slot | (hdr[0].generation << 20);
-        headers[k].n_moves = hdr[0].n_moves;
-        headers[k].result = hdr[0].result;
-        headers[k].reserved = 0;
-        TG_HIP(hipMemcpy((uint8_t*)states + (size_t)k * sb, s->out_state.as<uint8_t>() + o * sb, sb, hipMemcpyDeviceToHost));
-        size_t nm = (size_t)std::min(hdr[0].n_moves, (int32_t)EX_MOVES);
-        std::memset(moves + (size_t)k * EX_MOVES, 0, EX_MOVES * 2);
-        std::memset(visits + (size_t)k * EX_MOVES, 0, EX_MOVES * 4);
-        TG_HIP(hipMemcpy(moves + (size_t)k * EX_MOVES, s->out_moves.as<uint16_t>() + o * EX_MOVES, nm * 2, hipMemcpyDeviceToHost));
-        TG_HIP(hipMemcpy(visits + (size_t)k * EX_MOVES, s->out_visits.as<uint32_t>() + o * EX_MOVES, nm * 4, hipMemcpyDeviceToHost));
+    const unsigned long long avail = total - s->drained;
+    const int k = (int)std::min<unsigned long long>((unsigned long long)cap, avail);
+    // the k examples are consecutive ring entries: at most two contiguous runs per array (wrap-around), one copy each
+    std::vector<ExampleRec> hdr((size_t)k);
+    for (int done = 0; done < k;) {
+        const size_t o = (size_t)((s->drained + done) % ME);
+        const int run = (int)std::min<size_t>((size_t)(k - done), (size_t)ME - o);
+        TG_HIP(hipMemcpy(hdr.data() + done, s->out_hdr.as<ExampleRec>() + o, (size_t)run * sizeof(ExampleRec), hipMemcpyDeviceToHost));
+        TG_HIP(hipMemcpy((uint8_t*)states + (size_t)done * sb, s->out_state.as<uint8_t>() + o * sb, (size_t)run * sb, hipMemcpyDeviceToHost));
+        TG_HIP(hipMemcpy(moves + (size_t)done * EX_MOVES, s->out_moves.as<uint16_t>() + o * EX_MOVES, (size_t)run * EX_MOVES * 2, hipMemcpyDeviceToHost));
+        TG_HIP(hipMemcpy(visits + (size_t)done * EX_MOVES, s->out_visits.as<uint32_t>() + o * EX_MOVES, (size_t)run * EX_MOVES * 4, hipMemcpyDeviceToHost));
+        done += run;
     }
+    for (int i = 0; i < k; i++) {
+        headers[i].game_id = hdr[i].slot | (hdr[i].generation << 20);
+        headers[i].n_moves = hdr[i].n_moves;
+        headers[i].result = hdr[i].result;
+        headers[i].reserved = 0;
+        // entries past n_moves are whatever an earlier example left in the ring slot: clear them for the caller
+        const size_t nm = (size_t)std::min(std::max(hdr[i].n_moves, 0), (int32_t)EX_MOVES);
+        std::memset(moves + (size_t)i * EX_MOVES + nm, 0, (EX_MOVES - nm) * 2);
+        std::memset(visits + (size_t)i * EX_MOVES + nm, 0, (EX_MOVES - nm) * 4);
+    }
+    s->drained += (unsigned long long)k;
     *n_out = k;
     return TG_OK;
 }

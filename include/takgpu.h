@@ -252,7 +252,11 @@ int tg_policy_eval_dev(TgEngine* e, int n, const void* d_states, float* d_policy
  * ------------------------------------------------------------------------------------- */
 typedef struct TgSearchConfig {
     int32_t games;            /* concurrent games (≤ cfg.max_batch)                          */
-    int32_t arena_nodes;      /* node capacity of one game's tree arena (two arenas per game) */
+    int32_t arena_nodes;      /* node capacity of one game's tree arena (two arenas per game, 24 B per node).  A rollout
+                                 adds one node per legal move of the expanded leaf (≈ 45 on 5×5, ≈ 80 on 6×6) and the subtree
+                                 under the move played is kept (tree reuse), so long games with concentrated searches need
+                                 many times rollouts × branching: 2^19 ran 400 plies of 4096 5×5 games at 400 rollouts
+                                 (103 GB); 2^17 overflows after ≈ 180 plies (TG_ERR_ARENA_OVERFLOW) */
     float exploration_base;   /* EXPLORATION_BASE 500 (mcts.rs:7) */
     float exploration_init;   /* EXPLORATION_INIT 4   (mcts.rs:8) */
     uint64_t seed;            /* counter-based RNG key (noise, move sampling, openings)      */

@@ -19,7 +19,7 @@ ap.add_argument("--board", type=int, default=5)
 ap.add_argument("--games", type=int, default=4096)
 ap.add_argument("--rollouts", type=int, default=400)
 ap.add_argument("--plies", type=int, default=200)
-ap.add_argument("--arena", type=int, default=1 << 17)
+ap.add_argument("--arena", type=int, default=1 << 19, help="nodes per game arena (2^17 overflows after ~180 plies with a real network)")
 ap.add_argument("--evaluator", default="hash", choices=["hash", "dummy", "resnet"])
 ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"])
 ap.add_argument("--blocks", type=int, default=6)

@@ -673,7 +673,7 @@ hipError_t launch_value_bwd(hipStream_t st, const float* act, const float* dpre,
 static void wgrad_plan_conv(int B, int nsq, int ntiles, int* pw, int* cps, int* splits) {
     *pw = nsq >= 48 ? 1 : 48 / nsq;
     int chunks = (B + *pw - 1) / *pw;
-    int target = 1024 / ntiles;
+    int target = 512 / ntiles;  // two resident workgroups per CU (register-limited): one full round, half the partials to reduce
     if (target < 1) target = 1;
     *cps = (chunks + target - 1) / target;
     *splits = (chunks + *cps - 1) / *cps;

@@ -416,25 +416,51 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ X, int 
     for (int v = tid; v < XLS4; v += 256) Xt[(size_t)rows_chunk * XLS4 + v] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int row_begin = split * chunks_per_split * rows_chunk;
+    // CONV: the next chunk's X / G slots travel through registers (≤ 4 + 4 float4 per thread, unconditional clamped loads)
+    // while the current chunk's MFMAs run; they are written to LDS behind the barrier that ends the chunk
+    f32x4 px[4], pg[4];
+    auto prefetch = [&](int r0) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = u * 256 + tid;
+            const int r = idx >> 4, v = idx & 15;
+            const int rr = min(r0 + r, R - 1);
+            const int cx = min(xc0 + 4 * v, xs - 4), cg = min(gc0 + 4 * v, gs - 4);
+            px[u] = *(const f32x4*)(X + (size_t)rr * xs + cx);
+            pg[u] = *(const f32x4*)(G + (size_t)rr * gs + cg);
+        }
+    };
+    if (CONV && row_begin < R) prefetch(row_begin);
     for (int ch = 0; ch < chunks_per_split; ch++) {
         const int r0 = row_begin + ch * rows_chunk;
         if (r0 >= R) break;
         const int rows = min(rows_chunk, R - r0);
         const int rows_pad = (rows + 3) & ~3;
         __syncthreads();  // the previous chunk has been consumed
-        for (int idx = tid; idx < rows * XV; idx += 256) {
-            int r = idx / XV, v = idx - r * XV;
-            int c = xc0 + 4 * v;
-            f32x4 val = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (c < xvalid) val = *(const f32x4*)(X + (size_t)(r0 + r) * xs + c);
-            Xt[r * XLS4 + v] = val;
-        }
-        for (int idx = tid; idx < rows_pad * 16; idx += 256) {
-            int r = idx >> 4, v = idx & 15;
-            int c = gc0 + 4 * v;
-            f32x4 val = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (r < rows && c < gvalid) val = *(const f32x4*)(G + (size_t)(r0 + r) * gs + c);
-            Gt[r * GLS4 + v] = val;
+        if (CONV) {
+            const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int idx = u * 256 + tid;
+                const int r = idx >> 4, v = idx & 15;
+                if (idx < rows * 16) Xt[r * XLS4 + v] = (xc0 + 4 * v < xvalid) ? px[u] : zero;
+                if (idx < rows_pad * 16) Gt[r * GLS4 + v] = (r < rows && gc0 + 4 * v < gvalid) ? pg[u] : zero;
+            }
+        } else {
+            for (int idx = tid; idx < rows * XV; idx += 256) {
+                int r = idx / XV, v = idx - r * XV;
+                int c = xc0 + 4 * v;
+                f32x4 val = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (c < xvalid) val = *(const f32x4*)(X + (size_t)(r0 + r) * xs + c);
+                Xt[r * XLS4 + v] = val;
+            }
+            for (int idx = tid; idx < rows_pad * 16; idx += 256) {
+                int r = idx >> 4, v = idx & 15;
+                int c = gc0 + 4 * v;
+                f32x4 val = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (r < rows && c < gvalid) val = *(const f32x4*)(G + (size_t)(r0 + r) * gs + c);
+                Gt[r * GLS4 + v] = val;
+            }
         }
         if (CONV) {
             for (int r = tid; r < rows_pad; r += 256) {
@@ -452,6 +478,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ X, int 
             }
         }
         __syncthreads();
+        if (CONV && ch + 1 < chunks_per_split && r0 + rows_chunk < R) prefetch(r0 + rows_chunk);
         if (CONV) {
             for (int rr = 0; rr < rows_pad; rr += 4) {
                 const int r = rr + q;

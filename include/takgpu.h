@@ -263,7 +263,9 @@ typedef struct TgSearchConfig {
     uint32_t slot_base;       /* global index of this engine's first game: RNG streams are keyed by
                                  (seed, slot_base + g, …) so shards on different GPUs play different,
                                  reproducible games (rank r of a sharded run passes r * games)        */
-    uint32_t reserved;
+    uint32_t batch;           /* virtual rollouts per tree and iteration before the one network call — the batching of
+                                 `Player` (player.rs:77-93; pit.rs BATCH_SIZE 16).  0 = 1 (self_play_parallel: one leaf per game).
+                                 games × batch ≤ TgConfig.max_batch */
 } TgSearchConfig;
 
 int tg_search_create(TgEngine* e, const TgSearchConfig* cfg);
@@ -403,23 +405,24 @@ int tg_train_comm_init(TgEngine* e, int rank, int world_size, const void* id128)
 /* ---------------------------------------------------------------------------------------
  * Pit (replaces `pit`, train/src/pit.rs:15-96): the new network against the old one,
  * `pairs` openings × both colours, all 2·pairs games concurrently — one engine handle per weight set, each
- * holding one tree per game (the reference gives each side its own `Player`).  The side to move searches
- * `rollouts` leaves (reference: ROLLOUTS 50 × BATCH_SIZE 16), the waiting side `idle_rollouts` (the batch a
- * `Player` keeps in flight, player.rs:65-66), moves are pick_move(exploit = true).  Openings: a1, a random far
- * corner, `random_plies` random Flat/Cap placements (pit.rs:33-63), drawn from Philox(seed).  Not reproduced:
- * `Player`'s virtual-loss batching inside one tree (one leaf per tree per iteration here) and the early exit
- * of pit.rs:20-23 (all games run at once).  The caller applies the gate (main.rs:102: win_rate > 0.55).
- * Both engines' search / self-play state is replaced (tg_search_create is called on each).
+ * holding one tree per game (the reference gives each side its own `Player`).  The side to move runs `rollouts`
+ * iterations of `batch` virtual rollouts + one evaluation (reference: ROLLOUTS 50 × Player::rollout with BATCH_SIZE 16),
+ * the waiting side `idle_rollouts` iterations (the batch a `Player` keeps in flight, player.rs:65-66), moves are
+ * pick_move(exploit = true).  Openings: a1, a random far corner, `random_plies` random Flat/Cap placements
+ * (pit.rs:33-63), drawn from Philox(seed).  Not reproduced: the early exit of pit.rs:20-23 (all games run at once) and
+ * the exact interleaving of the waiting player's stale batch with the moves.  The caller applies the gate
+ * (main.rs:102: win_rate > 0.55).  Both engines' search / self-play state is replaced (tg_search_create is called on
+ * each); 2·pairs·batch ≤ max_batch of both engines.
  * ------------------------------------------------------------------------------------- */
 typedef struct TgPitConfig {
     int32_t pairs;          /* PIT_GAMES 128 */
-    int32_t rollouts;       /* ROLLOUTS × BATCH_SIZE = 800 leaves per move */
-    int32_t idle_rollouts;  /* 16 */
+    int32_t rollouts;       /* ROLLOUTS 50 iterations per move */
+    int32_t idle_rollouts;  /* 1 */
     int32_t random_plies;   /* RANDOM_PLIES 2 */
     int32_t komi;           /* Game::with_komi(2) */
     int32_t max_plies;      /* safety cap on the game length, 0 = none */
     int32_t arena_nodes;    /* per-game tree arena of both engines, 0 = 16384 */
-    int32_t reserved;
+    int32_t batch;          /* BATCH_SIZE 16 virtual rollouts per iteration; 0 = 1 */
     uint64_t seed;
 } TgPitConfig;
 typedef struct TgPitResult {

@@ -252,12 +252,13 @@ def _wrap_eval(n, psize, py_eval):
 class Search:
     """Lock-step MCTS over independent trees (reference Node + the loop of self_play.rs:181-210)."""
 
-    def __init__(self, n, head=HEAD_CONV, evaluator=EVAL_DUMMY, py_eval=None, base=500.0, init=4.0, seed=0):
+    def __init__(self, n, head=HEAD_CONV, evaluator=EVAL_DUMMY, py_eval=None, base=500.0, init=4.0, seed=0, batch=1):
         self.n = n
         self.psize = policy_size(n, head)
         self._cb = _wrap_eval(n, self.psize, py_eval) if py_eval is not None else None
         kind = EVAL_CALLBACK if py_eval is not None else evaluator
         self.h = lib().orc_search_new(n, kind, C.cast(self._cb, C.c_void_p) if self._cb else None, None, self.psize, base, init, seed)
+        lib().orc_search_batch(C.c_void_p(self.h), int(batch))  # virtual rollouts per tree and iteration (Player's batching)
         self.games = 0
 
     def __del__(self):

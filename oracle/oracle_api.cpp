@@ -273,6 +273,7 @@ void* orc_selfplay_new(int n, int games, int eval_kind, EvalFn fn, void* ctx, in
 void orc_selfplay_free(void* h) { delete (SelfPlayHandle*)h; }
 // OpenMP threads for the per-game phases of the lock-step loop (1 = serial; results do not depend on it)
 void orc_selfplay_threads(void* hh, int threads) { ((SelfPlayHandle*)hh)->sp.s.threads = threads < 1 ? 1 : threads; }
+void orc_search_batch(void* hh, int batch) { ((SearchHandle*)hh)->s.batch = batch < 1 ? 1 : batch; }
 void orc_search_threads(void* hh, int threads) { ((SearchHandle*)hh)->s.threads = threads < 1 ? 1 : threads; }
 
 int orc_selfplay_step(void* hh, int plies) {

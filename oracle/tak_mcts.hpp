@@ -388,35 +388,49 @@ struct Search {
         generation.assign(roots.size(), 0);
     }
     int threads = 1;  // > 1: the per-game phases run under OpenMP (games are independent; results identical to 1 thread)
+    int batch = 1;    // virtual rollouts per tree and iteration before the one evaluation: Player's batching (player.rs:77-93)
 
     // one iteration for every game whose mask byte is non-zero
     void iterate(const uint8_t* active) {
-        const int G = (int)games.size();
-        std::vector<uint8_t> res(G, 0xff);
-        std::vector<Game> leaf(G);
-        std::vector<std::vector<int>> path(G);
+        const int G = (int)games.size(), B = batch < 1 ? 1 : batch;
+        std::vector<uint8_t> res((size_t)G * B, 0xff);
+        std::vector<Game> leaf((size_t)G * B);
+        std::vector<std::vector<int>> path((size_t)G * B);
         std::vector<SearchError> errs(G);
 #pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
         for (int i = 0; i < G; i++) {
             if (!alive[i] || (active && !active[i])) continue;
-            leaf[i] = games[i];  // games.clone(), self_play.rs:184
-            res[i] = virtual_rollout(nodes[i], leaf[i], path[i], sp, errs[i]);
+            for (int b = 0; b < B; b++) {  // (0..batch).filter_map(virtual_rollout), player.rs:79-90
+                const size_t k = (size_t)i * B + b;
+                leaf[k] = games[i];  // game.clone()
+                res[k] = virtual_rollout(nodes[i], leaf[k], path[k], sp, errs[i]);
+            }
         }
-        std::vector<int> idx;
+        std::vector<size_t> idx;
         std::vector<Game> for_eval;
-        for (int i = 0; i < G; i++) {
-            if (res[i] == 0xff) continue;
+        for (size_t k = 0; k < res.size(); k++) {
+            if (res[k] == 0xff) continue;
             expansions++;
-            err.merge(errs[i]);
-            if (res[i] == TG_ONGOING) { idx.push_back(i); for_eval.push_back(leaf[i]); }
+            if (res[k] == TG_ONGOING) { idx.push_back(k); for_eval.push_back(leaf[k]); }
         }
+        for (int i = 0; i < G; i++) err.merge(errs[i]);
         std::vector<std::vector<float>> policy;
         std::vector<float> eval;
         ev.run(for_eval, policy, eval);
         evals += for_eval.size();
-        const int K = (int)idx.size();
+        // de-virtualise in rollout order; the paths of one tree are handled by one thread, in order
+        std::vector<std::pair<size_t, size_t>> span(G, {0, 0});  // [first, last) into idx per game
+        {
+            size_t k = 0;
+            for (int i = 0; i < G; i++) {
+                span[i].first = k;
+                while (k < idx.size() && idx[k] / (size_t)B == (size_t)i) k++;
+                span[i].second = k;
+            }
+        }
 #pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
-        for (int k = 0; k < K; k++) devirtualize_path(nodes[idx[k]], path[idx[k]], 0, policy[k], eval[k], n);
+        for (int i = 0; i < G; i++)
+            for (size_t k = span[i].first; k < span[i].second; k++) devirtualize_path(nodes[i], path[idx[k]], 0, policy[k], eval[k], n);
     }
 };
 

@@ -29,7 +29,8 @@ def main():
     ap.add_argument("--chunks-in-step", type=int, default=4)
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--pit-pairs", type=int, default=0, help="> 0: gate every round with tg_pit (train/src/main.rs:98-106)")
-    ap.add_argument("--pit-rollouts", type=int, default=64)
+    ap.add_argument("--pit-rollouts", type=int, default=50, help="batches per move (pit.rs ROLLOUTS)")
+    ap.add_argument("--pit-batch", type=int, default=16, help="virtual rollouts per batch (pit.rs BATCH_SIZE)")
     args = ap.parse_args()
 
     import tak_amd
@@ -43,7 +44,8 @@ def main():
     eng.train_create(chunk_size=args.chunk, chunks_in_step=args.chunks_in_step)
     old = None
     if args.pit_pairs:
-        old = tak_amd.Engine(args.board, res_blocks=args.blocks, filters=args.filters, evaluator=tak_amd.EVAL_RESNET, max_batch=2 * args.pit_pairs)
+        old = tak_amd.Engine(args.board, res_blocks=args.blocks, filters=args.filters, evaluator=tak_amd.EVAL_RESNET,
+                             max_batch=2 * args.pit_pairs * args.pit_batch)
         old.load_state_dict(tensors)
     eng.selfplay_create(args.games, arena_nodes=1 << 13, seed=0, rollouts=args.rollouts, max_examples=4 * args.examples)
     report = []
@@ -66,7 +68,7 @@ def main():
         gate = None
         if old is not None:  # training_loop: keep the new network only if it beats the old one (WIN_RATE_THRESHOLD 0.55)
             t0 = time.perf_counter()
-            gate = tak_amd.pit(eng, old, pairs=args.pit_pairs, rollouts=args.pit_rollouts, idle_rollouts=16, seed=rnd, max_plies=200)
+            gate = tak_amd.pit(eng, old, pairs=args.pit_pairs, rollouts=args.pit_rollouts, batch=args.pit_batch, idle_rollouts=1, seed=rnd, max_plies=200)
             gate["seconds"] = time.perf_counter() - t0
             new_tensors = {k: eng.train_get_tensor(k, v.shape) for k, v in tensors.items()}
             if gate["win_rate"] > 0.55:

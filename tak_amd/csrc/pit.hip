@@ -1,7 +1,8 @@
 // pit.hip — batched two-network evaluation: `pit` of reference train/src/pit.rs:15-96 (and the gate of
 // train/src/main.rs:98-106) on top of the C ABI.  Host code only: it drives two engine handles (one per
 // weight set) through tg_search_*; every game of the match is played concurrently — 2·pairs lock-step games,
-// each with one tree per network — instead of the reference's one game at a time through `Player`.
+// each with one tree per network — instead of the reference's one game at a time through `Player`.  `Player`'s batching
+// (`batch` virtual rollouts per tree, then one evaluation) is TgSearchConfig.batch.
 #include <cstring>
 #include <vector>
 
@@ -34,7 +35,9 @@ extern "C" int tg_pit(TgEngine* e_new, TgEngine* e_old, const TgPitConfig* cfg, 
         return fail(TG_ERR_INVALID_ARG, "tg_pit: engines differ in board size / policy head");
     if (cfg->pairs <= 0 || cfg->rollouts <= 0 || cfg->random_plies < 0) return fail(TG_ERR_INVALID_ARG, "tg_pit: bad configuration");
     const int n = e_new->cfg.board_size, G = 2 * cfg->pairs;
-    if (G > e_new->cfg.max_batch || G > e_old->cfg.max_batch) return fail(TG_ERR_INVALID_ARG, "tg_pit: 2·pairs exceeds max_batch");
+    const int batch = cfg->batch > 0 ? cfg->batch : 1;
+    if ((long long)G * batch > e_new->cfg.max_batch || (long long)G * batch > e_old->cfg.max_batch)
+        return fail(TG_ERR_INVALID_ARG, "tg_pit: 2·pairs·batch exceeds max_batch");
     const size_t sb = tg_state_bytes(n);
     const int idle_rollouts = cfg->idle_rollouts > 0 ? cfg->idle_rollouts : 1;  // the waiting tree needs an expanded root (play.rs:35)
     std::memset(out, 0, sizeof(*out));
@@ -82,6 +85,7 @@ extern "C" int tg_pit(TgEngine* e_new, TgEngine* e_old, const TgPitConfig* cfg, 
     sc.exploration_base = 500.0f;
     sc.exploration_init = 4.0f;
     sc.seed = cfg->seed;
+    sc.batch = (uint32_t)batch;
     TgEngine* eng[2] = {e_new, e_old};
     for (TgEngine* e : eng) {
         rc = tg_search_create(e, &sc);
@@ -119,8 +123,8 @@ extern "C" int tg_pit(TgEngine* e_new, TgEngine* e_old, const TgPitConfig* cfg, 
             act[0][g] = new_to_move; idle[0][g] = alive[g] && !new_to_move;
             act[1][g] = idle[0][g];  idle[1][g] = new_to_move;
         }
-        // the side to move searches `rollouts` leaves (pit.rs:78-80: ROLLOUTS batches of BATCH_SIZE); the waiting side
-        // gets the one batch `Player` keeps in flight (player.rs:65-66,140), which also expands its root
+        // the side to move runs `rollouts` batches of `batch` virtual rollouts (pit.rs:78-80: ROLLOUTS × Player::rollout); the
+        // waiting side gets the batch `Player` keeps in flight (player.rs:65-66,140), which also expands its root
         for (int k = 0; k < 2; k++) {
             rc = tg_search_run(eng[k], cfg->rollouts, act[k].data());
             if (rc) return rc;

@@ -59,9 +59,9 @@ struct SearchDev {
     uint8_t* alive;      // [G]
     uint32_t* generation;// [G]
     // per-iteration leaf hand-off
-    int32_t* path_len;   // [G]
-    uint32_t* path;      // [G][MAX_DEPTH]
-    uint8_t* leaf_kind;  // [G] 0 skipped, 1 needs evaluation, 2 terminal (already backed up)
+    int32_t* path_len;   // [G·batch]  (every per-leaf array below has G·batch entries, slot = g·batch + pass)
+    uint32_t* path;      // [G·batch][MAX_DEPTH]
+    uint8_t* leaf_kind;  // [G·batch] 0 skipped, 1 needs evaluation, 2 terminal (already backed up)
     uint64_t* leaf_hash; // [G] (TG_EVAL_HASH)
     float* planes;       // [G][nsq][cin_pad] NHWC network input (null when the tower encodes from leaf_state)
     uint8_t* leaf_state; // [G][state bytes] packed leaf positions
@@ -74,6 +74,7 @@ struct SearchDev {
     unsigned long long* counters;  // [G][2] per game: expansions, evals (summed on read; a single shared word would
                                    // serialise 2·G same-address atomics per iteration, ≈ 11 ns each)
     int G, cap, n, cin_pad, P, ctab_size, legacy5, evaluator;
+    int batch, pass;     // virtual rollouts per tree and iteration; the one this launch performs (leaf slot = g·batch + pass)
     uint32_t slot_base;
     uint64_t seed;
 };

@@ -73,6 +73,9 @@ static int upload_mask(TgEngine* e, const uint8_t* active, const uint8_t** d_out
 static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     if (!e) return fail(TG_ERR_INVALID_ARG, "null engine");
     if (!cfg || cfg->games <= 0 || cfg->games > e->cfg.max_batch) return fail(TG_ERR_INVALID_ARG, "games must be in 1..max_batch");
+    const size_t B = cfg->batch ? cfg->batch : 1;  // virtual rollouts per tree and iteration
+    if (B > 4096 || (e->cfg.evaluator == TG_EVAL_RESNET && (size_t)cfg->games * B > (size_t)e->cfg.max_batch))
+        return fail(TG_ERR_INVALID_ARG, "games x batch leaves per iteration exceed max_batch");
     if (cfg->arena_nodes < 1024) return fail(TG_ERR_INVALID_ARG, "arena_nodes must be at least 1024");
     if (e->cfg.evaluator == TG_EVAL_RESNET && !net_ready(e)) return fail(TG_ERR_STATE, "network weights not finalized (tg_net_finalize)");
     TG_HIP(hipSetDevice(e->cfg.device));
@@ -93,10 +96,10 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     TG_HIP(s->root_state.ensure(G * e->g.bytes));
     TG_HIP(s->alive.ensure(G));
     TG_HIP(s->generation.ensure(G * 4));
-    TG_HIP(s->path_len.ensure(G * 4));
-    TG_HIP(s->path.ensure(G * MAX_DEPTH * 4));
-    TG_HIP(s->leaf_kind.ensure(G));
-    TG_HIP(s->leaf_hash.ensure(G * 8));
+    TG_HIP(s->path_len.ensure(G * B * 4));
+    TG_HIP(s->path.ensure(G * B * MAX_DEPTH * 4));
+    TG_HIP(s->leaf_kind.ensure(G * B));
+    TG_HIP(s->leaf_hash.ensure(G * B * 8));
     TG_HIP(s->op.ensure(G * 4));
     TG_HIP(s->active.ensure(G));
     TG_HIP(s->noise.ensure(G * EX_MOVES * 4));
@@ -112,12 +115,12 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     TG_HIP(s->s_moves.ensure(G * 2));
     if (e->cfg.evaluator == TG_EVAL_RESNET) {
         if (net_takes_states(e)) {
-            TG_HIP(s->leaf_state.ensure(G * e->g.bytes));
+            TG_HIP(s->leaf_state.ensure(G * B * e->g.bytes));
             TG_HIP(hipMemset(s->leaf_state.p, 0, s->leaf_state.bytes));
         } else
-        TG_HIP(s->planes.ensure(G * e->g.nsq * cin_pad * 4));
-        TG_HIP(s->policy.ensure(G * (size_t)e->policy_size * 4));
-        TG_HIP(s->eval.ensure(G * 4));
+        TG_HIP(s->planes.ensure(G * B * e->g.nsq * cin_pad * 4));
+        TG_HIP(s->policy.ensure(G * B * (size_t)e->policy_size * 4));
+        TG_HIP(s->eval.ensure(G * B * 4));
         if (s->planes.p) TG_HIP(hipMemset(s->planes.p, 0, s->planes.bytes));
     }
     // exploration_rate(n) = ln((1 + n + base) / base) + init for integer visit counts (mcts.rs:10-12),
@@ -144,6 +147,7 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     d.counters = s->counters.as<unsigned long long>();
     d.G = cfg->games; d.cap = cfg->arena_nodes; d.n = e->g.n; d.cin_pad = cin_pad; d.P = e->policy_size; d.ctab_size = ctab_size;
     d.legacy5 = e->legacy5 ? 1 : 0; d.evaluator = e->cfg.evaluator; d.slot_base = cfg->slot_base; d.seed = cfg->seed;
+    d.batch = (int)B; d.pass = 0;
     e->search = sp.release();
     return TG_OK;
 }
@@ -164,14 +168,25 @@ static int search_reset_trees(TgEngine* e) {
 // one lock-step iteration: the body of train/src/self_play.rs:181-210
 static int search_iterate(TgEngine* e, const uint8_t* d_active) {
     Search* s = e->search;
-    launch_select(e->stream, s->d, d_active);
+    // `batch` virtual rollouts per tree (Player's batching model, alpha-tak/src/player.rs:77-93) are `batch` launches of the
+    // select kernel — the kernel boundary orders a pass's tree updates before the next pass reads them — then ONE network
+    // batch of games × batch leaves, then the de-virtualisations in the same order
+    SearchDev d = s->d;
+    for (int b = 0; b < s->d.batch; b++) {
+        d.pass = b;
+        launch_select(e->stream, d, d_active);
+    }
     TG_HIP(hipGetLastError());
     if (e->cfg.evaluator == TG_EVAL_RESNET) {
-        int rc = s->d.planes ? net_forward_dev(e, s->d.G, s->d.planes, s->d.policy, s->d.eval)
-                             : net_forward_states_dev(e, s->d.G, s->d.leaf_state, s->d.policy, s->d.eval);
+        const int leaves = s->d.G * s->d.batch;
+        int rc = s->d.planes ? net_forward_dev(e, leaves, s->d.planes, s->d.policy, s->d.eval)
+                             : net_forward_states_dev(e, leaves, s->d.leaf_state, s->d.policy, s->d.eval);
         if (rc) return rc;
     }
-    launch_backup(e->stream, s->d);
+    for (int b = 0; b < s->d.batch; b++) {
+        d.pass = b;
+        launch_backup(e->stream, d);
+    }
     TG_HIP(hipGetLastError());
     return TG_OK;
 }
@@ -198,7 +213,7 @@ static bool dual_stream_ok(TgEngine* e) {
     // the half-batch MFMA kernels fill the chip less well than they overlap; kept opt-in
     static const bool on = getenv("TG_DUAL_STREAM") != nullptr;
     Search* s = e->search;
-    return on && e->cfg.evaluator == TG_EVAL_RESNET && !s->d.planes && net_takes_states(e) && s->d.G >= 512;
+    return on && s->d.batch == 1 && e->cfg.evaluator == TG_EVAL_RESNET && !s->d.planes && net_takes_states(e) && s->d.G >= 512;
 }
 
 static int search_iterate_many(TgEngine* e, int iters) {
@@ -463,7 +478,9 @@ int tg_search_counters(TgEngine* e, uint64_t* expansions, uint64_t* evals) {
 int tg_selfplay_create(TgEngine* e, const TgSearchConfig* scfg, const TgSelfPlayConfig* cfg) {
     if (!cfg) return fail(TG_ERR_INVALID_ARG, "null self-play config");
     if (cfg->rollouts < 1 || cfg->max_examples < 1) return fail(TG_ERR_INVALID_ARG, "rollouts and max_examples must be positive");
-    int rc = search_alloc(e, scfg);
+    TgSearchConfig sc1 = *scfg;
+    sc1.batch = 1;  // self_play_parallel gathers ONE leaf per game and iteration (self_play.rs:181-210)
+    int rc = search_alloc(e, &sc1);
     if (rc) return rc;
     Search* s = e->search;
     s->selfplay = true;

@@ -54,8 +54,11 @@ __global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __re
     const int g = game_of_wave();
     if (g >= S.G) return;
     const int lane = lane_id();
+    // leaf slot of this pass: `batch` virtual rollouts per tree and iteration (Player's batching, player.rs:77-93) are `batch`
+    // launches of this kernel, pass S.pass writing slot g·batch + pass
+    const size_t slot = (size_t)g * (size_t)S.batch + (size_t)S.pass;
     if (!S.alive[g] || (active && !active[g])) {
-        if (lane == 0) S.leaf_kind[g] = 0;
+        if (lane == 0) S.leaf_kind[slot] = 0;
         return;
     }
     const Geom geo = make_geom(S.n);
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __re
                 });
                 if ((int)count > room || count > 0xfffu) {
                     flag(S, ERRF_ARENA);
-                    if (lane == 0) S.leaf_kind[g] = 0;
+                    if (lane == 0) S.leaf_kind[slot] = 0;
                     return;
                 }
                 float temp_policy = 1.0f / (float)count;
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __re
         if (__ballot(nan)) flag(S, ERRF_NAN);
         if (wi < 0) {  // cannot happen for a consistent tree; never index out of the arena
             flag(S, ERRF_NAN);
-            if (lane == 0) S.leaf_kind[g] = 0;
+            if (lane == 0) S.leaf_kind[slot] = 0;
             return;
         }
         // the winning lane (the one whose own best is the wave's best) hands its child's records down
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __re
         ws_play(s, mv, geo);
         if (depth >= MAX_DEPTH) {
             flag(S, ERRF_DEPTH);
-            if (lane == 0) S.leaf_kind[g] = 0;
+            if (lane == 0) S.leaf_kind[slot] = 0;
             return;
         }
         if (lane == 0) path[depth] = chosen;
@@ -191,21 +194,21 @@ __global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __re
         }
         hot[nd] = h;
     }
-    uint32_t* gpath = S.path + (size_t)g * MAX_DEPTH;
+    uint32_t* gpath = S.path + slot * MAX_DEPTH;
     for (int d = lane; d < depth; d += 64) gpath[d] = path[d];
     if (!terminal) {
         if (S.evaluator == TG_EVAL_RESNET) {
-            if (S.planes) ws_encode<true>(s, geo, S.planes + (size_t)g * geo.nsq * S.cin_pad, S.cin_pad);
-            else ws_store(s, S.leaf_state + (size_t)g * geo.bytes, geo);  // game_repr happens inside the fused tower
+            if (S.planes) ws_encode<true>(s, geo, S.planes + slot * geo.nsq * S.cin_pad, S.cin_pad);
+            else ws_store(s, S.leaf_state + slot * geo.bytes, geo);  // game_repr happens inside the fused tower
         }
         else if (S.evaluator == TG_EVAL_HASH) {
             uint64_t h = ws_hash(s, geo);
-            if (lane == 0) S.leaf_hash[g] = h;
+            if (lane == 0) S.leaf_hash[slot] = h;
         }
     }
     if (lane == 0) {
-        S.path_len[g] = depth;
-        S.leaf_kind[g] = terminal ? 2 : 1;
+        S.path_len[slot] = depth;
+        S.leaf_kind[slot] = terminal ? 2 : 1;
         S.counters[2 * (size_t)g] += 1ull;
         if (!terminal) S.counters[2 * (size_t)g + 1] += 1ull;
     }
@@ -218,22 +221,23 @@ __global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __re
 __global__ __launch_bounds__(256) void k_backup(SearchDev S) {
     const int g = game_of_wave();
     if (g >= S.G) return;
-    if (S.leaf_kind[g] != 1) return;
+    const size_t slot = (size_t)g * (size_t)S.batch + (size_t)S.pass;
+    if (S.leaf_kind[slot] != 1) return;
     const int lane = lane_id();
     const size_t base = ((size_t)g * 2 + S.sel[g]) * (size_t)S.cap;
     NodeHot* hot = S.hot + base;
     NodeCold* cold = S.cold + base;
-    const uint32_t* path = S.path + (size_t)g * MAX_DEPTH;
-    const int L = S.path_len[g];
+    const uint32_t* path = S.path + slot * MAX_DEPTH;
+    const int L = S.path_len[slot];
     const uint32_t leaf = L ? path[L - 1] : 0u;
     NodeCold lc = cold[leaf];
     const uint32_t nchild = uni((uint32_t)lc.nres) & 0xfffu, cb = uni(lc.child);
     float e;
     uint64_t hsh = 0;
-    if (S.evaluator == TG_EVAL_RESNET) e = S.eval[g];
-    else if (S.evaluator == TG_EVAL_HASH) { hsh = S.leaf_hash[g]; e = hash_eval(hsh); }
+    if (S.evaluator == TG_EVAL_RESNET) e = S.eval[slot];
+    else if (S.evaluator == TG_EVAL_HASH) { hsh = S.leaf_hash[slot]; e = hash_eval(hsh); }
     else e = 0.0f;
-    const float* pol = S.policy + (size_t)g * S.P;
+    const float* pol = S.policy + slot * S.P;
     bool bad = false;
     for (uint32_t i = lane; i < nchild; i += 64) {
         uint32_t mv = cold[cb + i].mv;

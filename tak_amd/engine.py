@@ -32,7 +32,7 @@ class TgConfig(C.Structure):
 
 class TgSearchConfig(C.Structure):
     _fields_ = [("games", C.c_int32), ("arena_nodes", C.c_int32), ("exploration_base", C.c_float),
-                ("exploration_init", C.c_float), ("seed", C.c_uint64), ("slot_base", C.c_uint32), ("reserved", C.c_uint32)]
+                ("exploration_init", C.c_float), ("seed", C.c_uint64), ("slot_base", C.c_uint32), ("batch", C.c_uint32)]
 
 
 class TgProfile(C.Structure):
@@ -65,7 +65,7 @@ class TgTrainConfig(C.Structure):
 
 class TgPitConfig(C.Structure):
     _fields_ = [("pairs", C.c_int32), ("rollouts", C.c_int32), ("idle_rollouts", C.c_int32), ("random_plies", C.c_int32),
-                ("komi", C.c_int32), ("max_plies", C.c_int32), ("arena_nodes", C.c_int32), ("reserved", C.c_int32),
+                ("komi", C.c_int32), ("max_plies", C.c_int32), ("arena_nodes", C.c_int32), ("batch", C.c_int32),
                 ("seed", C.c_uint64)]
 
 
@@ -197,9 +197,10 @@ def comm_unique_id():
     return uid.tobytes()
 
 
-def pit(new, old, pairs=128, rollouts=800, idle_rollouts=16, random_plies=2, komi=2, max_plies=0, arena_nodes=0, seed=0):
-    """`pit(new, old)` of train/src/pit.rs on two engines (one per weight set) → dict(wins, losses, draws, win_rate, …)"""
-    cfg = TgPitConfig(pairs, rollouts, idle_rollouts, random_plies, komi, max_plies, arena_nodes, 0, seed)
+def pit(new, old, pairs=128, rollouts=50, batch=16, idle_rollouts=1, random_plies=2, komi=2, max_plies=0, arena_nodes=0, seed=0):
+    """`pit(new, old)` of train/src/pit.rs on two engines (one per weight set) → dict(wins, losses, draws, win_rate, …);
+    `rollouts` iterations of `batch` virtual rollouts per move (ROLLOUTS × BATCH_SIZE); 2·pairs·batch ≤ max_batch"""
+    cfg = TgPitConfig(pairs, rollouts, idle_rollouts, random_plies, komi, max_plies, arena_nodes, batch, seed)
     res = TgPitResult()
     rc = load_library().tg_pit(new.h, old.h, C.byref(cfg), C.byref(res))
     if rc:
@@ -404,8 +405,9 @@ class Engine:
         self._check(self.lib.tg_policy_eval_dev(self.h, n, C.c_void_p(d_states), C.c_void_p(d_policy), C.c_void_p(d_eval)))
 
     # ---- Node / search ----------------------------------------------------------------------------
-    def search_create(self, games, arena_nodes=1 << 16, base=500.0, init=4.0, seed=0, slot_base=0):
-        cfg = TgSearchConfig(games, arena_nodes, base, init, seed, slot_base, 0)
+    def search_create(self, games, arena_nodes=1 << 16, base=500.0, init=4.0, seed=0, slot_base=0, batch=1):
+        """batch: virtual rollouts per tree and iteration (Player's batching); games * batch <= max_batch"""
+        cfg = TgSearchConfig(games, arena_nodes, base, init, seed, slot_base, batch)
         self._check(self.lib.tg_search_create(self.h, C.byref(cfg)))
         self.games = games
 

@@ -2,10 +2,10 @@
 the analysis tools use for ONE game: rollout / add_noise / pick_move / play_move / get_examples.
 
 The reference overlaps a rollout thread with the network call (one batch of virtual rollouts always in flight).  Here the
-tree lives on the GPU; `rollout` runs `batch` lock-step iterations of the one-game search (one leaf per iteration — the
-16-leaf virtual-loss batches inside one tree are not reproduced), so this class is about API parity, not
-throughput: throughput comes from many concurrent games (tg_selfplay_*, tg_pit).  Several Players can share one engine only
-one at a time (the engine holds one search state)."""
+tree lives on the GPU and `rollout` is one iteration of the one-game search with TgSearchConfig.batch = `batch`: `batch` virtual
+rollouts in the tree, one network call for the leaves that are not terminal, de-virtualisation in order — the same tree
+updates as Player::rollout (player.rs:77-110, 125-128), without the thread.  The engine's max_batch must be ≥ batch.  Several
+Players can share one engine only one at a time (the engine holds one search state)."""
 import numpy as np
 
 from .engine import TG_MAX_MOVES
@@ -19,7 +19,7 @@ class Player:
         self.save_examples = bool(save_examples)
         self.examples = []  # IncompleteExample: (state, moves, visits)
         self.rng = np.random.default_rng(seed)
-        engine.search_create(1, arena_nodes=arena_nodes, seed=seed)
+        engine.search_create(1, arena_nodes=arena_nodes, seed=seed, batch=self.batch)
         engine.search_reset(np.ascontiguousarray(game, np.uint8).reshape(1, -1))
         self.rollout()  # the reference requests the first batch in the constructor (player.rs:65-66)
 
@@ -27,8 +27,8 @@ class Player:
         return self.e.search_states()[0]
 
     def rollout(self, game=None):
-        """`batch` rollouts from the current root (player.rs:125-128)."""
-        self.e.search_run(self.batch)
+        """One batch of `batch` virtual rollouts from the current root (player.rs:125-128)."""
+        self.e.search_run(1)
 
     def add_noise(self, alpha, ratio, game=None):
         """Node::apply_dirichlet on the root (player.rs:118-122)."""

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 RNG_PIT_CORNER, RNG_PIT_RANDOM = 8, 9
 
 
-def _oracle_pit(orc, n, evals, pairs, rollouts, idle, random_plies, komi, seed, max_plies=0):
+def _oracle_pit(orc, n, evals, pairs, rollouts, idle, random_plies, komi, seed, max_plies=0, batch=1):
     head = orc.HEAD_FC5 if n == 5 else orc.HEAD_CONV
     op = np.stack([orc.new_game(n, half_komi=2 * komi) for _ in range(pairs)])
     for ply in range(2 + random_plies):
@@ -29,7 +29,7 @@ def _oracle_pit(orc, n, evals, pairs, rollouts, idle, random_plies, komi, seed, 
         assert not status.any()
     G = 2 * pairs
     states = np.repeat(op, 2, axis=0)
-    trees = [orc.Search(n, head=head, evaluator=ev, seed=seed) for ev in evals]
+    trees = [orc.Search(n, head=head, evaluator=ev, seed=seed, batch=batch) for ev in evals]
     for t in trees:
         t.reset(states)
     alive = np.ones(G, bool)
@@ -70,16 +70,17 @@ def _oracle_pit(orc, n, evals, pairs, rollouts, idle, random_plies, komi, seed, 
     return dict(wins=wins, losses=losses, draws=draws, plies=plies, unfinished=int(alive.sum()))
 
 
-@pytest.mark.parametrize("n,pairs,rollouts", [(4, 6, 40), (5, 5, 30)])
-def test_pit_matches_oracle_replay(orc, n, pairs, rollouts):
+@pytest.mark.parametrize("n,pairs,rollouts,batch", [(4, 6, 40, 1), (5, 5, 30, 1), (5, 4, 6, 8)])
+def test_pit_matches_oracle_replay(orc, n, pairs, rollouts, batch):
     import tak_amd
 
     head = tak_amd.HEAD_FC5 if n == 5 else tak_amd.HEAD_CONV
     new = tak_amd.Engine(n, evaluator=tak_amd.EVAL_HASH, max_batch=64, policy_head=head)
     old = tak_amd.Engine(n, evaluator=tak_amd.EVAL_DUMMY, max_batch=64, policy_head=head)
-    kw = dict(pairs=pairs, rollouts=rollouts, idle_rollouts=4, random_plies=2, komi=2, seed=11, max_plies=60)
-    got = tak_amd.pit(new, old, arena_nodes=1 << 14, **kw)
-    want = _oracle_pit(orc, n, (orc.EVAL_HASH, orc.EVAL_DUMMY), kw["pairs"], kw["rollouts"], kw["idle_rollouts"], 2, 2, 11, max_plies=60)
+    kw = dict(pairs=pairs, rollouts=rollouts, batch=batch, idle_rollouts=4 if batch == 1 else 1, random_plies=2, komi=2, seed=11, max_plies=60)
+    got = tak_amd.pit(new, old, arena_nodes=1 << 16, **kw)
+    want = _oracle_pit(orc, n, (orc.EVAL_HASH, orc.EVAL_DUMMY), kw["pairs"], kw["rollouts"], kw["idle_rollouts"], 2, 2, 11, max_plies=60,
+                       batch=batch)
     for k in ("wins", "losses", "draws", "plies", "unfinished"):
         assert got[k] == want[k], (got, want)
     assert got["wins"] + got["losses"] + got["draws"] + got["unfinished"] == 2 * pairs
@@ -94,7 +95,7 @@ def test_identical_networks_split_every_pair(orc):
 
     a = tak_amd.Engine(5, evaluator=tak_amd.EVAL_HASH, max_batch=64)
     b = tak_amd.Engine(5, evaluator=tak_amd.EVAL_HASH, max_batch=64)
-    r = tak_amd.pit(a, b, pairs=16, rollouts=24, idle_rollouts=24, seed=3, max_plies=80)
+    r = tak_amd.pit(a, b, pairs=16, rollouts=12, batch=2, idle_rollouts=12, seed=3, max_plies=80)
     # same evaluator, same budget on both sides → the two games of a pair are the same game with the roles swapped
     assert r["wins"] == r["losses"] and r["draws"] % 2 == 0 and r["unfinished"] % 2 == 0
     with pytest.raises(tak_amd.TgError):

@@ -206,6 +206,57 @@ def test_tree_parity_on_the_bf16x3_path(orc, n, blocks, filters, head):
     ev.close()
 
 
+@pytest.mark.parametrize("n,games,batch,iters", [(4, 6, 4, 60), (5, 5, 16, 40), (3, 3, 8, 50)])
+def test_batched_virtual_rollouts_match_oracle(orc, n, games, batch, iters):
+    # Player's batching (player.rs:77-93): `batch` virtual rollouts per tree, ONE evaluation batch, de-virtualisation in order.
+    # Later rollouts of a batch see the virtual visits (and the temporary uniform priors) the earlier ones left.
+    import tak_amd
+
+    e = _mk(n, tak_amd.EVAL_HASH, games * batch)
+    e.search_create(games, arena_nodes=1 << 17, batch=batch)
+    s = orc.Search(n, head=orc.HEAD_FC5 if n == 5 else orc.HEAD_CONV, evaluator=orc.EVAL_HASH, batch=batch)
+    sts = _roots(orc, n, games, seed=12, max_plies=20 if n > 3 else 4)
+    e.search_reset(sts)
+    s.reset(sts)
+    e.search_run(iters)
+    s.run(iters)
+    _assert_same_trees(e, s, games)
+    assert e.search_counters()[0] == games * batch * iters == s.counters()[0]
+    # advance every game by its most visited move and keep searching the reused trees
+    r = e.search_root()
+    mv = np.array([_best(r, g) for g in range(games)], np.uint16)
+    e.search_play(mv)
+    s.play(mv)
+    e.search_run(10)
+    s.run(10)
+    _assert_same_trees(e, s, games)
+    e.close()
+
+
+def test_batched_rollouts_with_real_network(orc):
+    import tak_amd
+
+    n, blocks, filters, games, batch = 5, 2, 64, 4, 16
+    net = torch_ref.make_net(n, blocks, filters, "fc5", seed=5)
+    tensors = torch_ref.abi_tensors(net)
+    e = _mk(n, tak_amd.EVAL_RESNET, games * batch, res_blocks=blocks, filters=filters)
+    e.load_state_dict(tensors)
+    ev = _mk(n, tak_amd.EVAL_RESNET, games * batch, res_blocks=blocks, filters=filters)
+    ev.load_state_dict(tensors)
+    e.search_create(games, arena_nodes=1 << 17, batch=batch)
+    s = orc.Search(n, head=orc.HEAD_FC5, py_eval=lambda st: ev.policy_eval(st), batch=batch)
+    sts = _roots(orc, n, games, seed=14, max_plies=25)
+    e.search_reset(sts)
+    s.reset(sts)
+    e.search_run(30)
+    s.run(30)
+    _assert_same_trees(e, s, games)
+    with pytest.raises(tak_amd.TgError):
+        e.search_create(games, batch=2 * batch)  # games x batch > max_batch
+    e.close()
+    ev.close()
+
+
 def test_dirichlet_spec_matches_oracle(orc):
     import tak_amd
 

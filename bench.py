@@ -118,8 +118,12 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible — the engine has no CPU fallback", file=sys.stderr)
         sys.exit(2)
+    # TAK_BENCH_BACKEND=gloo rehearses the N>1 path with several ranks on ONE card (RCCL refuses two ranks per device)
+    backend = os.environ.get("TAK_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    dist = tdist.init("nccl", rank, world, device=torch.device("cuda", local_rank))
+    dist = tdist.init(backend, rank, world, device=torch.device("cuda", local_rank) if backend == "nccl" else None)
 
     import tak_amd
 
@@ -164,7 +168,7 @@ def main():
         return dt_local, s1["expansions"] - s0["expansions"], s1["evals"] - s0["evals"], prof
 
     dt_local, expansions, evals, prof = run(args.precision, args.profile_every)
-    dt, total_exp = tdist.reduce_time_and_count(dist, dt_local, expansions, device="cuda")
+    dt, total_exp = tdist.reduce_time_and_count(dist, dt_local, expansions, device="cuda" if backend == "nccl" else "cpu")
 
     if rank == 0:
         out = {

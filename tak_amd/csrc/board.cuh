@@ -282,6 +282,33 @@ __device__ inline int enum_spreads(int max_carry, int free_run, bool smash, F&& 
     return count;
 }
 
+// Number of patterns enum_spreads emits, in closed form: pickup k in p parts ↔ choosing p-1 of the k-1 gaps, all p ≤ free_run
+// count; a smash needs p = free_run+1 with the last part = 1 (C(k-2, free_run-1) ways, or the single stone when k = 1).
+struct SpreadCountTable {
+    uint8_t c[9][8][2];
+    constexpr SpreadCountTable() : c() {
+        int binom[9][9] = {};
+        for (int a = 0; a < 9; a++) {
+            binom[a][0] = 1;
+            for (int b = 1; b <= a; b++) binom[a][b] = binom[a - 1][b - 1] + (b <= a - 1 ? binom[a - 1][b] : 0);
+        }
+        for (int mc = 0; mc < 9; mc++)
+            for (int fr = 0; fr < 8; fr++)
+                for (int sm = 0; sm < 2; sm++) {
+                    int total = 0;
+                    for (int k = 1; k <= mc; k++) {
+                        for (int p = 1; p <= k && p <= fr; p++) total += binom[k - 1][p - 1];
+                        if (sm && fr + 1 <= k) total += k == 1 ? 1 : (fr >= 1 ? binom[k - 2][fr - 1] : 0);
+                    }
+                    c[mc][fr][sm] = (uint8_t)total;
+                }
+    }
+};
+__device__ inline int spread_count(int max_carry, int free_run, bool smash) {
+    static constexpr SpreadCountTable T{};
+    return T.c[max_carry][free_run][smash ? 1 : 0];
+}
+
 __device__ inline int wave_inclusive_scan(int v) {
     int lane = lane_id();
 #pragma unroll
@@ -344,7 +371,7 @@ __device__ inline int ws_movegen(const WState& s, const Geom& g, int cap, F&& em
         int cnt = 0;
         if (kind == 1) cnt = 1;
         else if (kind == 2) cnt = (stones > 0 ? 2 : 0) + (caps > 0 ? 1 : 0);
-        else if (kind == 3) cnt = enum_spreads(max_carry, free_run, smash, [](int, uint32_t) {});
+        else if (kind == 3) cnt = spread_count(max_carry, free_run, smash);
         int incl = wave_inclusive_scan(cnt);
         int off = base + incl - cnt;
         if (kind == 1) {

@@ -76,3 +76,26 @@ def test_selfplay_small(orc):
             break
     hdr2, states2, moves2, visits2 = sp2.drain(100000)
     assert np.array_equal(hdr, hdr2) and np.array_equal(states, states2) and np.array_equal(visits, visits2)
+
+
+def test_dirichlet_noise_distribution(orc):
+    """apply_dirichlet (alpha-tak/src/search/noise.rs:6-16) draws from rand_distr::Dirichlet with thread_rng — only the
+    DISTRIBUTION can be compared.  The counter-based replacement must have Dirichlet(α·1) marginals: each component is
+    Beta(α, (K-1)α): mean 1/K, variance (1/K)(1-1/K)/(Kα+1); components sum to 1."""
+    import numpy as np
+
+    alpha, k, draws = 0.2, 30, 4000
+    x = np.stack([orc.dirichlet(k, alpha, 77, g, 0, 3) for g in range(draws)]).astype(np.float64)
+    assert np.all(x >= 0) and np.allclose(x.sum(1), 1.0, atol=1e-5)
+    mean, var = 1.0 / k, (1.0 / k) * (1 - 1.0 / k) / (k * alpha + 1)
+    # standard error of the mean of one component over `draws` samples = sqrt(var/draws); 5 sigma over 30 components
+    assert np.all(np.abs(x.mean(0) - mean) < 5 * np.sqrt(var / draws))
+    assert abs(x.var(0).mean() - var) < 0.05 * var
+    # against an independent sampler (numpy's Dirichlet): the mean of the largest component and the quantiles of one component
+    ref = np.random.default_rng(0).dirichlet([alpha] * k, 20000)
+    assert abs(x.max(1).mean() - ref.max(1).mean()) < 0.01
+    qs = [0.5, 0.75, 0.9, 0.97]
+    assert np.allclose(np.quantile(x.ravel(), qs), np.quantile(ref.ravel(), qs), rtol=0.08, atol=2e-4)
+    # different streams (slot, generation, ply) are different draws; the same key is the same draw
+    assert not np.array_equal(orc.dirichlet(k, alpha, 77, 0, 0, 3), orc.dirichlet(k, alpha, 77, 0, 1, 3))
+    assert np.array_equal(orc.dirichlet(k, alpha, 77, 5, 2, 9), orc.dirichlet(k, alpha, 77, 5, 2, 9))

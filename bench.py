@@ -94,7 +94,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=6)
     ap.add_argument("--filters", type=int, default=64)
     ap.add_argument("--head", default="fc5", choices=["fc5", "conv"])
-    ap.add_argument("--arena", type=int, default=1 << 17, help="MCTS nodes per game arena")
+    ap.add_argument("--arena", type=int, default=0,
+                    help="MCTS nodes per game arena; 0 = 2^17 for runs of up to 120 plies, 2^19 beyond (retained subtrees grow with the ply, DESIGN.md)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-games", type=int, default=256)
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -129,6 +130,8 @@ def main():
 
     net, tensors = make_weights(args.board, args.blocks, args.filters, args.head, seed=args.seed)
     steps_total = args.steps + args.warmup
+    if args.arena <= 0:
+        args.arena = 1 << 17 if steps_total <= 120 else 1 << 19
 
     def barrier(eng):
         eng.sync()

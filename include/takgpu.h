@@ -221,6 +221,12 @@ int tg_perft(TgEngine* e, int n, const void* states, int depth, uint64_t* counts
  * "policy.weight" "policy.bias" (FC5: [1575, F*25]; CONV: [ch, F, 3, 3]); "value.weight"
  * "value.bias" ([1, F*N*N]).  Creation order of net5.rs:29-62 / net6.rs:29-57. */
 int tg_net_set_tensor(TgEngine* e, const char* name, const float* data, size_t count);
+/* Network::default() (net5.rs:29-73 / net6.rs:29-69): fill every tensor with tch's default initialisers (conv: weight
+ * U(±1/sqrt(fan_in)), bias 0; BatchNorm: weight U(0,1), bias 0, mean 0, var 1; linear: weight and bias U(±1/sqrt(in))),
+ * drawn from Philox(seed).  The reference draws from libtorch's global generator: same distribution, other values. */
+int tg_net_init_random(TgEngine* e, uint64_t seed);
+/* read back a tensor (tch layout) as last set / initialised / committed by the trainer — what Network::save writes */
+int tg_net_get_tensor(TgEngine* e, const char* name, float* out, size_t count);
 /* Fold BN (eval mode, eps 1e-5) into the convs, re-layout for the MFMA kernels, upload. */
 int tg_net_finalize(TgEngine* e);
 /* Arithmetic of the residual tower (call before tg_net_finalize).
@@ -247,8 +253,8 @@ int tg_policy_eval_dev(TgEngine* e, int n, const void* d_states, float* d_policy
 /* ---------------------------------------------------------------------------------------
  * Search (replaces Node + Node::{virtual_rollout, devirtualize_path, select, apply_dirichlet,
  * pick_move, play}, alpha-tak/src/search/{node,mcts,noise,play}.rs) for `games` independent
- * trees stepped in lock-step, one leaf per game per iteration — the loop body of
- * train/src/self_play.rs:181-210.
+ * trees stepped in lock-step, `batch` leaves per game per iteration (1 = the loop body of
+ * train/src/self_play.rs:181-210; 16 = Player::rollout, player.rs:77-110).
  * ------------------------------------------------------------------------------------- */
 typedef struct TgSearchConfig {
     int32_t games;            /* concurrent games (≤ cfg.max_batch)                          */

@@ -8,6 +8,7 @@
 
 #include "engine.h"
 #include "kernels.h"
+#include "rng.cuh"
 
 namespace tg {
 
@@ -476,6 +477,68 @@ extern "C" {
 
 int tg_net_set_tensor(TgEngine* e, const char* name, const float* data, size_t count) { return net_set_tensor(e, name, data, count); }
 int tg_net_finalize(TgEngine* e) { return net_finalize(e); }
+
+// Network::default() (net5.rs:29-73 / net6.rs:29-69): every layer with tch's default initialisers — conv2d: weight
+// KaimingUniform = U(±1/sqrt(fan_in)), bias 0; batch_norm2d: weight U(0,1), bias 0, running mean 0 / var 1; linear: weight
+// KaimingUniform, bias U(±1/sqrt(in)).  (tch 0.7 is not vendored in the reference: these are its documented defaults; only the
+// distribution matters.)  Draws come from Philox(seed; tensor index, element index).
+int tg_net_init_random(TgEngine* e, uint64_t seed) {
+    if (!e || !e->net) return fail(TG_ERR_STATE, "engine has no network (evaluator is not TG_EVAL_RESNET)");
+    Net* n = e->net;
+    const int F = e->cfg.filters, R = e->cfg.res_blocks, nsq = e->g.nsq;
+    uint32_t tensor_id = 0;
+    auto uniform = [&](const std::string& name, size_t count, float lo, float hi) {
+        std::vector<float> v(count);
+        for (size_t i = 0; i < count; i += 4) {
+            U4 r = philox4x32_10(seed, tensor_id, (uint32_t)(i >> 2), (uint32_t)((uint64_t)i >> 34), 0x696e6974u);
+            for (size_t k = 0; k < 4 && i + k < count; k++) v[i + k] = lo + (hi - lo) * ((float)(r.v[k] >> 8) * (1.0f / 16777216.0f));
+        }
+        n->tensors[name] = std::move(v);
+        tensor_id++;
+    };
+    auto constant = [&](const std::string& name, size_t count, float c) { n->tensors[name] = std::vector<float>(count, c); };
+    auto conv = [&](const std::string& name, int O, int I) {
+        float b = 1.0f / std::sqrt((float)(I * 9));
+        uniform(name + ".weight", (size_t)O * I * 9, -b, b);
+        constant(name + ".bias", O, 0.0f);
+    };
+    auto bn = [&](const std::string& name) {
+        uniform(name + ".weight", F, 0.0f, 1.0f);
+        constant(name + ".bias", F, 0.0f);
+        constant(name + ".running_mean", F, 0.0f);
+        constant(name + ".running_var", F, 1.0f);
+    };
+    auto linear = [&](const std::string& name, int out, int in) {
+        float b = 1.0f / std::sqrt((float)in);
+        uniform(name + ".weight", (size_t)out * in, -b, b);
+        uniform(name + ".bias", out, -b, b);
+    };
+    conv("conv0", F, e->cin);
+    bn("bn0");
+    for (int i = 0; i < R; i++) {
+        std::string r = "res" + std::to_string(i);
+        conv(r + ".conv1", F, F);
+        conv(r + ".conv2", F, F);
+        bn(r + ".bn1");
+        bn(r + ".bn2");
+    }
+    if (e->cfg.policy_head == TG_HEAD_FC5) linear("policy", e->policy_size, F * nsq);
+    else conv("policy", e->policy_size / nsq, F);
+    linear("value", 1, F * nsq);
+    n->ready = false;
+    return TG_OK;
+}
+
+// the tensor as last given to tg_net_set_tensor / tg_net_init_random / tg_train_commit (Network::save reads these)
+int tg_net_get_tensor(TgEngine* e, const char* name, float* out, size_t count) {
+    if (!e || !e->net) return fail(TG_ERR_STATE, "engine has no network (evaluator is not TG_EVAL_RESNET)");
+    if (!name || !out) return fail(TG_ERR_INVALID_ARG, "tg_net_get_tensor: null argument");
+    auto it = e->net->tensors.find(name);
+    if (it == e->net->tensors.end()) return fail(TG_ERR_INVALID_ARG, (std::string("tg_net_get_tensor: no tensor ") + name).c_str());
+    if (it->second.size() != count) return fail(TG_ERR_INVALID_ARG, (std::string("tg_net_get_tensor: ") + name + " has " + std::to_string(it->second.size()) + " elements").c_str());
+    std::memcpy(out, it->second.data(), count * sizeof(float));
+    return TG_OK;
+}
 int tg_net_set_precision(TgEngine* e, int precision) {
     if (!e || !e->net) return fail(TG_ERR_STATE, "engine has no network (evaluator is not TG_EVAL_RESNET)");
     if (precision != TG_PRECISION_F32 && precision != TG_PRECISION_BF16X3) return fail(TG_ERR_INVALID_ARG, "unknown precision");

@@ -81,7 +81,7 @@ class TgPitResult(C.Structure):
 ABI_SYMBOLS = [
     "tg_state_bytes", "tg_engine_create", "tg_engine_destroy", "tg_last_error", "tg_sync", "tg_stream",
     "tg_input_channels", "tg_policy_size", "tg_movegen", "tg_play", "tg_result", "tg_encode", "tg_move_index",
-    "tg_perft", "tg_net_set_tensor", "tg_net_finalize", "tg_net_set_precision", "tg_policy_eval", "tg_forward_mcts", "tg_policy_eval_dev",
+    "tg_perft", "tg_net_set_tensor", "tg_net_init_random", "tg_net_get_tensor", "tg_net_finalize", "tg_net_set_precision", "tg_policy_eval", "tg_forward_mcts", "tg_policy_eval_dev",
     "tg_search_create", "tg_search_reset", "tg_search_run", "tg_search_apply_dirichlet", "tg_search_apply_noise",
     "tg_search_root", "tg_search_play", "tg_search_states", "tg_search_dump", "tg_search_counters",
     "tg_selfplay_create", "tg_selfplay_step", "tg_selfplay_stats", "tg_selfplay_drain",
@@ -378,6 +378,18 @@ class Engine:
     def set_precision(self, precision):
         """"f32" (exact, default) or "bf16x3" (split-bf16 tower); takes effect at the next load_state_dict / finalize"""
         self._check(self.lib.tg_net_set_precision(self.h, {"f32": 0, "bf16x3": 1}[precision]))
+
+    def init_random(self, seed=0, finalize=True):
+        """Network::default(): tch's default initialisers drawn from Philox(seed) (tg_net_init_random)."""
+        self._check(self.lib.tg_net_init_random(self.h, C.c_uint64(seed)))
+        if finalize:
+            self._check(self.lib.tg_net_finalize(self.h))
+
+    def get_tensor(self, name, shape):
+        """the tensor as last set / initialised / committed (tg_net_get_tensor) — what Network::save writes"""
+        out = np.zeros(shape, np.float32)
+        self._check(self.lib.tg_net_get_tensor(self.h, name.encode(), _p(out), C.c_size_t(out.size)))
+        return out
 
     def load_state_dict(self, tensors):
         """tensors: {name: array} with the names of include/takgpu.h (tch layouts)."""

@@ -2,6 +2,7 @@
 and refuses to compute without a GPU (no CPU fallback)."""
 import os
 import re
+import subprocess
 
 import pytest
 
@@ -58,3 +59,30 @@ def test_product_does_not_touch_oracle():
             if f.endswith((".py", ".hip", ".h", ".cuh", ".cpp", "Makefile")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in src.lower().replace("no oracle", ""), os.path.join(dirpath, f)
+
+
+def _build_c_host(tmp_path):
+    exe = str(tmp_path / "selfplay_host")
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-O2", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "selfplay_host.c"), "-L" + os.path.join(ROOT, "tak_amd"), "-ltakgpu",
+           "-Wl,-rpath," + os.path.join(ROOT, "tak_amd"), "-o", exe]
+    subprocess.run(cmd, check=True)
+    return exe
+
+
+def test_header_is_plain_c99():
+    """the boundary is a C ABI: takgpu.h must compile as C (not only as C++), with no other include"""
+    hdr = os.path.join(ROOT, "include", "takgpu.h")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
+
+
+def test_c_host_links_and_fails_loudly_without_gpu(lib, tmp_path):
+    """examples/selfplay_host.c (C99, no Python / torch) builds against the header and the library alone; without a
+    GPU the engine refuses to start instead of falling back to anything"""
+    import torch
+
+    exe = _build_c_host(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present (tests/test_gpu_net.py runs the host)")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr

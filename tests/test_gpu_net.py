@@ -115,3 +115,71 @@ def test_weight_errors():
     assert ei.value.code == -4 and "res0.bn2.running_var" in str(ei.value)
     assert e.policy_eval(np.zeros((0, 256), np.uint8))[0].shape == (0, 1575)  # empty batch is fine (net5.rs:121)
     e.close()
+
+
+@pytest.mark.parametrize("n,head", [(5, "fc5"), (6, "conv")])
+def test_default_init_matches_tch_defaults_and_torch_forward(orc, n, head):
+    """Network::default() (net5.rs:29-73): tg_net_init_random draws tch's default initialisers; the tensors read back
+    through tg_net_get_tensor have those distributions, and the forward on them equals PyTorch's on the same tensors."""
+    import tak_amd
+
+    F, R = 32, 2
+    e = _engine(n, R, F, head)
+    e.init_random(seed=5)
+    P = tak_amd.policy_size(n, tak_amd.HEAD_FC5 if head == "fc5" else tak_amd.HEAD_CONV)
+    cin = tak_amd.input_channels(n)
+    shapes = {"conv0.weight": (F, cin, 3, 3), "conv0.bias": (F,), "bn0.weight": (F,), "bn0.bias": (F,), "bn0.running_mean": (F,),
+              "bn0.running_var": (F,), "value.weight": (1, F * n * n), "value.bias": (1,)}
+    for i in range(R):
+        for c in ("conv1", "conv2"):
+            shapes[f"res{i}.{c}.weight"] = (F, F, 3, 3)
+            shapes[f"res{i}.{c}.bias"] = (F,)
+        for b in ("bn1", "bn2"):
+            for leaf in ("weight", "bias", "running_mean", "running_var"):
+                shapes[f"res{i}.{b}.{leaf}"] = (F,)
+    if head == "fc5":
+        shapes["policy.weight"], shapes["policy.bias"] = (P, F * n * n), (P,)
+    else:
+        shapes["policy.weight"], shapes["policy.bias"] = (P // (n * n), F, 3, 3), (P // (n * n),)
+    t = {k: e.get_tensor(k, s) for k, s in shapes.items()}
+    w = t["res1.conv2.weight"]
+    bound = 1.0 / np.sqrt(F * 9)
+    assert np.abs(w).max() <= bound and abs(w.mean()) < 0.05 * bound and abs(w.std() - bound / np.sqrt(3)) < 0.03 * bound
+    assert np.all(t["res0.conv1.bias"] == 0) and np.all(t["bn0.bias"] == 0) and np.all(t["res1.bn2.running_var"] == 1)
+    g = np.concatenate([t[k] for k in t if k.endswith(("bn0.weight", "bn1.weight", "bn2.weight"))])
+    assert 0 <= g.min() and g.max() <= 1 and abs(g.mean() - 0.5) < 0.08
+    pb = t["policy.bias"]
+    if head == "fc5":
+        lb = 1.0 / np.sqrt(F * n * n)
+        assert np.abs(pb).max() <= lb and pb.std() > 0.4 * lb and np.abs(t["policy.weight"]).max() <= lb
+    else:
+        assert np.all(pb == 0)
+    assert not np.array_equal(t["res0.conv1.weight"], t["res0.conv2.weight"])
+    # another seed → other values; the same seed → the same values
+    e2 = _engine(n, R, F, head)
+    e2.init_random(seed=6)
+    assert not np.array_equal(e2.get_tensor("conv0.weight", shapes["conv0.weight"]), t["conv0.weight"])
+    e2.init_random(seed=5)
+    assert np.array_equal(e2.get_tensor("conv0.weight", shapes["conv0.weight"]), t["conv0.weight"])
+    e2.close()
+    # forward on these tensors = PyTorch forward on the same tensors
+    net = torch_ref.make_net(n, R, F, head)
+    torch_ref.load_abi_tensors(net, t)
+    states = orc.random_positions(n, 24, seed=3, max_plies=40, half_komi=4)
+    pol, ev = e.policy_eval(states)
+    rp, rv = torch_ref.forward(net, orc.encode(n, states))
+    assert np.abs(pol - rp).max() <= TOL and np.abs(ev - rv).max() <= TOL
+    e.close()
+
+
+def test_c_host_runs_selfplay_through_the_abi(tmp_path):
+    """examples/selfplay_host.c: a C99 program against takgpu.h + libtakgpu.so only (perft KAT, policy_eval, self-play,
+    drain, example text)"""
+    import subprocess
+
+    import test_abi
+
+    exe = test_abi._build_c_host(tmp_path)
+    r = subprocess.run([exe, "128", "24", "70"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "perft(5x5, depth 3) = 43320" in r.stdout and r.stdout.strip().endswith("OK")

@@ -95,6 +95,17 @@ def abi_tensors(net):
     return out
 
 
+def load_abi_tensors(net, tensors):
+    """inverse of abi_tensors: {ABI tensor name: array} → the module's parameters and buffers"""
+    sd = net.state_dict()
+    for k in list(sd.keys()):
+        if k.endswith("num_batches_tracked"):
+            continue
+        sd[k] = torch.from_numpy(np.ascontiguousarray(tensors[abi_name(k)], np.float32)).reshape(sd[k].shape).clone()
+    net.load_state_dict(sd)
+    return net.eval()
+
+
 @torch.no_grad()
 def forward(net, planes):
     p, v = net(torch.from_numpy(np.ascontiguousarray(planes, np.float32)))

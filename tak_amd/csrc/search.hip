@@ -476,7 +476,7 @@ int tg_search_counters(TgEngine* e, uint64_t* expansions, uint64_t* evals) {
 // ---- self-play -----------------------------------------------------------------------------------
 
 int tg_selfplay_create(TgEngine* e, const TgSearchConfig* scfg, const TgSelfPlayConfig* cfg) {
-    if (!cfg) return fail(TG_ERR_INVALID_ARG, "null self-play config");
+    if (!cfg || !scfg) return fail(TG_ERR_INVALID_ARG, "null self-play config");
     if (cfg->rollouts < 1 || cfg->max_examples < 1) return fail(TG_ERR_INVALID_ARG, "rollouts and max_examples must be positive");
     TgSearchConfig sc1 = *scfg;
     sc1.batch = 1;  // self_play_parallel gathers ONE leaf per game and iteration (self_play.rs:181-210)

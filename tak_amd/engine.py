@@ -208,6 +208,33 @@ def pit(new, old, pairs=128, rollouts=50, batch=16, idle_rollouts=1, random_plie
     return res.as_dict()
 
 
+def tensor_shapes(n, res_blocks, filters, policy_head):
+    """{ABI tensor name: shape} in the creation order of net5.rs:29-62 / net6.rs:29-57 (tch layouts, include/takgpu.h)."""
+    F, cin, P = filters, input_channels(n), policy_size(n, policy_head)
+    out = {}
+
+    def conv(name, o, i):
+        out[name + ".weight"], out[name + ".bias"] = (o, i, 3, 3), (o,)
+
+    def bn(name):
+        for leaf in ("weight", "bias", "running_mean", "running_var"):
+            out[f"{name}.{leaf}"] = (F,)
+
+    conv("conv0", F, cin)
+    bn("bn0")
+    for i in range(res_blocks):
+        conv(f"res{i}.conv1", F, F)
+        conv(f"res{i}.conv2", F, F)
+        bn(f"res{i}.bn1")
+        bn(f"res{i}.bn2")
+    if policy_head == HEAD_FC5:
+        out["policy.weight"], out["policy.bias"] = (P, F * n * n), (P,)
+    else:
+        conv("policy", P // (n * n), F)
+    out["value.weight"], out["value.bias"] = (1, F * n * n), (1,)
+    return out
+
+
 def _mask(active):
     return np.ascontiguousarray(active, np.uint8) if active is not None else None
 
@@ -390,6 +417,10 @@ class Engine:
         out = np.zeros(shape, np.float32)
         self._check(self.lib.tg_net_get_tensor(self.h, name.encode(), _p(out), C.c_size_t(out.size)))
         return out
+
+    def state_dict(self):
+        """{name: array} of every tensor as last set / initialised / committed (Network::save's content)"""
+        return {k: self.get_tensor(k, shp) for k, shp in tensor_shapes(self.n, self.cfg.res_blocks, self.cfg.filters, self.head).items()}
 
     def load_state_dict(self, tensors):
         """tensors: {name: array} with the names of include/takgpu.h (tch layouts)."""

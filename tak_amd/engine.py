@@ -188,6 +188,29 @@ def parse_example(n, line):
     return st, mv[: k.value].copy(), vs[: k.value].copy(), res.value
 
 
+def read_examples(n, paths):
+    """Load `.data` example files as train/src/main.rs:69-80 does (one Example per line, alpha-tak/src/example.rs:100-133)
+    → (states [k, bytes], n_moves [k], moves [k, TG_MAX_MOVES], visits [k, TG_MAX_MOVES], results [k]): the layout tg_train takes."""
+    if isinstance(paths, (str, bytes, os.PathLike)):
+        paths = [paths]
+    rows = []
+    for path in paths:
+        with open(path) as f:
+            for line in f.read().split("\n"):
+                if line.strip():
+                    rows.append(parse_example(n, line))
+    k = len(rows)
+    states = np.zeros((k, state_bytes(n)), np.uint8)
+    n_moves = np.zeros(k, np.int32)
+    moves = np.zeros((k, TG_MAX_MOVES), np.uint16)
+    visits = np.zeros((k, TG_MAX_MOVES), np.uint32)
+    results = np.zeros(k, np.float32)
+    for i, (st, mv, vs, res) in enumerate(rows):
+        states[i], n_moves[i], results[i] = st, len(mv), res
+        moves[i, : len(mv)], visits[i, : len(mv)] = mv, vs
+    return states, n_moves, moves, visits, results
+
+
 def comm_unique_id():
     """ncclGetUniqueId on this rank (128 bytes); broadcast it to the other ranks with any host transport."""
     uid = np.zeros(128, np.uint8)

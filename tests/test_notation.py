@@ -60,3 +60,24 @@ def test_example_line_roundtrip(orc):
         assert np.array_equal(st, want) and np.array_equal(mv, moves[i, :k]) and np.array_equal(vs, visits[i, :k])
         assert res == hdr["result"][i] and np.signbit(res) == np.signbit(hdr["result"][i])
     assert seen_results <= {"1", "-1", "0", "-0"} and len(seen_results) >= 2
+
+
+def test_example_file_roundtrip(orc, tmp_path):
+    """a `.data` file (self_play.rs:98, one Example per line) written from drained examples loads back into the arrays tg_train takes"""
+    n = 5
+    sp = orc.SelfPlay(n, 3, head=orc.HEAD_FC5, evaluator=orc.EVAL_HASH, rollouts=10, total_games=3, seed=9)
+    for _ in range(300):
+        sp.step(1)
+        if not sp.states()[1].any():
+            break
+    hdr, states, moves, visits = sp.drain(10000)
+    path = tmp_path / "games.data"
+    with open(path, "w") as f:
+        for i in range(len(hdr)):
+            k = int(hdr["n_moves"][i])
+            f.write(tak_amd.format_example(n, states[i], moves[i, :k], visits[i, :k], float(hdr["result"][i])) + "\n")
+    st, nm, mv, vs, res = tak_amd.read_examples(n, path)
+    want = states.copy()
+    want[:, 256 - 16 + 9] = 0  # reversible_plies is not part of the text format
+    assert len(st) == len(hdr) > 5 and np.array_equal(st, want) and np.array_equal(nm, hdr["n_moves"])
+    assert np.array_equal(mv, moves) and np.array_equal(vs, visits) and np.array_equal(res, hdr["result"])

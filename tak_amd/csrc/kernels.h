@@ -61,7 +61,7 @@ hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp,
                        int NP, int out_stride, int n_valid);
 hipError_t launch_value_head(hipStream_t st, const float* act, const float* wv, float bv, int B, int len, float* eval);
 hipError_t launch_softmax(hipStream_t st, const float* logits, int row_stride, bool conv_head, int nsq, int ch_stride, int P,
-                          int B, float* policy);
+                          int B, float* policy, float* eval = nullptr);
 hipError_t launch_nchw_to_nhwc(hipStream_t st, const float* src, int B, int C, int nsq, int Cpad, float* dst);
 
 // train_kernels.hip

@@ -27,6 +27,7 @@ struct Net {
     ConvLayer policy_conv;            // TG_HEAD_CONV
     DevBuf policy_w, policy_b;        // TG_HEAD_FC5: Wp [K/16][NP][16]
     int policy_np = 0;                // padded FC outputs
+    bool value_in_fc = false;         // the value head rides in padding column P of the policy FC (logit P = value pre-activation)
     DevBuf value_w;                   // [nsq*F] in NHWC order
     float value_b = 0.0f;
     // activations (max_batch positions)
@@ -243,6 +244,23 @@ int net_finalize(TgEngine* e) {
                     wp[((k >> 4) * NP + o) * 16 + (k & 15)] = (*w)[(size_t)o * K + (size_t)c * nsq + sq];
                 }
         }
+        // the FC is padded anyway: column P carries the value head (Linear(F·nsq → 1), net5.rs:62), so the value costs no
+        // kernel of its own — the softmax kernel applies the tanh
+        n->value_in_fc = false;
+        {
+            auto wv = find(n, "value.weight", K, err);
+            auto bv = wv ? find(n, "value.bias", 1, err) : nullptr;
+            if (!bv) return fail(TG_ERR_WEIGHTS, err);
+            if (NP > P && !getenv("TG_SEPARATE_VALUE_HEAD")) {
+                bp[P] = (*bv)[0];
+                for (int c = 0; c < F; c++)
+                    for (int sq = 0; sq < nsq; sq++) {
+                        size_t k = (size_t)sq * F + c;
+                        wp[((k >> 4) * NP + P) * 16 + (k & 15)] = (*wv)[(size_t)c * nsq + sq];
+                    }
+                n->value_in_fc = true;
+            }
+        }
         n->policy_np = NP;
         TG_HIP(n->policy_w.ensure(wp.size() * 4));
         TG_HIP(n->policy_b.ensure(bp.size() * 4));
@@ -324,10 +342,25 @@ int net_finalize(TgEngine* e) {
                     ws[slot * 8 + (k & 7)] = hi;
                     ws[(slot + CB) * 8 + (k & 7)] = lo;
                 }
+            if (n->value_in_fc && NP > P) {  // column P = the value head, split like every other column
+                auto wv = find(n, "value.weight", K, err);
+                if (!wv) return fail(TG_ERR_WEIGHTS, err);
+                for (size_t k = 0; k < K; k++) {
+                    int sq = (int)(k / F), c = (int)(k % F);
+                    float v = (*wv)[(size_t)c * nsq + sq];
+                    uint16_t hi = f32_to_bf16(v), lo = f32_to_bf16(v - bf16_to_f32(hi));
+                    const size_t cb = (size_t)P / CB, col = (size_t)P % CB, q = (k & 31) >> 3;
+                    size_t slot = ((((k >> 5) * (size_t)(NP / CB) + cb) * 4 + q) * 2) * CB + col;
+                    ws[slot * 8 + (k & 7)] = hi;
+                    ws[(slot + CB) * 8 + (k & 7)] = lo;
+                }
+            }
             TG_HIP(n->s3_fc.ensure(ws.size() * 2));
             TG_HIP(hipMemcpy(n->s3_fc.p, ws.data(), ws.size() * 2, hipMemcpyHostToDevice));
             std::vector<float> bp(NP, 0.0f);
             std::copy(bsrc->begin(), bsrc->end(), bp.begin());
+            if (n->value_in_fc && NP > P) bp[P] = n->value_b;
+            else n->value_in_fc = false;
             TG_HIP(n->s3_fc_b.ensure(bp.size() * 4));
             TG_HIP(hipMemcpy(n->s3_fc_b.p, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
             n->s3_fc_on = true;
@@ -435,14 +468,16 @@ static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const ui
             TG_HIP(launch_conv3x3(st, x, L.w.as<float>(), L.b.as<float>(), nullptr, logits, M, N, F, L.cout_pad, L.cout_pad, L.cout, false));
         TG_HIP(launch_softmax(st, logits, nsq * L.cout_pad, true, nsq, L.cout_pad, e->policy_size, nb, d_policy));
     } else if (n->s3 && n->s3_fc_on) {
-        TG_HIP(launch_fc_s3(st, x, n->s3_fc.p, n->s3_fc_b.as<float>(), logits, nb, nsq * F, n->s3_np, n->s3_np, e->policy_size));
-        TG_HIP(launch_softmax(st, logits, n->s3_np, false, nsq, 0, e->policy_size, nb, d_policy));
+        TG_HIP(launch_fc_s3(st, x, n->s3_fc.p, n->s3_fc_b.as<float>(), logits, nb, nsq * F, n->s3_np, n->s3_np, e->policy_size + (n->value_in_fc ? 1 : 0)));
+        TG_HIP(launch_softmax(st, logits, n->s3_np, false, nsq, 0, e->policy_size, nb, d_policy, n->value_in_fc ? d_eval : nullptr));
     } else {
         TG_HIP(launch_gemm(st, x, nsq * F, n->policy_w.as<float>(), n->policy_b.as<float>(), logits, nb, nsq * F, n->policy_np,
-                           n->policy_np, e->policy_size));
-        TG_HIP(launch_softmax(st, logits, n->policy_np, false, nsq, 0, e->policy_size, nb, d_policy));
+                           n->policy_np, e->policy_size + (n->value_in_fc ? 1 : 0)));
+        TG_HIP(launch_softmax(st, logits, n->policy_np, false, nsq, 0, e->policy_size, nb, d_policy, n->value_in_fc ? d_eval : nullptr));
     }
-    if (n->s3 && (n->s3_fc_on || n->s3_head_on)) TG_HIP(launch_value_head_s3(st, x, n->value_w.as<float>(), n->value_b, nb, nsq * F, d_eval));
+    if (e->cfg.policy_head == TG_HEAD_FC5 && n->value_in_fc) {
+        // eval = tanh(logit P), written by the softmax kernel
+    } else if (n->s3 && (n->s3_fc_on || n->s3_head_on)) TG_HIP(launch_value_head_s3(st, x, n->value_w.as<float>(), n->value_b, nb, nsq * F, d_eval));
     else TG_HIP(launch_value_head(st, x, n->value_w.as<float>(), n->value_b, nb, nsq * F, d_eval));
     if (chain) chain->push_back(prof_event(n, st));
     return TG_OK;

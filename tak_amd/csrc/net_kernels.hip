@@ -593,10 +593,11 @@ __global__ __launch_bounds__(256) void k_value_head(const float* __restrict__ ac
 // conv_head (NHWC conv output) or simply [b][p] for the FC head; the probabilities are written in the
 // reference's order p = ch·N² + sq.
 __global__ __launch_bounds__(256) void k_softmax(const float* __restrict__ logits, int row_stride, int conv_head, int nsq,
-                                                 int ch_stride, int P, float* __restrict__ policy) {
+                                                 int ch_stride, int P, float* __restrict__ policy, float* __restrict__ eval) {
     __shared__ float red[4];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* x = logits + (size_t)b * row_stride;
+    if (eval && tid == 0) eval[b] = tanhf(x[P]);  // FC head: column P of the policy FC is the value head's pre-activation
     auto at = [&](int p) -> float {
         if (!conv_head) return x[p];
         int ch = p / nsq, sq = p - ch * nsq;
@@ -823,12 +824,12 @@ hipError_t launch_value_head(hipStream_t st, const float* act, const float* wv, 
 }
 
 hipError_t launch_softmax(hipStream_t st, const float* logits, int row_stride, bool conv_head, int nsq, int ch_stride, int P,
-                          int B, float* policy) {
+                          int B, float* policy, float* eval) {
     if (conv_head && (ch_stride & 3) == 0 && (size_t)nsq * (ch_stride + 1) * 4 <= 64 * 1024) {
         hipLaunchKernelGGL(k_softmax_conv, dim3(B), dim3(256), (size_t)nsq * (ch_stride + 1) * 4, st, logits, nsq, ch_stride, P / nsq, policy);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_softmax, dim3(B), dim3(256), 0, st, logits, row_stride, conv_head ? 1 : 0, nsq, ch_stride, P, policy);
+    hipLaunchKernelGGL(k_softmax, dim3(B), dim3(256), 0, st, logits, row_stride, conv_head ? 1 : 0, nsq, ch_stride, P, policy, conv_head ? nullptr : eval);
     return hipGetLastError();
 }
 

@@ -277,15 +277,50 @@ def test_dirichlet_spec_matches_oracle(orc):
     e.close()
 
 
-@pytest.mark.parametrize("n,games,rollouts,total", [(4, 8, 24, 20), (5, 6, 16, 9)])
+def test_selfplay_config_c1_with_the_real_network(orc):
+    """BASELINE config C1 (5×5, 64 games, 100 sims/move) on the C2 network for the first plies of every game: the oracle's
+    self_play_parallel evaluates its leaf batches through tg_policy_eval, the engine through its own leaf batch — same
+    statistics after every ply, same examples."""
+    import tak_amd
+
+    games, rollouts, plies = 64, 100, 10
+    net = torch_ref.make_net(5, 6, 64, "fc5", seed=0)
+    tensors = torch_ref.abi_tensors(net)
+    e = _mk(5, tak_amd.EVAL_RESNET, games, res_blocks=6, filters=64)
+    e.load_state_dict(tensors)
+    ev = _mk(5, tak_amd.EVAL_RESNET, games, res_blocks=6, filters=64)
+    ev.load_state_dict(tensors)
+    kw = dict(rollouts=rollouts, noise_plies=80, exploit_plies=40, noise_alpha=0.2, noise_ratio=0.3, komi=2, total_games=0)
+    e.selfplay_create(games, arena_nodes=1 << 16, seed=0, max_examples=1 << 14, **kw)
+    sp = orc.SelfPlay(5, games, head=orc.HEAD_FC5, py_eval=lambda st: ev.policy_eval(st), seed=0, **kw)
+    for step in range(plies):
+        e.selfplay_step(1)
+        sp.step(1)
+        a, b = e.selfplay_stats(), sp.stats()
+        assert a == b, (step, a, b)
+    assert a["expansions"] >= games * rollouts * (plies - 2)
+    gh, gs, gm, gv = e.selfplay_drain(1 << 14)
+    oh, os_, om, ov = sp.drain(1 << 14)
+    assert np.array_equal(gh, oh) and np.array_equal(gs, os_) and np.array_equal(gm, om) and np.array_equal(gv, ov)
+    # the live roots agree too (visit counts of every legal move of every game)
+    st_o, alive_o = sp.states()
+    assert np.array_equal(e.search_states(), st_o)
+    e.close()
+    ev.close()
+
+
+@pytest.mark.parametrize("n,games,rollouts,total", [(4, 8, 24, 20), (5, 6, 16, 9), (5, 64, 100, 80)])
 def test_selfplay_driver_matches_oracle(orc, n, games, rollouts, total):
     # self_play_parallel end to end: openings, instant wins, noise, rollouts, sampling / argmax,
     # tree reuse, game recycling and example emission — every example identical, in the same order
     import tak_amd
 
-    kw = dict(rollouts=rollouts, noise_plies=6, exploit_plies=4, noise_alpha=0.2, noise_ratio=0.3, komi=2, total_games=total)
+    # the last case is BASELINE config C1 (5×5, 64 games, 100 sims/move) with the reference's noise / temperature schedule
+    c1 = games == 64
+    kw = dict(rollouts=rollouts, noise_plies=80 if c1 else 6, exploit_plies=40 if c1 else 4, noise_alpha=0.2, noise_ratio=0.3, komi=2,
+              total_games=total)
     e = _mk(n, tak_amd.EVAL_HASH, games)
-    e.selfplay_create(games, arena_nodes=1 << 15, seed=5, max_examples=1 << 14, **kw)
+    e.selfplay_create(games, arena_nodes=1 << 16 if c1 else 1 << 15, seed=5, max_examples=1 << 14, **kw)
     head = orc.HEAD_FC5 if n == 5 else orc.HEAD_CONV
     sp = orc.SelfPlay(n, games, head=head, evaluator=orc.EVAL_HASH, seed=5, **kw)
     for step in range(400):

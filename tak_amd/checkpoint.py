@@ -55,9 +55,13 @@ def save_tch_varstore(path, tensors, res_blocks, **order):
         def __init__(self):
             super().__init__()
 
+    # tch's `Tensor::save_multi` goes through torch::serialize::OutputArchive::write(name, tensor, /*is_buffer=*/false): every
+    # variable — the BatchNorm running statistics too — is a PARAMETER of the archived module, and tch's loader walks
+    # module.named_parameters() only.  So parameters it is (requires_grad off: they are plain data here).
     m = _Store()
     for abi, name in tch_names(res_blocks, **order):
-        m.register_buffer(name, torch.from_numpy(np.ascontiguousarray(tensors[abi], np.float32)).clone())
+        t = torch.from_numpy(np.ascontiguousarray(tensors[abi], np.float32)).clone()
+        m.register_parameter(name, torch.nn.Parameter(t, requires_grad=False))
     torch.jit.save(torch.jit.script(m), path)
 
 

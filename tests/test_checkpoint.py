@@ -27,6 +27,11 @@ def test_round_trip_and_order_robustness(tmp_path, n, blocks, filters, head):
         checkpoint.save_tch_varstore(path, tensors, blocks, conv_order=conv_order, bn_order=bn_order)
         back = checkpoint.load_tch_varstore(path, blocks)
         assert set(back) == set(tensors)
+        if i == 0:  # tch's loader walks module.named_parameters() only: every variable must be one, the BN statistics too
+            import torch
+
+            params = dict(torch.jit.load(path).named_parameters())
+            assert set(params) == {t for _, t in names} and not any(p.requires_grad for p in params.values())
         for k in tensors:
             assert back[k].shape == tensors[k].shape and np.array_equal(back[k], tensors[k]), (k, conv_order, bn_order)
 

@@ -556,6 +556,67 @@ __global__ __launch_bounds__(512) void k_fc_lds(const float* __restrict__ A, int
     }
 }
 
+// The same FC for SMALL batches (host-driven MCTS evaluates 16–32 leaves per call; Player, pit): k_fc_lds gives a row block
+// of 128 positions to one workgroup and needs ≥ 4096 rows to fill the chip, so a 32-row call took as long as a 4096-row
+// one.  Here a wave owns one 16-row tile × 2 output tiles and streams both operands straight from global (no LDS, no
+// barrier): M/16 × NP/32 waves.  Every output element is accumulated over k in the same order by the same MFMA as in
+// k_fc_lds, so the two kernels return identical bits and the choice between them is invisible.
+constexpr int FCS_CT = 2;
+constexpr int FC_SMALL_ROWS = 512;  // up to here the small-batch kernel is the faster one (4 workgroups of k_fc_lds)
+__global__ __launch_bounds__(256) void k_fc_small(const float* __restrict__ A, int lda, const float* __restrict__ Wp,
+                                                  const float* __restrict__ bias, float* __restrict__ out, int M, int K, int NP,
+                                                  int out_stride, int n_valid) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int row = blockIdx.x * 16 + r16;
+    const bool row_ok = row < M;
+    const int n0 = (blockIdx.y * 4 + wave) * (FCS_CT * 16);
+    if (n0 >= NP) return;
+    const f32x4* ap = (const f32x4*)(A + (size_t)(row_ok ? row : M - 1) * lda) + q;
+    const f32x4* wg = (const f32x4*)Wp + ((size_t)(n0 + r16) * 4 + q);  // slot (chunk, col, q) at (chunk*NP + col)*4 + q
+    const size_t wchunk = (size_t)NP * 4;
+    const int nchunks = K >> 4;
+    constexpr int D = 4;  // chunks in flight
+    f32x4 a[D], w[D][FCS_CT];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        const int kc = d < nchunks ? d : nchunks - 1;
+        a[d] = ap[(size_t)kc * 4];
+#pragma unroll
+        for (int j = 0; j < FCS_CT; j++) w[d][j] = wg[(size_t)kc * wchunk + j * 64];
+    }
+    f32x4 acc[FCS_CT];
+#pragma unroll
+    for (int j = 0; j < FCS_CT; j++) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int kc0 = 0; kc0 < nchunks; kc0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            if (kc0 + d < nchunks) {
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int j = 0; j < FCS_CT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[d][j][t], a[d][t], acc[j], 0, 0, 0);
+            }
+            const int kn = kc0 + d + D < nchunks ? kc0 + d + D : nchunks - 1;
+            a[d] = ap[(size_t)kn * 4];
+#pragma unroll
+            for (int j = 0; j < FCS_CT; j++) w[d][j] = wg[(size_t)kn * wchunk + j * 64];
+        }
+    }
+    if (row_ok) {
+#pragma unroll
+        for (int j = 0; j < FCS_CT; j++) {
+            const int nn = n0 + j * 16 + 4 * q;
+            if (nn < n_valid) {
+                f32x4 v = acc[j] + *(const f32x4*)&bias[nn];
+                float* o = out + (size_t)row * out_stride + nn;
+                if (nn + 3 < n_valid) *(f32x4*)o = v;
+                else for (int t = 0; t < 4; t++) if (nn + t < n_valid) o[t] = v[t];
+            }
+        }
+    }
+}
+
 __device__ inline float wave_sum(float v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
@@ -754,12 +815,28 @@ hipError_t launch_conv3x3(hipStream_t st, const float* in, const float* Wp, cons
                           int M, int n, int Cpad, int CoutP, int out_stride, int cout_valid, bool relu) {
     const int B = M / (n * n);
     // whole-positions kernel where the shape divides evenly (the BASELINE configs); generic tiles otherwise
-    if (n == 5 && CoutP == 64 && Cpad <= 80)  // 16 positions = 25 row tiles, 4 channel tiles × 2 row groups of 13
-        return launch_conv_pos_t<13, 8>(st, in, Wp, bias, res, out, B, n, Cpad, CoutP, out_stride, cout_valid, relu, 16, 4);
-    if (n == 6 && CoutP % 128 == 0 && Cpad <= 128)  // 4 positions = 9 row tiles, 8 channel tiles
-        return launch_conv_pos_t<9, 8>(st, in, Wp, bias, res, out, B, n, Cpad, CoutP, out_stride, cout_valid, relu, 4, 8);
-    if (n == 5 && CoutP % 128 == 0 && Cpad <= 128)  // 8 positions = 200 rows in 13 row tiles, 8 channel tiles
-        return launch_conv_pos_t<13, 8>(st, in, Wp, bias, res, out, B, n, Cpad, CoutP, out_stride, cout_valid, relu, 8, 8);
+    // small batches take fewer positions per workgroup (shorter critical path, same bits — see launch_tower)
+#define TG_CONV_POS(RTW, NW, PW, CTW) \
+    return launch_conv_pos_t<RTW, NW>(st, in, Wp, bias, res, out, B, n, Cpad, CoutP, out_stride, cout_valid, relu, PW, CTW)
+    if (n == 5 && CoutP == 64 && Cpad <= 80) {  // 16 positions = 25 row tiles, 4 channel tiles × 2 row groups of 13
+        if (B <= 256) TG_CONV_POS(2, 4, 1, 4);
+        if (B <= 512) TG_CONV_POS(4, 4, 2, 4);
+        if (B <= 1024) TG_CONV_POS(7, 4, 4, 4);
+        if (B <= 2048) TG_CONV_POS(13, 4, 8, 4);
+        TG_CONV_POS(13, 8, 16, 4);
+    }
+    if (n == 6 && CoutP % 128 == 0 && Cpad <= 128) {  // 4 positions = 9 row tiles, 8 channel tiles
+        if (B <= 256) TG_CONV_POS(3, 8, 1, 8);
+        if (B <= 512) TG_CONV_POS(5, 8, 2, 8);
+        TG_CONV_POS(9, 8, 4, 8);
+    }
+    if (n == 5 && CoutP % 128 == 0 && Cpad <= 128) {  // 8 positions = 200 rows in 13 row tiles, 8 channel tiles
+        if (B <= 256) TG_CONV_POS(2, 8, 1, 8);
+        if (B <= 512) TG_CONV_POS(4, 8, 2, 8);
+        if (B <= 1024) TG_CONV_POS(7, 8, 4, 8);
+        TG_CONV_POS(13, 8, 8, 8);
+    }
+#undef TG_CONV_POS
     if (conv_lds_bytes(2, n, Cpad) > 160 * 1024) {  // wide inputs (data gradient of the 6×6 policy head): 64-row tiles
         if (CoutP % 128 == 0) return launch_conv_t<1, 2>(st, in, Wp, bias, res, out, M, n, Cpad, CoutP, out_stride, cout_valid, relu);
         return launch_conv_t<1, 1>(st, in, Wp, bias, res, out, M, n, Cpad, CoutP, out_stride, cout_valid, relu);
@@ -791,23 +868,63 @@ bool tower_supported(int n, int F, int cin_pad) {
 }
 
 hipError_t launch_tower(hipStream_t st, const float* in, const TowerParams& T, float* out, int B, int n) {
-    if (n == 5 && T.F == 64 && T.cin_pad == 80) return launch_tower_t<13, 8, 5, 4, false>(st, in, T, out, B, n, 16, 4);
-    if (n == 6 && T.F == 128 && T.cin_pad == 96) return launch_tower_t<9, 8, 6, 8, false>(st, in, T, out, B, n, 4, 8);
-    if (n == 5 && T.F == 128 && T.cin_pad == 80) return launch_tower_t<13, 8, 5, 8, false>(st, in, T, out, B, n, 8, 8);
+    // A workgroup's run time is that of its positions' row tiles, whatever the batch: with 16 positions per workgroup a
+    // 32-position call (the reference's BATCH_SIZE) ran 2 workgroups for as long as 4096 positions take.  Small batches
+    // therefore use instantiations with fewer positions (row tiles) per workgroup; the per-element arithmetic — taps,
+    // chunks, MFMA k-steps in the same order — does not depend on the tiling, so results are bit-identical.
+    if (n == 5 && T.F == 64 && T.cin_pad == 80) {
+        if (B <= 256) return launch_tower_t<2, 4, 5, 4, false>(st, in, T, out, B, n, 1, 4);
+        if (B <= 512) return launch_tower_t<4, 4, 5, 4, false>(st, in, T, out, B, n, 2, 4);
+        if (B <= 1024) return launch_tower_t<7, 4, 5, 4, false>(st, in, T, out, B, n, 4, 4);
+        if (B <= 2048) return launch_tower_t<13, 4, 5, 4, false>(st, in, T, out, B, n, 8, 4);
+        return launch_tower_t<13, 8, 5, 4, false>(st, in, T, out, B, n, 16, 4);
+    }
+    if (n == 6 && T.F == 128 && T.cin_pad == 96) {
+        if (B <= 256) return launch_tower_t<3, 8, 6, 8, false>(st, in, T, out, B, n, 1, 8);
+        if (B <= 512) return launch_tower_t<5, 8, 6, 8, false>(st, in, T, out, B, n, 2, 8);
+        return launch_tower_t<9, 8, 6, 8, false>(st, in, T, out, B, n, 4, 8);
+    }
+    if (n == 5 && T.F == 128 && T.cin_pad == 80) {
+        if (B <= 256) return launch_tower_t<2, 8, 5, 8, false>(st, in, T, out, B, n, 1, 8);
+        if (B <= 512) return launch_tower_t<4, 8, 5, 8, false>(st, in, T, out, B, n, 2, 8);
+        if (B <= 1024) return launch_tower_t<7, 8, 5, 8, false>(st, in, T, out, B, n, 4, 8);
+        return launch_tower_t<13, 8, 5, 8, false>(st, in, T, out, B, n, 8, 8);
+    }
     return hipErrorInvalidValue;
 }
 
 // same, with the input planes encoded in-kernel from packed game states
 hipError_t launch_tower_states(hipStream_t st, const uint8_t* states, const TowerParams& T, float* out, int B, int n) {
     const float* in = (const float*)states;
-    if (n == 5 && T.F == 64 && T.cin_pad == 80) return launch_tower_t<13, 8, 5, 4, true>(st, in, T, out, B, n, 16, 4);
-    if (n == 6 && T.F == 128 && T.cin_pad == 96) return launch_tower_t<9, 8, 6, 8, true>(st, in, T, out, B, n, 4, 8);
-    if (n == 5 && T.F == 128 && T.cin_pad == 80) return launch_tower_t<13, 8, 5, 8, true>(st, in, T, out, B, n, 8, 8);
+    if (n == 5 && T.F == 64 && T.cin_pad == 80) {
+        // fewer positions per workgroup for small batches (see tower_small_batch below): identical bits, shorter critical path
+        if (B <= 256) return launch_tower_t<2, 4, 5, 4, true>(st, in, T, out, B, n, 1, 4);
+        if (B <= 512) return launch_tower_t<4, 4, 5, 4, true>(st, in, T, out, B, n, 2, 4);
+        if (B <= 1024) return launch_tower_t<7, 4, 5, 4, true>(st, in, T, out, B, n, 4, 4);
+        if (B <= 2048) return launch_tower_t<13, 4, 5, 4, true>(st, in, T, out, B, n, 8, 4);
+        return launch_tower_t<13, 8, 5, 4, true>(st, in, T, out, B, n, 16, 4);
+    }
+    if (n == 6 && T.F == 128 && T.cin_pad == 96) {
+        if (B <= 256) return launch_tower_t<3, 8, 6, 8, true>(st, in, T, out, B, n, 1, 8);
+        if (B <= 512) return launch_tower_t<5, 8, 6, 8, true>(st, in, T, out, B, n, 2, 8);
+        return launch_tower_t<9, 8, 6, 8, true>(st, in, T, out, B, n, 4, 8);
+    }
+    if (n == 5 && T.F == 128 && T.cin_pad == 80) {
+        if (B <= 256) return launch_tower_t<2, 8, 5, 8, true>(st, in, T, out, B, n, 1, 8);
+        if (B <= 512) return launch_tower_t<4, 8, 5, 8, true>(st, in, T, out, B, n, 2, 8);
+        if (B <= 1024) return launch_tower_t<7, 8, 5, 8, true>(st, in, T, out, B, n, 4, 8);
+        return launch_tower_t<13, 8, 5, 8, true>(st, in, T, out, B, n, 8, 8);
+    }
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp, const float* bias, float* out, int M, int K,
                        int NP, int out_stride, int n_valid) {
+    if (NP % FC_COLS == 0 && K % FC_KSTEP == 0 && M <= FC_SMALL_ROWS && NP % (FCS_CT * 16) == 0) {
+        dim3 grid((M + 15) / 16, (NP / (FCS_CT * 16) + 3) / 4);
+        hipLaunchKernelGGL(k_fc_small, grid, dim3(256), 0, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid);
+        return hipGetLastError();
+    }
     if (NP % FC_COLS == 0 && K % FC_KSTEP == 0) {
         dim3 grid((M + 127) / 128, NP / FC_COLS);
         hipLaunchKernelGGL(k_fc_lds, grid, dim3(512), 0, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid);

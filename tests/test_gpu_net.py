@@ -183,3 +183,27 @@ def test_c_host_runs_selfplay_through_the_abi(tmp_path):
     r = subprocess.run([exe, "128", "24", "70"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "perft(5x5, depth 3) = 43320" in r.stdout and r.stdout.strip().endswith("OK")
+
+
+@pytest.mark.parametrize("n,blocks,filters,head,sizes", [
+    (5, 6, 64, "fc5", (1, 200, 300, 700, 1500, 2500)),   # C2: every positions-per-workgroup variant of the tower + both FC kernels
+    (5, 2, 128, "fc5", (17, 300, 600, 1100)),             # C5 network shape
+    (6, 2, 128, "conv", (5, 260, 520)),                   # C3 shape, conv head
+    (5, 2, 64, "conv", (40, 500, 1100, 2100)),            # conv head on 5×5
+])
+def test_result_does_not_depend_on_the_batch_size(orc, n, blocks, filters, head, sizes):
+    """Small batches run instantiations with fewer positions per workgroup (and a barrier-free FC) so that a 32-leaf call does
+    not take as long as a 4096-leaf one; the per-element arithmetic is the same, so a position's outputs must be the same
+    BITS whatever batch it is evaluated in."""
+    net = torch_ref.make_net(n, blocks, filters, head, seed=11)
+    total = max(sizes)
+    sts = orc.random_positions(n, 64, seed=9, max_plies=60, half_komi=4)
+    sts = np.concatenate([sts] * ((total + 63) // 64))[:total]
+    e = _engine(n, blocks, filters, head, max_batch=total)
+    e.load_state_dict(torch_ref.abi_tensors(net))
+    p_ref, v_ref = e.policy_eval(sts)
+    assert np.array_equal(p_ref[:64], p_ref[64:128]) and np.abs(p_ref.sum(1) - 1).max() < 1e-5
+    for k in sizes[:-1]:
+        p, v = e.policy_eval(sts[:k])
+        assert np.array_equal(p, p_ref[:k]) and np.array_equal(v, v_ref[:k]), k
+    e.close()

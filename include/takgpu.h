@@ -262,7 +262,8 @@ typedef struct TgSearchConfig {
                                  adds one node per legal move of the expanded leaf (≈ 45 on 5×5, ≈ 80 on 6×6) and the subtree
                                  under the move played is kept (tree reuse), so long games with concentrated searches need
                                  many times rollouts × branching: 2^19 ran 400 plies of 4096 5×5 games at 400 rollouts
-                                 (103 GB); 2^17 overflows after ≈ 180 plies (TG_ERR_ARENA_OVERFLOW) */
+                                 (103 GB); 2^17 overflows after ≈ 180 plies (TG_ERR_ARENA_OVERFLOW).
+                                 0 = auto: the largest power of two in [2^14, 2^19] whose arenas fit in half of the free device memory */
     float exploration_base;   /* EXPLORATION_BASE 500 (mcts.rs:7) */
     float exploration_init;   /* EXPLORATION_INIT 4   (mcts.rs:8) */
     uint64_t seed;            /* counter-based RNG key (noise, move sampling, openings)      */

@@ -76,7 +76,7 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     const size_t B = cfg->batch ? cfg->batch : 1;  // virtual rollouts per tree and iteration
     if (B > 4096 || (e->cfg.evaluator == TG_EVAL_RESNET && (size_t)cfg->games * B > (size_t)e->cfg.max_batch))
         return fail(TG_ERR_INVALID_ARG, "games x batch leaves per iteration exceed max_batch");
-    if (cfg->arena_nodes < 1024) return fail(TG_ERR_INVALID_ARG, "arena_nodes must be at least 1024");
+    if (cfg->arena_nodes != 0 && cfg->arena_nodes < 1024) return fail(TG_ERR_INVALID_ARG, "arena_nodes must be 0 (auto) or at least 1024");
     if (e->cfg.evaluator == TG_EVAL_RESNET && !net_ready(e)) return fail(TG_ERR_STATE, "network weights not finalized (tg_net_finalize)");
     TG_HIP(hipSetDevice(e->cfg.device));
     if (e->search) {
@@ -87,6 +87,17 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     std::unique_ptr<Search> sp(new Search());
     Search* s = sp.get();
     s->cfg = *cfg;
+    if (s->cfg.arena_nodes == 0) {
+        // auto: the largest power of two that keeps the arenas (two per game) inside half of the free device memory, between
+        // 2^14 and 2^19 nodes (2^19 ran 400 plies of 4096 5×5 games at 400 rollouts; the HBM is there to be used)
+        size_t free_b = 0, total_b = 0;
+        TG_HIP(hipMemGetInfo(&free_b, &total_b));
+        const size_t per_node = 2 * (sizeof(NodeHot) + sizeof(NodeCold)) * (size_t)cfg->games;
+        int cap = 1 << 19;
+        while (cap > (1 << 14) && (size_t)cap * per_node > free_b / 2) cap >>= 1;
+        s->cfg.arena_nodes = cap;
+    }
+    cfg = &s->cfg;
     const size_t G = (size_t)cfg->games, cap = (size_t)cfg->arena_nodes;
     const int cin_pad = e->cin_pad;
     TG_HIP(s->hot.ensure(G * 2 * cap * sizeof(NodeHot)));

@@ -545,7 +545,7 @@ class Engine:
         return ms.value, out_states, res, cnt
 
     # ---- self_play_parallel ------------------------------------------------------------------------
-    def selfplay_create(self, games, arena_nodes=1 << 16, base=500.0, init=4.0, seed=0, rollouts=400, noise_plies=80,
+    def selfplay_create(self, games, arena_nodes=0, base=500.0, init=4.0, seed=0, rollouts=400, noise_plies=80,
                         exploit_plies=40, noise_alpha=0.2, noise_ratio=0.3, komi=2, total_games=0, max_examples=1 << 16,
                         slot_base=0):
         scfg = TgSearchConfig(games, arena_nodes, base, init, seed, slot_base, 0)

@@ -363,3 +363,22 @@ def test_examples_written_in_reference_text_format(orc, tmp_path):
         want[256 - 16 + 9] = 0
         assert np.array_equal(st, want) and np.array_equal(mv, om[i, :k]) and np.array_equal(vs, ov[i, :k]) and res == oh["result"][i]
     e.close()
+
+
+def test_arena_auto_sizing(orc):
+    """arena_nodes = 0: the engine sizes the per-game arenas from the free device memory (2^14 … 2^19 nodes) — a search that
+    overflows a 2^10 arena runs through"""
+    import tak_amd
+
+    e = _mk(5, tak_amd.EVAL_HASH, 8)
+    sts = _roots(orc, 5, 8, seed=2, max_plies=10)
+    e.search_create(8, arena_nodes=1024)
+    e.search_reset(sts)
+    with pytest.raises(tak_amd.TgError):
+        e.search_run(400)
+        e.search_root()
+    e.search_create(8, arena_nodes=0)
+    e.search_reset(sts)
+    e.search_run(400)
+    assert (e.search_root()["root_visits"] == 400).all()
+    e.close()

@@ -175,7 +175,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "MCTS node-expansions/sec (5x5 Tak, 400 sims/move, 4096 games/GPU)",
+            "metric": f"MCTS node-expansions/sec ({args.board}x{args.board} Tak, {args.rollouts} sims/move, {args.games} games/GPU)",
             "value": total_exp / dt,
             "unit": "node-expansions/s",
             "n_gpus": world,

@@ -142,6 +142,18 @@ std::string format_tps(const HostState& s) {
 }
 
 // Tps FromStr + From<Tps> for Game<N> (tak/src/tps.rs:38-96): board, side to move, ply, reserves from the board
+// decimal digits only (no sign, no trailing text), at most 5 of them
+static bool parse_count(const std::string& t, int& out) {
+    if (t.empty() || t.size() > 5) return false;
+    int v = 0;
+    for (char c : t) {
+        if (c < '0' || c > '9') return false;
+        v = v * 10 + (c - '0');
+    }
+    out = v;
+    return true;
+}
+
 bool parse_tps(int n, const std::string& text, HostState& s) {
     s = HostState();
     s.n = n;
@@ -170,8 +182,9 @@ bool parse_tps(int n, const std::string& text, HostState& s) {
             std::string cell = row.substr(i, j == std::string::npos ? std::string::npos : j - i);
             if (cell.empty()) return false;
             if (cell[0] == 'x') {
-                int run = cell.size() > 1 ? std::atoi(cell.c_str() + 1) : 1;
-                if (run < 1) return false;
+                int run = 1;
+                if (cell.size() > 1 && !parse_count(cell.substr(1), run)) return false;
+                if (run < 1 || run > n) return false;
                 x += run;
             } else {
                 if (x >= n) return false;
@@ -193,8 +206,8 @@ bool parse_tps(int n, const std::string& text, HostState& s) {
         if (x != n) return false;
     }
     if (color != "1" && color != "2") return false;
-    int move_number = std::atoi(number.c_str());
-    if (move_number < 1) return false;
+    int move_number = 0;
+    if (!parse_count(number, move_number) || move_number < 1 || move_number > 30000) return false;
     int stones, caps;
     starting_stones(n, stones, caps);
     int ws = stones, wc = caps, bs = stones, bc = caps;
@@ -203,6 +216,7 @@ bool parse_tps(int n, const std::string& text, HostState& s) {
         if (s.top[sq] == 2) { if (s.stack[sq].back() == 0) { ws++; wc--; } else { bs++; bc--; } }
         for (uint8_t c : s.stack[sq]) { if (c == 0) ws--; else bs--; }
     }
+    if (ws < 0 || wc < 0 || bs < 0 || bc < 0) return false;  // more stones on the board than a player owns
     s.h.n = (uint8_t)n;
     s.h.to_move = color == "2";
     s.h.ply = (uint16_t)((move_number - 1) * 2 + (s.h.to_move ? 1 : 0));
@@ -286,11 +300,24 @@ int tg_parse_example(int n, const char* line, void* state, int cap_moves, TgMove
     if (f.size() != 8) return fail(TG_ERR_INVALID_ARG, "example line needs 8 ';'-separated fields");
     HostState hs;
     if (!parse_tps(n, f[0], hs)) return fail(TG_ERR_INVALID_ARG, "example: bad tps");
-    hs.h.white_stones = (uint8_t)std::atoi(f[1].c_str()); hs.h.white_caps = (uint8_t)std::atoi(f[2].c_str());
-    hs.h.black_stones = (uint8_t)std::atoi(f[3].c_str()); hs.h.black_caps = (uint8_t)std::atoi(f[4].c_str());
-    hs.h.half_komi = (int8_t)std::atoi(f[5].c_str());
-    *result = std::strtof(f[6].c_str(), nullptr);
-    pack(hs, (uint8_t*)state);
+    // the fields parse as Rust's u8 / i8 / f32 `FromStr` do (example.rs:108-114): digits only, in range, nothing after them
+    int r[4], komi = 0;
+    for (int i = 0; i < 4; i++)
+        if (!parse_count(f[1 + i], r[i]) || r[i] > 255) return fail(TG_ERR_INVALID_ARG, "example: bad reserve count");
+    {
+        const bool neg = !f[5].empty() && f[5][0] == '-';
+        if (!parse_count(neg ? f[5].substr(1) : f[5], komi) || komi > (neg ? 128 : 127)) return fail(TG_ERR_INVALID_ARG, "example: bad half komi");
+        if (neg) komi = -komi;
+    }
+    {
+        char* end = nullptr;
+        *result = std::strtof(f[6].c_str(), &end);
+        if (f[6].empty() || f[6].size() > 32 || end != f[6].c_str() + f[6].size() || f[6][0] == ' ' || f[6][0] == '\t')
+            return fail(TG_ERR_INVALID_ARG, "example: bad result");
+    }
+    hs.h.white_stones = (uint8_t)r[0]; hs.h.white_caps = (uint8_t)r[1];
+    hs.h.black_stones = (uint8_t)r[2]; hs.h.black_caps = (uint8_t)r[3];
+    hs.h.half_komi = (int8_t)komi;
     int k = 0;
     p = 0;
     const std::string& pol = f[7];
@@ -301,13 +328,22 @@ int tg_parse_example(int n, const char* line, void* state, int cap_moves, TgMove
         if (c == std::string::npos) return fail(TG_ERR_INVALID_ARG, "example: pair has missing delimiter");
         TgMove mv;
         if (!parse_move(n, pair.substr(0, c), mv)) return fail(TG_ERR_INVALID_ARG, "example: bad move " + pair);
-        if (k < cap_moves && moves && visits) { moves[k] = mv; visits[k] = (uint32_t)std::strtoul(pair.c_str() + c + 1, nullptr, 10); }
+        const std::string vs = pair.substr(c + 1);
+        unsigned long long v = 0;
+        if (vs.empty() || vs.size() > 10) return fail(TG_ERR_INVALID_ARG, "example: bad visit count in " + pair);
+        for (char ch : vs) {
+            if (ch < '0' || ch > '9') return fail(TG_ERR_INVALID_ARG, "example: bad visit count in " + pair);
+            v = v * 10 + (unsigned)(ch - '0');
+        }
+        if (v > 0xffffffffull) return fail(TG_ERR_INVALID_ARG, "example: visit count out of range in " + pair);
+        if (k < cap_moves && moves && visits) { moves[k] = mv; visits[k] = (uint32_t)v; }
         k++;
         if (q == std::string::npos) break;
         p = q + 1;
     }
     *n_moves = k;
     if (k > cap_moves) return fail(TG_ERR_INVALID_ARG, "example: more moves than cap_moves");
+    pack(hs, (uint8_t*)state);
     return TG_OK;
 }
 

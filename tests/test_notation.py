@@ -1,6 +1,7 @@
 """Text formats of the product (PTN, TPS, example lines) — host-only, no GPU needed — against the oracle's
 restatement and the reference's TPS known-answer string."""
 import numpy as np
+import pytest
 
 import tak_amd
 
@@ -81,3 +82,54 @@ def test_example_file_roundtrip(orc, tmp_path):
     want[:, 256 - 16 + 9] = 0  # reversible_plies is not part of the text format
     assert len(st) == len(hdr) > 5 and np.array_equal(st, want) and np.array_equal(nm, hdr["n_moves"])
     assert np.array_equal(mv, moves) and np.array_equal(vs, visits) and np.array_equal(res, hdr["result"])
+
+
+def test_parsers_survive_garbage(orc):
+    """tg_parse_move / tg_parse_tps / tg_parse_example are host code fed with files from elsewhere: random and mutated input
+    must come back as an error (or a valid parse), never crash or write out of bounds"""
+    import random
+
+    rnd = random.Random(5)
+    n = 5
+    sp = orc.SelfPlay(n, 2, head=orc.HEAD_FC5, evaluator=orc.EVAL_HASH, rollouts=8, total_games=2, seed=4)
+    for _ in range(200):
+        sp.step(1)
+        if not sp.states()[1].any():
+            break
+    hdr, states, moves, visits = sp.drain(1000)
+    lines = []
+    for i in range(min(len(hdr), 20)):
+        k = int(hdr["n_moves"][i])
+        lines.append(tak_amd.format_example(n, states[i], moves[i, :k], visits[i, :k], float(hdr["result"][i])))
+    alphabet = "abcdefgh12345678SC+-<>x/,;:. \t-0129"
+    ok = bad = 0
+    for trial in range(6000):
+        kind = trial % 3
+        if kind == 0:
+            text = "".join(rnd.choice(alphabet) for _ in range(rnd.randrange(0, 40)))
+        else:
+            text = list(rnd.choice(lines))
+            for _ in range(rnd.randrange(1, 6)):
+                pos = rnd.randrange(len(text))
+                op = rnd.randrange(3)
+                if op == 0:
+                    text[pos] = rnd.choice(alphabet)
+                elif op == 1:
+                    del text[pos]
+                else:
+                    text.insert(pos, rnd.choice(alphabet) * rnd.randrange(1, 30))
+            text = "".join(text)
+        for size in (5, 6):
+            for fn in (tak_amd.parse_move, tak_amd.parse_tps, tak_amd.parse_example):
+                try:
+                    fn(size, text)
+                    ok += 1
+                except tak_amd.TgError:
+                    bad += 1
+    assert bad > 1000 and ok > 0
+    # very long inputs
+    for fn in (tak_amd.parse_move, tak_amd.parse_tps, tak_amd.parse_example):
+        with pytest.raises(tak_amd.TgError):
+            fn(5, "x5," * 100000)
+        with pytest.raises(tak_amd.TgError):
+            fn(5, lines[0].split(";")[0] + ";" + "9" * 5000)

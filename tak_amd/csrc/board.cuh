@@ -538,6 +538,7 @@ __device__ inline void ws_encode(const WState& s, const Geom& g, float* out, int
 // pattern) → index into the legacy 1575 table (−1 = the reference panics), built on the host by rule.
 __device__ inline int move_index_dev(uint32_t mv, int n, bool legacy5, const int16_t* __restrict__ lut5) {
     uint32_t sq = mv & 63u, f = (mv >> 6) & 3u, pat = (mv >> 8) & 0xffu;
+    if ((int)sq >= n * n) return -1;  // not a square of this board (garbage from the caller must not index past the LUT)
     if (legacy5) {
         int row = (int)sq / 5, col = (int)sq % 5;
         if (pat == 0) return f > 2 ? -1 : (col * 5 + row) * 3 + (int)f;

@@ -77,6 +77,8 @@ struct TgEngine {
 };
 
 namespace tg {
+// engine.hip: host-side sanity check of caller-supplied packed states (TG_ERR_INVALID_ARG naming the first bad one)
+int validate_states(const TgEngine* e, int k, const uint8_t* states, const char* who);
 // net.hip
 int net_create(TgEngine* e);
 void net_destroy(Net* n);

@@ -315,6 +315,8 @@ int tg_search_reset(TgEngine* e, const void* states) {
     if (rc) return rc;
     if (!states) return fail(TG_ERR_INVALID_ARG, "tg_search_reset: null states");
     Search* s = e->search;
+    rc = validate_states(e, s->d.G, (const uint8_t*)states, "tg_search_reset");
+    if (rc) return rc;
     const size_t G = (size_t)s->d.G;
     TG_HIP(hipMemcpyAsync(s->root_state.p, states, G * e->g.bytes, hipMemcpyHostToDevice, e->stream));
     TG_HIP(hipMemsetAsync(s->alive.p, 1, G, e->stream));

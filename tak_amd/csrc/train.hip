@@ -326,6 +326,8 @@ int upload_chunk(TgEngine* e, int n, const uint8_t* states, const int32_t* n_mov
     std::vector<float> z8((size_t)n * 8);
     for (int i = 0; i < n; i++) {
         const int s = order ? order[i] : i;
+        int vrc = validate_states(e, 1, states + (size_t)s * sb, "training example");
+        if (vrc) return vrc;
         if (n_moves[s] <= 0 || n_moves[s] > TG_MAX_MOVES) return fail(TG_ERR_INVALID_ARG, "training example: n_moves out of range");
         uint64_t total = 0;
         for (int k = 0; k < n_moves[s]; k++) total += visits[(size_t)s * TG_MAX_MOVES + k];

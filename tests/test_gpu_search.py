@@ -382,3 +382,31 @@ def test_arena_auto_sizing(orc):
     e.search_run(400)
     assert (e.search_root()["root_visits"] == 400).all()
     e.close()
+
+
+def test_states_no_game_can_reach_are_refused(orc):
+    """tg_search_reset validates caller-supplied states on the host: the tree kernels size child arrays from a state's
+    move count, so garbage is an argument error, not something to explore"""
+    import tak_amd
+
+    e = _mk(5, tak_amd.EVAL_HASH, 4)
+    e.search_create(4, arena_nodes=1 << 12)
+    good = _roots(orc, 5, 4, seed=1, max_plies=20)
+    e.search_reset(good)
+    hdr = 256 - 16
+    cases = []
+    bad = good.copy(); bad[1, hdr + 0] = 6; cases.append(bad)                      # another board size
+    bad = good.copy(); bad[2, 200 + 3] = 63 | (2 << 6); cases.append(bad)           # a 63-high stack on 5×5
+    bad = good.copy(); bad[0, hdr + 4] = 200; cases.append(bad)                     # 200 stones in reserve
+    bad = good.copy(); bad[3, 200:225] = 0; bad[3, 0:8] = 255; cases.append(bad)    # colour bits on an empty square
+    bad = good.copy(); bad[0, hdr + 1] = 7; cases.append(bad)                       # to_move = 7
+    rng = np.random.default_rng(0)
+    bad = rng.integers(0, 256, good.shape, dtype=np.uint8); cases.append(bad)       # noise
+    for bad in cases:
+        with pytest.raises(tak_amd.TgError) as ei:
+            e.search_reset(bad)
+        assert ei.value.code == -1 and "is not a position" in str(ei.value)
+    e.search_reset(good)  # the engine is still usable
+    e.search_run(20)
+    assert (e.search_root()["root_visits"] == 20).all()
+    e.close()

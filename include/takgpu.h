@@ -276,7 +276,8 @@ typedef struct TgSearchConfig {
 } TgSearchConfig;
 
 int tg_search_create(TgEngine* e, const TgSearchConfig* cfg);
-/* (re)start every tree as Node::default() with the given root states (host, games packed states) */
+/* (re)start every tree as Node::default() with the given root states (host, games packed states).  The states are checked
+ * on the host (board size, heights, colour bits, reserves): one no game can reach → TG_ERR_INVALID_ARG naming it. */
 int tg_search_reset(TgEngine* e, const void* states);
 /* run `iters` lock-step iterations (virtual_rollout → policy_eval → devirtualize_path).
  * active: optional host mask (games bytes, 0 = skip this game), NULL = all. */
@@ -386,7 +387,8 @@ typedef struct TgTrainConfig {
 int tg_train_create(TgEngine* e, const TgTrainConfig* cfg);
 /* train_inner (network.rs:58-97) on one chunk of n ≤ chunk_size examples (layout of tg_selfplay_drain:
  * states, n_moves, rows of TG_MAX_MOVES moves / visits; results = Example::result).  Returns the two losses
- * the reference prints (loss_p, loss_z); *stepped = 1 when this chunk completed an optimiser step. */
+ * the reference prints (loss_p, loss_z); *stepped = 1 when this chunk completed an optimiser step.  Examples are validated on
+ * the host (a reachable state, 1 ≤ n_moves ≤ TG_MAX_MOVES, at least one visit) → TG_ERR_INVALID_ARG. */
 int tg_train_chunk(TgEngine* e, int n, const void* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
                    const float* results, float* loss_p, float* loss_z, int32_t* stepped);
 /* Network::train (network.rs:37-56): fresh Adam state, shuffle (Philox keyed by seed; the reference uses

@@ -179,14 +179,12 @@ static int search_reset_trees(TgEngine* e) {
 // one lock-step iteration: the body of train/src/self_play.rs:181-210
 static int search_iterate(TgEngine* e, const uint8_t* d_active) {
     Search* s = e->search;
-    // `batch` virtual rollouts per tree (Player's batching model, alpha-tak/src/player.rs:77-93) are `batch` launches of the
-    // select kernel — the kernel boundary orders a pass's tree updates before the next pass reads them — then ONE network
-    // batch of games × batch leaves, then the de-virtualisations in the same order
+    // `batch` virtual rollouts per tree (Player's batching model, alpha-tak/src/player.rs:77-93) run back to back inside the
+    // select kernel (a game's tree belongs to one wave), then ONE network batch of games × batch leaves, then the
+    // de-virtualisations in the same order inside the backup kernel
     SearchDev d = s->d;
-    for (int b = 0; b < s->d.batch; b++) {
-        d.pass = b;
-        launch_select(e->stream, d, d_active);
-    }
+    d.pass = s->d.batch > 1 ? -1 : 0;  // -1: the kernel runs the `batch` passes of a game back to back in that game's wave
+    launch_select(e->stream, d, d_active);
     TG_HIP(hipGetLastError());
     if (e->cfg.evaluator == TG_EVAL_RESNET) {
         const int leaves = s->d.G * s->d.batch;
@@ -194,10 +192,7 @@ static int search_iterate(TgEngine* e, const uint8_t* d_active) {
                              : net_forward_states_dev(e, leaves, s->d.leaf_state, s->d.policy, s->d.eval);
         if (rc) return rc;
     }
-    for (int b = 0; b < s->d.batch; b++) {
-        d.pass = b;
-        launch_backup(e->stream, d);
-    }
+    launch_backup(e->stream, d);
     TG_HIP(hipGetLastError());
     return TG_OK;
 }

@@ -49,14 +49,12 @@ __device__ inline void update_concrete(NodeHot& h, float reward) {
 // virtual visit (or back a concrete result up when the rollout ends on a terminal node), and leave
 // the leaf encoded in the network input batch.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __restrict__ active) {
-    __shared__ uint32_t path_lds[WPB][MAX_DEPTH];
-    const int g = game_of_wave();
-    if (g >= S.G) return;
+__device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* __restrict__ active, const int g, const int pass,
+                                            uint32_t* path) {
     const int lane = lane_id();
-    // leaf slot of this pass: `batch` virtual rollouts per tree and iteration (Player's batching, player.rs:77-93) are `batch`
-    // launches of this kernel, pass S.pass writing slot g·batch + pass
-    const size_t slot = (size_t)g * (size_t)S.batch + (size_t)S.pass;
+    // leaf slot of this pass: `batch` virtual rollouts per tree and iteration (Player's batching, player.rs:77-93), pass p
+    // writing slot g·batch + p
+    const size_t slot = (size_t)g * (size_t)S.batch + (size_t)pass;
     if (!S.alive[g] || (active && !active[g])) {
         if (lane == 0) S.leaf_kind[slot] = 0;
         return;
@@ -67,7 +65,6 @@ __global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __re
     const size_t base = ((size_t)g * 2 + S.sel[g]) * (size_t)S.cap;
     NodeHot* hot = S.hot + base;
     NodeCold* cold = S.cold + base;
-    uint32_t* path = path_lds[threadIdx.x >> 6];
     const uint32_t root_color = s.to_move;
     uint32_t node = 0;
     int depth = 0;
@@ -214,14 +211,27 @@ __global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __re
     }
 }
 
+// One wave per game.  S.pass ≥ 0: that one virtual rollout; S.pass < 0: all `batch` virtual rollouts of the iteration one after
+// the other — a game's tree is only ever touched by its own wave, so the passes need no kernel boundary between them, only
+// the wave's own stores made visible to its later loads (agent-scope fence: write back, invalidate the vector L1).
+__global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __restrict__ active) {
+    __shared__ uint32_t path_lds[WPB][MAX_DEPTH];
+    const int g = game_of_wave();
+    if (g >= S.G) return;
+    uint32_t* path = path_lds[threadIdx.x >> 6];
+    const int p0 = S.pass < 0 ? 0 : S.pass, p1 = S.pass < 0 ? S.batch : S.pass + 1;
+    for (int p = p0; p < p1; p++) {
+        select_pass(S, active, g, p, path);
+        if (p + 1 < p1) __threadfence();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // devirtualize_path, mcts.rs:67-91: real priors for the leaf's children, value backed up with
 // alternating sign, virtual visits removed.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_backup(SearchDev S) {
-    const int g = game_of_wave();
-    if (g >= S.G) return;
-    const size_t slot = (size_t)g * (size_t)S.batch + (size_t)S.pass;
+__device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, const int pass) {
+    const size_t slot = (size_t)g * (size_t)S.batch + (size_t)pass;
     if (S.leaf_kind[slot] != 1) return;
     const int lane = lane_id();
     const size_t base = ((size_t)g * 2 + S.sel[g]) * (size_t)S.cap;
@@ -261,6 +271,17 @@ __global__ __launch_bounds__(256) void k_backup(SearchDev S) {
         hot[nd].q = h.q;
         hot[nd].visits = h.visits;
         hot[nd].virt = h.virt;
+    }
+}
+
+// S.pass as in k_select: one de-virtualisation, or all of the iteration's in rollout order
+__global__ __launch_bounds__(256) void k_backup(SearchDev S) {
+    const int g = game_of_wave();
+    if (g >= S.G) return;
+    const int p0 = S.pass < 0 ? 0 : S.pass, p1 = S.pass < 0 ? S.batch : S.pass + 1;
+    for (int p = p0; p < p1; p++) {
+        backup_pass(S, g, p);
+        if (p + 1 < p1) __threadfence();
     }
 }
 

@@ -101,6 +101,7 @@ struct SearchDev;
 struct SelfPlayDev;
 void launch_select(hipStream_t st, const SearchDev& S, const uint8_t* active);
 void launch_backup(hipStream_t st, const SearchDev& S);
+void launch_backup_select(hipStream_t st, const SearchDev& S);  // backup of iteration i + select of iteration i+1 (batch 1)
 void launch_dirichlet(hipStream_t st, const SearchDev& S, const uint8_t* active, float alpha, float ratio);
 void launch_apply_noise(hipStream_t st, const SearchDev& S, const uint8_t* active, const float* noise, float ratio);
 void launch_reroot(hipStream_t st, const SearchDev& S, const int32_t* op);

@@ -226,6 +226,23 @@ static int search_iterate_many(TgEngine* e, int iters) {
     Search* s = e->search;
     if (iters <= 0) return TG_OK;
     if (!dual_stream_ok(e)) {
+        if (s->d.batch == 1 && iters > 1 && !getenv("TG_NO_FUSED_BACKUP_SELECT")) {
+            // select(0) | net | backup(0)+select(1) | net | … | backup(iters-1): one tree kernel per iteration
+            SearchDev d = s->d;
+            d.pass = 0;
+            launch_select(e->stream, d, nullptr);
+            for (int i = 0; i < iters; i++) {
+                if (e->cfg.evaluator == TG_EVAL_RESNET) {
+                    int rc = s->d.planes ? net_forward_dev(e, s->d.G, s->d.planes, s->d.policy, s->d.eval)
+                                         : net_forward_states_dev(e, s->d.G, s->d.leaf_state, s->d.policy, s->d.eval);
+                    if (rc) return rc;
+                }
+                if (i + 1 < iters) launch_backup_select(e->stream, d);
+                else launch_backup(e->stream, d);
+            }
+            TG_HIP(hipGetLastError());
+            return TG_OK;
+        }
         for (int i = 0; i < iters; i++) {
             int rc = search_iterate(e, nullptr);
             if (rc) return rc;

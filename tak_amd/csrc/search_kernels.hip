@@ -213,7 +213,8 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
 
 // One wave per game.  S.pass ≥ 0: that one virtual rollout; S.pass < 0: all `batch` virtual rollouts of the iteration one after
 // the other — a game's tree is only ever touched by its own wave, so the passes need no kernel boundary between them, only
-// the wave's own stores made visible to its later loads (agent-scope fence: write back, invalidate the vector L1).
+// the wave's own stores ordered before its later loads (s_waitcnt: a wave's accesses go through one in-order, write-through
+// L1 path; an agent-scope fence would write back the whole L2 per wave and cost more than the launches it replaces).
 __global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __restrict__ active) {
     __shared__ uint32_t path_lds[WPB][MAX_DEPTH];
     const int g = game_of_wave();
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __re
     const int p0 = S.pass < 0 ? 0 : S.pass, p1 = S.pass < 0 ? S.batch : S.pass + 1;
     for (int p = p0; p < p1; p++) {
         select_pass(S, active, g, p, path);
-        if (p + 1 < p1) __threadfence();
+        if (p + 1 < p1) wave_sync_mem();
     }
 }
 
@@ -281,8 +282,20 @@ __global__ __launch_bounds__(256) void k_backup(SearchDev S) {
     const int p0 = S.pass < 0 ? 0 : S.pass, p1 = S.pass < 0 ? S.batch : S.pass + 1;
     for (int p = p0; p < p1; p++) {
         backup_pass(S, g, p);
-        if (p + 1 < p1) __threadfence();
+        if (p + 1 < p1) wave_sync_mem();
     }
+}
+
+// De-virtualise iteration i and select the leaf of iteration i + 1 in one launch (one leaf per game): the two touch the same
+// few nodes of the same tree from the same wave, so the second finds them in cache and one kernel boundary per iteration
+// disappears.  Same device functions as the separate kernels → same trees.
+__global__ __launch_bounds__(256) void k_backup_select(SearchDev S) {
+    __shared__ uint32_t path_lds[WPB][MAX_DEPTH];
+    const int g = game_of_wave();
+    if (g >= S.G) return;
+    backup_pass(S, g, 0);
+    wave_sync_mem();
+    select_pass(S, nullptr, g, 0, path_lds[threadIdx.x >> 6]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -730,6 +743,7 @@ void launch_select(hipStream_t st, const SearchDev& S, const uint8_t* active) {
     hipLaunchKernelGGL(k_select, wgrid(S.G), dim3(256), 0, st, S, active);
 }
 void launch_backup(hipStream_t st, const SearchDev& S) { hipLaunchKernelGGL(k_backup, wgrid(S.G), dim3(256), 0, st, S); }
+void launch_backup_select(hipStream_t st, const SearchDev& S) { hipLaunchKernelGGL(k_backup_select, wgrid(S.G), dim3(256), 0, st, S); }
 void launch_dirichlet(hipStream_t st, const SearchDev& S, const uint8_t* active, float alpha, float ratio) {
     hipLaunchKernelGGL(k_dirichlet, dim3(S.G), dim3(64), 0, st, S, active, alpha, ratio);
 }

@@ -387,6 +387,17 @@ int net_forward_dev(TgEngine* e, int nb, const float* d_planes, float* d_policy,
 
 bool net_takes_states(const TgEngine* e) { return net_ready(e) && (e->net->fused || e->net->s3); }
 
+// FC head with the value column: the logits buffer ([max_batch][*ld], logit P = value pre-activation) the search reads when it
+// passes d_policy = nullptr to the forward (no softmax kernel, no probabilities in HBM); nullptr for every other topology
+const float* net_fc_logits(const TgEngine* e, int* ld) {
+    if (!net_ready(e)) return nullptr;
+    const Net* n = e->net;
+    if (e->cfg.policy_head != TG_HEAD_FC5 || !n->value_in_fc || e->policy_size > 2048) return nullptr;
+    if (n->s3 && !n->s3_fc_on) return nullptr;  // split tower with the f32 FC: keep the plain path
+    *ld = n->s3 && n->s3_fc_on ? n->s3_np : n->policy_np;  // the row stride the FC kernel in use writes
+    return n->logits.as<float>();
+}
+
 // half batch on its own stream (only when the tower encodes from states); see search.hip
 int net_forward_states_at(TgEngine* e, int nb, const uint8_t* d_states, float* d_policy, float* d_eval, hipStream_t st, int pos0) {
     if (!net_takes_states(e)) return fail(TG_ERR_STATE, "net_forward_states_at needs the fused tower");
@@ -469,14 +480,15 @@ static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const ui
         TG_HIP(launch_softmax(st, logits, nsq * L.cout_pad, true, nsq, L.cout_pad, e->policy_size, nb, d_policy));
     } else if (n->s3 && n->s3_fc_on) {
         TG_HIP(launch_fc_s3(st, x, n->s3_fc.p, n->s3_fc_b.as<float>(), logits, nb, nsq * F, n->s3_np, n->s3_np, e->policy_size + (n->value_in_fc ? 1 : 0)));
-        TG_HIP(launch_softmax(st, logits, n->s3_np, false, nsq, 0, e->policy_size, nb, d_policy, n->value_in_fc ? d_eval : nullptr));
+        if (d_policy) TG_HIP(launch_softmax(st, logits, n->s3_np, false, nsq, 0, e->policy_size, nb, d_policy, n->value_in_fc ? d_eval : nullptr));
     } else {
         TG_HIP(launch_gemm(st, x, nsq * F, n->policy_w.as<float>(), n->policy_b.as<float>(), logits, nb, nsq * F, n->policy_np,
                            n->policy_np, e->policy_size + (n->value_in_fc ? 1 : 0)));
-        TG_HIP(launch_softmax(st, logits, n->policy_np, false, nsq, 0, e->policy_size, nb, d_policy, n->value_in_fc ? d_eval : nullptr));
+        if (d_policy) TG_HIP(launch_softmax(st, logits, n->policy_np, false, nsq, 0, e->policy_size, nb, d_policy, n->value_in_fc ? d_eval : nullptr));
     }
+    if (!d_policy && !(e->cfg.policy_head == TG_HEAD_FC5 && n->value_in_fc)) return fail(TG_ERR_STATE, "logits-only forward needs the FC head with the value column");
     if (e->cfg.policy_head == TG_HEAD_FC5 && n->value_in_fc) {
-        // eval = tanh(logit P), written by the softmax kernel
+        // eval = tanh(logit P), written by the softmax kernel (or taken by the tree backup straight from the logits)
     } else if (n->s3 && (n->s3_fc_on || n->s3_head_on)) TG_HIP(launch_value_head_s3(st, x, n->value_w.as<float>(), n->value_b, nb, nsq * F, d_eval));
     else TG_HIP(launch_value_head(st, x, n->value_w.as<float>(), n->value_b, nb, nsq * F, d_eval));
     if (chain) chain->push_back(prof_event(n, st));

@@ -19,6 +19,7 @@
 
 #include "board.cuh"
 #include "conv_mainloop.cuh"
+#include "softmax.cuh"
 #include "kernels.h"
 
 namespace tg {
@@ -617,17 +618,6 @@ __global__ __launch_bounds__(256) void k_fc_small(const float* __restrict__ A, i
     }
 }
 
-__device__ inline float wave_sum(float v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    return v;
-}
-__device__ inline float wave_max(float v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
-    return v;
-}
-
 // value head: Linear(F·N² → 1) + tanh (net5.rs:62,109 / net6.rs:57,104-107).  One wave per position;
 // wv is permuted to the NHWC order of the activations.
 __global__ __launch_bounds__(256) void k_value_head(const float* __restrict__ act, const float* __restrict__ wv, float bv,
@@ -665,7 +655,7 @@ __global__ __launch_bounds__(256) void k_softmax(const float* __restrict__ logit
         return x[sq * ch_stride + ch];
     };
     // the row is read once and kept in registers when it fits (P ≤ 8·256: the FC head's 1575 outputs)
-    constexpr int KEEP = 8;
+    constexpr int KEEP = SOFTMAX_KEEP;
     const bool cached = P <= KEEP * 256;
     float v[KEEP];
     float mx = -INFINITY;

@@ -66,6 +66,9 @@ struct SearchDev {
     float* planes;       // [G][nsq][cin_pad] NHWC network input (null when the tower encodes from leaf_state)
     uint8_t* leaf_state; // [G][state bytes] packed leaf positions
     float* policy;       // [G][P]
+    const float* logits; // FC head: [G·batch][logit_ld] policy logits with the value pre-activation in column P; when set the
+                         // backup takes softmax and tanh itself (softmax.cuh) and `policy` / `eval` are not produced
+    int logit_ld;
     float* eval;         // [G]
     // constants
     const float* ctab;   // exploration_rate(n) for integer n (host logf, mcts.rs:10-12)

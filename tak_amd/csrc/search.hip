@@ -159,6 +159,7 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     d.G = cfg->games; d.cap = cfg->arena_nodes; d.n = e->g.n; d.cin_pad = cin_pad; d.P = e->policy_size; d.ctab_size = ctab_size;
     d.legacy5 = e->legacy5 ? 1 : 0; d.evaluator = e->cfg.evaluator; d.slot_base = cfg->slot_base; d.seed = cfg->seed;
     d.batch = (int)B; d.pass = 0;
+    d.logits = nullptr; d.logit_ld = 0;  // refreshed before every iteration (bind_logits)
     e->search = sp.release();
     return TG_OK;
 }
@@ -176,9 +177,24 @@ static int search_reset_trees(TgEngine* e) {
     return TG_OK;
 }
 
+// FC-head networks: the backup reads the network's logits buffer directly (softmax statistics and tanh in the tree kernel,
+// softmax.cuh).  Bound per call: the weights may have been re-finalised (tg_train_commit, another precision) since the
+// search was created.
+static void bind_logits(TgEngine* e) {
+    Search* s = e->search;
+    s->d.logits = nullptr;
+    s->d.logit_ld = 0;
+    static const bool off = getenv("TG_DUAL_STREAM") != nullptr || getenv("TG_NO_FUSED_SOFTMAX") != nullptr;
+    if (off || e->cfg.evaluator != TG_EVAL_RESNET) return;
+    int ld = 0;
+    const float* lg = net_fc_logits(e, &ld);
+    if (lg) { s->d.logits = lg; s->d.logit_ld = ld; }
+}
+
 // one lock-step iteration: the body of train/src/self_play.rs:181-210
 static int search_iterate(TgEngine* e, const uint8_t* d_active) {
     Search* s = e->search;
+    bind_logits(e);
     // `batch` virtual rollouts per tree (Player's batching model, alpha-tak/src/player.rs:77-93) run back to back inside the
     // select kernel (a game's tree belongs to one wave), then ONE network batch of games × batch leaves, then the
     // de-virtualisations in the same order inside the backup kernel
@@ -188,8 +204,9 @@ static int search_iterate(TgEngine* e, const uint8_t* d_active) {
     TG_HIP(hipGetLastError());
     if (e->cfg.evaluator == TG_EVAL_RESNET) {
         const int leaves = s->d.G * s->d.batch;
-        int rc = s->d.planes ? net_forward_dev(e, leaves, s->d.planes, s->d.policy, s->d.eval)
-                             : net_forward_states_dev(e, leaves, s->d.leaf_state, s->d.policy, s->d.eval);
+        float* pol = s->d.logits ? nullptr : s->d.policy;  // logits mode: the backup takes softmax / tanh itself
+        int rc = s->d.planes ? net_forward_dev(e, leaves, s->d.planes, pol, s->d.eval)
+                             : net_forward_states_dev(e, leaves, s->d.leaf_state, pol, s->d.eval);
         if (rc) return rc;
     }
     launch_backup(e->stream, d);
@@ -225,6 +242,7 @@ static bool dual_stream_ok(TgEngine* e) {
 static int search_iterate_many(TgEngine* e, int iters) {
     Search* s = e->search;
     if (iters <= 0) return TG_OK;
+    bind_logits(e);
     if (!dual_stream_ok(e)) {
         if (s->d.batch == 1 && iters > 1 && !getenv("TG_NO_FUSED_BACKUP_SELECT")) {
             // select(0) | net | backup(0)+select(1) | net | … | backup(iters-1): one tree kernel per iteration
@@ -233,8 +251,9 @@ static int search_iterate_many(TgEngine* e, int iters) {
             launch_select(e->stream, d, nullptr);
             for (int i = 0; i < iters; i++) {
                 if (e->cfg.evaluator == TG_EVAL_RESNET) {
-                    int rc = s->d.planes ? net_forward_dev(e, s->d.G, s->d.planes, s->d.policy, s->d.eval)
-                                         : net_forward_states_dev(e, s->d.G, s->d.leaf_state, s->d.policy, s->d.eval);
+                    float* pol = s->d.logits ? nullptr : s->d.policy;
+                    int rc = s->d.planes ? net_forward_dev(e, s->d.G, s->d.planes, pol, s->d.eval)
+                                         : net_forward_states_dev(e, s->d.G, s->d.leaf_state, pol, s->d.eval);
                     if (rc) return rc;
                 }
                 if (i + 1 < iters) launch_backup_select(e->stream, d);

@@ -11,6 +11,7 @@
 #include "kernels.h"
 #include "rng.cuh"
 #include "search.cuh"
+#include "softmax.cuh"
 
 namespace tg {
 
@@ -245,7 +246,14 @@ __device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, con
     const uint32_t nchild = uni((uint32_t)lc.nres) & 0xfffu, cb = uni(lc.child);
     float e;
     uint64_t hsh = 0;
-    if (S.evaluator == TG_EVAL_RESNET) e = S.eval[slot];
+    // FC head: softmax statistics and tanh from the logits row, in k_softmax's order (the probabilities of the ≈ 45 children are
+    // all that is needed — the other 1530 never get written or read)
+    const float* lrow = S.logits ? S.logits + slot * (size_t)S.logit_ld : nullptr;
+    float lmx = 0.0f, linv = 0.0f;
+    if (S.evaluator == TG_EVAL_RESNET && lrow) {
+        softmax_stats_wave(lrow, S.P, lmx, linv);
+        e = tanhf(lrow[S.P]);
+    } else if (S.evaluator == TG_EVAL_RESNET) e = S.eval[slot];
     else if (S.evaluator == TG_EVAL_HASH) { hsh = S.leaf_hash[slot]; e = hash_eval(hsh); }
     else e = 0.0f;
     const float* pol = S.policy + slot * S.P;
@@ -255,7 +263,7 @@ __device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, con
         int idx = move_index_dev(mv, S.n, S.legacy5 != 0, S.lut5);
         float p;
         if (idx < 0 || idx >= S.P) { bad = true; p = 0.0f; }
-        else if (S.evaluator == TG_EVAL_RESNET) p = pol[idx];
+        else if (S.evaluator == TG_EVAL_RESNET) p = lrow ? expf(lrow[idx] - lmx) * linv : pol[idx];
         else if (S.evaluator == TG_EVAL_HASH) p = hash_policy(hsh, (uint32_t)idx);
         else p = 1.0f;
         hot[cb + i].prior = p;

@@ -371,21 +371,22 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
         __syncthreads();  // every wave has finished reading the previous image
         const int LS4n = (F + LDS_PAD16) >> 2;
         const bool conv1 = (layer & 1) == 1;  // next layer is conv2 of the same block: it starts from the block input
-        f32x4 nxt[RTW];
-#pragma unroll
-        for (int j = 0; j < RTW; j++) {
-            nxt[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (conv1 && rho0 + j * 16 < rows) nxt[j] = lds4[(rho0 + j * 16) * LS4n + (ch0 >> 2) + q];  // own tile of X
-        }
         Cpad = F;
         LS4 = LS4n;
+        // tile by tile: read the own tile of X (the initial value of conv2's accumulator), overwrite it with this layer's
+        // output — no second register set (at layer 0 the pitch changes: conv1 is false there, nothing is read back)
 #pragma unroll
-        for (int j = 0; j < RTW; j++)
-            if (rho0 + j * 16 < rows) lds4[(rho0 + j * 16) * LS4 + (ch0 >> 2) + q] = acc[j];
+        for (int j = 0; j < RTW; j++) {
+            f32x4 x0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (rho0 + j * 16 < rows) {
+                const int at = (rho0 + j * 16) * LS4 + (ch0 >> 2) + q;
+                if (conv1) x0 = lds4[at];
+                lds4[at] = acc[j];
+            }
+            acc[j] = x0;
+        }
         if (layer == 0)
             for (int idx = tid; idx < LS4; idx += NWAVES * 64) lds4[rows * LS4 + idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int j = 0; j < RTW; j++) acc[j] = nxt[j];
         __syncthreads();
     }
 }

@@ -272,3 +272,31 @@ def test_example_validation(orc):
     with pytest.raises(tak_amd.TgError):
         e.train_chunk(np.tile(sts, (2, 1)), np.tile(cnt, 2), np.tile(mv, (2, 1)), np.tile(visits, (2, 1)), np.tile(results, 2))  # > chunk_size
     e.close()
+
+
+def test_training_from_an_example_file(orc, tmp_path):
+    """train/src/main.rs:69-80 + Network::train: examples written in the reference's `.data` text format, read back with
+    read_examples and trained on — the same result as training on the arrays they came from (the text format drops only
+    reversible_plies, which the encoder does not read)."""
+    import tak_amd
+
+    n, blocks, filters, head = 5, 1, 32, "fc5"
+    net = torch_ref.make_net(n, blocks, filters, head, seed=4)
+    ex = _examples(orc, n, 24, seed=3)
+    states, n_moves, moves, visits, results = ex
+    path = tmp_path / "selfplay.data"
+    with open(path, "w") as f:
+        for i in range(len(states)):
+            k = int(n_moves[i])
+            f.write(tak_amd.format_example(n, states[i], moves[i, :k], visits[i, :k], float(results[i])) + "\n")
+    back = tak_amd.read_examples(n, path)
+    assert np.array_equal(back[1], n_moves) and np.array_equal(back[2], moves) and np.array_equal(back[3], visits)
+    out = []
+    for data in (ex, back):
+        e = _engine(n, blocks, filters, head)
+        e.load_state_dict(torch_ref.abi_tensors(net))
+        e.train_create(learning_rate=1e-3, chunk_size=8, chunks_in_step=1)
+        lp, lz, steps = e.train(*data, seed=7)
+        out.append((lp, lz, steps, e.train_get_tensor("value.weight", (1, filters * n * n))))
+        e.close()
+    assert out[0][:3] == out[1][:3] and out[0][2] == 3 and np.array_equal(out[0][3], out[1][3])

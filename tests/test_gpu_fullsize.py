@@ -154,3 +154,57 @@ def test_training_chunk_full_size_properties(orc):
     lp2, v2 = e.train_forward(a_states[perm])
     assert np.abs(lp1[perm] - lp2).max() < 1e-4 and np.abs(v1[perm] - v2).max() < 1e-4
     e.close()
+
+
+def test_config_c3_full_size(orc):
+    """BASELINE config C3 (6×6, 4096 concurrent games, 10-block × 128-filter net, conv-251 policy head) at full width:
+    size-independent properties of the forward, the search and two plies of self-play, and a slice of trees bit for bit
+    against the oracle fed by the same network kernels."""
+    import tak_amd
+
+    n, blocks, filters = 6, 10, 128
+    net = torch_ref.make_net(n, blocks, filters, "conv", seed=0, randomize_bn=False)
+    tensors = torch_ref.abi_tensors(net)
+    e = tak_amd.Engine(n, res_blocks=blocks, filters=filters, evaluator=tak_amd.EVAL_RESNET, max_batch=G)
+    e.load_state_dict(tensors)
+    base = orc.random_positions(n, 2000, seed=5, max_plies=70, half_komi=4)
+    base = base[orc.result(n, base) == 0]
+    sts = np.tile(base, (G // len(base) + 1, 1))[:G]
+    p, v = e.policy_eval(sts)
+    assert p.shape == (G, 9036) and np.abs(p.sum(1) - 1).max() < 2e-5 and (p > 0).all() and (np.abs(v) <= 1).all()
+    idx = np.arange(0, G, 128)
+    p_ref, v_ref = torch_ref.forward(net, orc.encode(n, sts[idx]))
+    assert np.abs(p[idx] - p_ref).max() <= 1e-4 and np.abs(v[idx] - v_ref).max() <= 1e-4
+    assert np.array_equal(p[0], p[len(base)]) and v[0] == v[len(base)]  # same position, another slot of the batch
+    iters = 12
+    e.search_create(G, arena_nodes=1 << 13)
+    e.search_reset(sts)
+    e.search_run(iters)
+    r = e.search_root()
+    exp, ev = e.search_counters()
+    assert exp == G * iters and ev <= exp and (r["root_visits"] == iters).all()
+    assert np.array_equal(r["counts"], orc.movegen(n, sts)[1])
+    ev_eng = tak_amd.Engine(n, res_blocks=blocks, filters=filters, evaluator=tak_amd.EVAL_RESNET, max_batch=16)
+    ev_eng.load_state_dict(tensors)
+    pick = np.arange(0, G, G // 8)
+    s = orc.Search(n, head=orc.HEAD_CONV, py_eval=lambda st: ev_eng.policy_eval(st))
+    s.reset(sts[pick])
+    s.run(iters)
+    for k, g in enumerate(pick):
+        a, b = e.search_dump(int(g)), s.dump(k)
+        assert len(a) == len(b) and all(np.array_equal(a[f], b[f]) for f in a.dtype.names), g
+    ev_eng.close()
+    rollouts = 8
+    e.selfplay_create(G, arena_nodes=1 << 13, seed=3, rollouts=rollouts, max_examples=G * 4)
+    e.selfplay_step(2)
+    st = e.selfplay_stats()
+    assert st["plies"] == 2 and st["games_finished"] == 0
+    assert st["expansions"] == 2 * G * (rollouts + 1) == st["evals"]
+    states = e.search_states()
+    hdr = 384 - 16
+    plies = states[:, hdr + 2].astype(int) | (states[:, hdr + 3].astype(int) << 8)
+    assert (plies == 4).all()
+    heights = (states[:, 288:324] & 63).sum(1)
+    reserves = states[:, hdr + 4 : hdr + 8].astype(int).sum(1)
+    assert (heights + reserves == 62).all()
+    e.close()

@@ -1,7 +1,7 @@
 // softmax.cuh — the reduction order of the policy softmax, shared by k_softmax (net_kernels.hip: one 256-thread block per
 // position) and the tree backup (search_kernels.hip: one wave per game computes the same statistics from the logits, so
-// the probabilities never go through HBM).  Both must return the same BITS: the oracle's trees are built from
-// tg_policy_eval's probabilities, the engine's from the in-kernel ones.
+// the probabilities never go through HBM).  Both must return the same BITS: a host-side MCTS (the narrow seam, the parity
+// tests) builds its trees from tg_policy_eval's probabilities, the engine from the in-kernel ones.
 #pragma once
 #include <hip/hip_runtime.h>
 

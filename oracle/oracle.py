@@ -69,6 +69,8 @@ def lib():
         l.orc_selfplay_new.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                        C.c_uint64, C.c_void_p, C.c_uint32]
         l.orc_random_positions.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_void_p]
+        l.orc_playouts.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]
         l.orc_seeded_game.argtypes = [C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]
         l.orc_state_hash.restype = C.c_uint64
         l.orc_state_hash.argtypes = [C.c_int, C.c_void_p]
@@ -209,6 +211,19 @@ def random_positions(n, count, seed, max_plies=60, half_komi=0):
     out = np.zeros((count, state_bytes(n)), np.uint8)
     lib().orc_random_positions(n, count, seed, max_plies, half_komi, _p(out))
     return out
+
+
+def playouts(n, count, seed, style=0, half_komi=127, avoid_roads=False, max_plies=1000):
+    """Whole pseudo-random games steered towards particular endings (see orc_playouts).  Returns a dict:
+    final / prev states, the last move, the final result and the highest stack of the final position."""
+    sb = state_bytes(n)
+    final = np.zeros((count, sb), np.uint8)
+    prev = np.zeros((count, sb), np.uint8)
+    move = np.zeros(count, np.uint16)
+    res = np.zeros(count, np.uint8)
+    mh = np.zeros(count, np.uint8)
+    lib().orc_playouts(n, count, seed, half_komi, style, int(avoid_roads), max_plies, _p(final), _p(prev), _p(move), _p(res), _p(mh))
+    return dict(final=final, prev=prev, move=move, result=res, max_height=mh)
 
 
 def seeded_game(n, seed):

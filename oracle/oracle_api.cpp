@@ -67,6 +67,7 @@ int orc_to_tps(int n, const uint8_t* state, char* buf, int cap) {
 // Game::play with Game::safe_play's keep-on-error behaviour (game.rs:136-145)
 void orc_play(int n, int k, uint8_t* states, const TgMove* moves, uint8_t* status) {
     size_t sb = state_bytes(n);
+#pragma omp parallel for schedule(static) if (k >= 4096)
     for (int i = 0; i < k; i++) {
         Game g = unpack(states + i * sb, n);
         Move m = decode_move(moves[i], n);
@@ -81,8 +82,9 @@ void orc_play(int n, int k, uint8_t* states, const TgMove* moves, uint8_t* statu
 
 void orc_movegen(int n, int k, const uint8_t* states, TgMove* moves, int32_t* counts) {
     size_t sb = state_bytes(n);
-    std::vector<Move> mv;
+#pragma omp parallel for schedule(static) if (k >= 4096)
     for (int i = 0; i < k; i++) {
+        std::vector<Move> mv;
         Game g = unpack(states + i * sb, n);
         g.possible_moves(mv);
         counts[i] = (int32_t)mv.size();
@@ -92,12 +94,14 @@ void orc_movegen(int n, int k, const uint8_t* states, TgMove* moves, int32_t* co
 
 void orc_result(int n, int k, const uint8_t* states, uint8_t* results) {
     size_t sb = state_bytes(n);
+#pragma omp parallel for schedule(static) if (k >= 4096)
     for (int i = 0; i < k; i++) results[i] = unpack(states + i * sb, n).result();
 }
 
 void orc_encode(int n, int k, const uint8_t* states, float* planes) {
     size_t sb = state_bytes(n);
     size_t per = (size_t)input_channels(n) * n * n;
+#pragma omp parallel for schedule(static) if (k >= 4096)
     for (int i = 0; i < k; i++) game_repr(unpack(states + i * sb, n), planes + i * per);
 }
 
@@ -122,8 +126,9 @@ int orc_legacy5_table(char* buf, int cap) {
 // ends).  Used to build test / bench inputs.
 void orc_random_positions(int n, int count, uint64_t seed, int max_plies, int half_komi, uint8_t* out) {
     size_t sb = state_bytes(n);
-    std::vector<Move> mv;
+#pragma omp parallel for schedule(dynamic, 256) if (count >= 4096)
     for (int i = 0; i < count; i++) {
+        std::vector<Move> mv;
         uint64_t s = mix64(seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(i + 1)));
         int target = (int)(mix64(s) % (uint64_t)(max_plies + 1));
         Game g = Game::start(n, half_komi);
@@ -137,6 +142,70 @@ void orc_random_positions(int n, int count, uint64_t seed, int max_plies, int ha
             g = c;
         }
         pack(g, out + i * sb);
+    }
+}
+
+// Whole pseudo-random games steered towards particular endings (test-input generator): every game is played
+// with the rules above until it ends or max_plies is reached; `style` weights the move classes so that the
+// rarer branches of Game::result (game.rs:220-267) are reached by PLAY — board-full and reserves-exhausted
+// flat counts with every komi parity, the 50-reversible-plies draw, tall stacks:
+//   0 uniform over the legal moves              1 flat placements whenever one exists (board fills up)
+//   2 mostly walls, few spreads (board full, few flats)   3 stacking game: spreads 60 %, placements mostly walls
+//   4 as 3 for a pseudo-random number of plies, then spreads only (reversible_plies runs up to 50)
+// avoid_roads: a candidate that completes a road is re-drawn (up to 8 times), so games last until another ending.
+// half_komi = 127: a pseudo-random half-komi in [-5, 6] per game.  Outputs per game: the final state, the
+// state before the last move, that move, the final result, and the highest stack seen at the end.
+void orc_playouts(int n, int count, uint64_t seed, int half_komi, int style, int avoid_roads, int max_plies, uint8_t* out_final,
+                  uint8_t* out_prev, TgMove* out_move, uint8_t* out_result, uint8_t* out_max_height) {
+    size_t sb = state_bytes(n);
+#pragma omp parallel for schedule(dynamic, 64) if (count >= 256)
+    for (int i = 0; i < count; i++) {
+        std::vector<Move> mv, pool;
+        uint64_t s = mix64(seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(i + 1)));
+        auto next = [&]() { s = mix64(s + 0x632BE59BD9B4E019ull); return s; };
+        int hk = half_komi == 127 ? (int)(next() % 12) - 5 : half_komi;
+        Game g = Game::start(n, hk), prev = g;
+        Move last;
+        const int switch_ply = 8 + (int)(next() % 40);
+        uint8_t res = TG_ONGOING;
+        for (int p = 0; p < max_plies; p++) {
+            res = g.result();
+            if (res != TG_ONGOING) break;
+            g.possible_moves(mv);
+            Game c;
+            Move pick;
+            for (int attempt = 0; attempt < 8; attempt++) {
+                // weight by move class: collect the preferred class, fall back to all moves
+                int want = -1;  // 0 flat, 1 wall, 2 cap, 3 spread, -1 any
+                uint64_t r = next() % 100;
+                if (style == 1) want = 0;
+                else if (style == 2) want = r < 65 ? 1 : r < 95 ? 0 : 3;
+                else if (style == 3 || (style == 4 && p < switch_ply)) want = r < 60 ? 3 : r < 85 ? 1 : r < 97 ? 0 : 2;
+                else if (style == 4) want = 3;
+                pool.clear();
+                if (want >= 0)
+                    for (const Move& m : mv)
+                        if ((m.spread ? 3 : (int)m.piece) == want) pool.push_back(m);
+                const std::vector<Move>& from = pool.empty() ? mv : pool;
+                pick = from[next() % from.size()];
+                c = g;
+                c.play(pick);
+                if (!avoid_roads) break;
+                uint8_t r2 = c.result();
+                if (r2 != TG_WHITE_ROAD && r2 != TG_BLACK_ROAD) break;
+            }
+            prev = g;
+            last = pick;
+            g = c;
+        }
+        res = g.result();
+        pack(g, out_final + (size_t)i * sb);
+        pack(prev, out_prev + (size_t)i * sb);
+        out_move[i] = encode_move(last, n);
+        out_result[i] = res;
+        int mh = 0;
+        for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) mh = g.board[y][x].len > mh ? g.board[y][x].len : mh;
+        out_max_height[i] = (uint8_t)mh;
     }
 }
 

@@ -309,7 +309,7 @@ def test_selfplay_config_c1_with_the_real_network(orc):
     ev.close()
 
 
-@pytest.mark.parametrize("n,games,rollouts,total", [(4, 8, 24, 20), (5, 6, 16, 9), (5, 64, 100, 80)])
+@pytest.mark.parametrize("n,games,rollouts,total", [(4, 8, 24, 20), (5, 6, 16, 9), (5, 64, 100, 80), (6, 8, 24, 14), (6, 16, 48, 24)])
 def test_selfplay_driver_matches_oracle(orc, n, games, rollouts, total):
     # self_play_parallel end to end: openings, instant wins, noise, rollouts, sampling / argmax,
     # tree reuse, game recycling and example emission — every example identical, in the same order
@@ -323,13 +323,14 @@ def test_selfplay_driver_matches_oracle(orc, n, games, rollouts, total):
     e.selfplay_create(games, arena_nodes=1 << 16 if c1 else 1 << 15, seed=5, max_examples=1 << 14, **kw)
     head = orc.HEAD_FC5 if n == 5 else orc.HEAD_CONV
     sp = orc.SelfPlay(n, games, head=head, evaluator=orc.EVAL_HASH, seed=5, **kw)
-    for step in range(400):
+    for step in range(1500):  # whole games, to completion (6×6 games under a pseudo-random evaluator run long)
         e.selfplay_step(1)
         sp.step(1)
         a, b = e.selfplay_stats(), sp.stats()
         assert a == b, (step, a, b)
         if not sp.states()[1].any():
             break
+    assert not sp.states()[1].any(), "games still running"
     assert b["games_finished"] >= total - games + 1 and b["examples"] > 0
     gh, gs, gm, gv = e.selfplay_drain(1 << 14)
     oh, os_, om, ov = sp.drain(1 << 14)

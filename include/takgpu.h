@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 1
+#define TG_ABI_VERSION 2
 
 /* ---------------------------------------------------------------------------------------
  * Status codes.  TG_PLAY_* mirror reference tak/src/error.rs:4-15 (PlayError) and
@@ -40,11 +40,19 @@ typedef enum TgStatus {
     TG_ERR_NO_DEVICE = -2,
     TG_ERR_HIP = -3,
     TG_ERR_WEIGHTS = -4,       /* missing / wrongly sized tensor at tg_net_finalize            */
-    TG_ERR_ARENA_OVERFLOW = -5,/* a game's MCTS node arena is full                              */
+    TG_ERR_ARENA_OVERFLOW = -5,/* the MCTS node pool is exhausted (TgSearchConfig.arena_nodes)     */
     TG_ERR_NAN = -6,           /* reference panics "tried comparing nan" (search/mcts.rs:110)   */
     TG_ERR_STATE = -7,         /* call sequence violated (e.g. search before weights)          */
-    TG_ERR_ILLEGAL_MOVE = -8   /* a move in a batch failed; per-item code in the status array  */
+    TG_ERR_ILLEGAL_MOVE = -8,  /* a move in a batch failed; per-item code in the status array  */
+    TG_ERR_LIMIT = -9          /* one of the fixed capacities below (TG_LIMIT_*) was exceeded      */
 } TgStatus;
+
+/* Fixed capacities of the search / self-play engine (the reference's heap structures have none).  Exceeding one
+ * sets a sticky error on the engine (TG_ERR_LIMIT from the next polling call) until tg_search_reset /
+ * tg_search_create / tg_selfplay_create. */
+#define TG_LIMIT_DEPTH 256          /* longest selection path (plies below the root)                     */
+#define TG_LIMIT_VISITS (1 << 22)   /* visits + virtual visits of one node (exploration-rate table)      */
+#define TG_LIMIT_GAME_PLIES 512     /* examples staged per self-play game = plies of one game            */
 
 typedef enum TgPlayError { /* per-item result of tg_play, 0 = Ok(()) */
     TG_PLAY_OK = 0,
@@ -258,12 +266,14 @@ int tg_policy_eval_dev(TgEngine* e, int n, const void* d_states, float* d_policy
  * ------------------------------------------------------------------------------------- */
 typedef struct TgSearchConfig {
     int32_t games;            /* concurrent games (≤ cfg.max_batch)                          */
-    int32_t arena_nodes;      /* node capacity of one game's tree arena (two arenas per game, 24 B per node).  A rollout
-                                 adds one node per legal move of the expanded leaf (≈ 45 on 5×5, ≈ 80 on 6×6) and the subtree
-                                 under the move played is kept (tree reuse), so long games with concentrated searches need
-                                 many times rollouts × branching: 2^19 ran 400 plies of 4096 5×5 games at 400 rollouts
-                                 (103 GB); 2^17 overflows after ≈ 180 plies (TG_ERR_ARENA_OVERFLOW).
-                                 0 = auto: the largest power of two in [2^14, 2^19] whose arenas fit in half of the free device memory */
+    int32_t arena_nodes;      /* AVERAGE node budget per game: all trees live in ONE pool of games × arena_nodes nodes
+                                 (24 B each) handed out in chunks, so a single tree may be far larger than this while
+                                 others are small.  A rollout adds one node per legal move of the expanded leaf (≈ 45 on
+                                 5×5, ≈ 80 on 6×6); the subtree under the move played is kept (tree reuse) and the rest
+                                 returns to the pool.  The reference's own workload — 32 games × 10 000 rollouts on 6×6 —
+                                 needs ≈ 2^20 per game (0.8 GB in all); 4096 5×5 games at 400 rollouts ≈ 2^16 – 2^17.
+                                 Exhausting the pool → TG_ERR_ARENA_OVERFLOW (sticky until reset).
+                                 0 = auto: half of the free device memory, at most 2^20 nodes per game */
     float exploration_base;   /* EXPLORATION_BASE 500 (mcts.rs:7) */
     float exploration_init;   /* EXPLORATION_INIT 4   (mcts.rs:8) */
     uint64_t seed;            /* counter-based RNG key (noise, move sampling, openings)      */
@@ -354,10 +364,14 @@ typedef struct TgSelfPlayStats {
     uint64_t plies;
     uint64_t white_wins, black_wins, draws;
     uint64_t instant_wins;
+    uint64_t dropped_examples; /* finished examples overwritten in the output ring before tg_selfplay_drain fetched them
+                                  (max_examples too small for the drain interval); 0 in a loss-free run */
 } TgSelfPlayStats;
 int tg_selfplay_stats(TgEngine* e, TgSelfPlayStats* out);
 /* copy out up to `cap` finished examples (headers + states + moves + visits) and remove them
- * from the ring.  states: cap packed states; moves/visits: cap × TG_MAX_MOVES. */
+ * from the ring.  states: cap packed states; moves/visits: cap × TG_MAX_MOVES.  Examples the ring has already
+ * overwritten (more than max_examples finished since the last drain) are skipped and counted in
+ * TgSelfPlayStats.dropped_examples: size max_examples ≥ games × expected plies per drain interval. */
 int tg_selfplay_drain(TgEngine* e, int cap, TgExampleHeader* headers, void* states, TgMove* moves,
                       uint32_t* visits, int32_t* n_out);
 

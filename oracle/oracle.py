@@ -40,7 +40,9 @@ class SelfPlayStats(C.Structure):
         "games_finished", "examples", "expansions", "evals", "plies", "white_wins", "black_wins", "draws", "instant_wins")]
 
     def as_dict(self):
-        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+        d = {k: int(getattr(self, k)) for k, _ in self._fields_}
+        d["dropped_examples"] = 0  # the restatement keeps every example (a Vec, as the reference does)
+        return d
 
 
 EVAL_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)

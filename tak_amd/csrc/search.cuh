@@ -2,13 +2,20 @@
 //
 // Replaces the heap tree of reference alpha-tak/src/search/node.rs:3-39 (Node { policy,
 // expected_reward, result, visits, virtual_visits, children: Box<[(Move, Node)]> }).
-// One arena pair per game; a node is two records so that PUCT selection streams only the hot one:
+// A node is two records so that PUCT selection streams only the hot one:
 //   NodeHot  (16 B)  prior, q (= expected_reward), visits, virtual visits   — read per child per level
 //   NodeCold ( 8 B)  first-child index, move code, n_children | result<<12   — read for the chosen child
 // The children of a node are contiguous (same order as Game::possible_moves), so a wave scanning them
-// issues fully coalesced 16-byte-per-lane loads.  Node 0 of the active arena is the root; on a move the
-// chosen child's subtree is compacted breadth-first into the game's other arena (tree reuse,
-// search/play.rs:26-43) so memory stays bounded without a free list.
+// issues fully coalesced 16-byte-per-lane loads.
+//
+// Memory: ONE node pool shared by all games, cut into chunks of 2^chunk_shift nodes.  A game bump-allocates the
+// children blocks of its expansions inside its open chunk and takes a new chunk from the pool's free ring when a
+// block does not fit (one atomic per ≈ 2^chunk_shift / branching expansions instead of one per expansion, and none
+// on a per-game counter).  So a tree is as large as the pool allows — a 10 000-rollout search of 32 games and a
+// 400-rollout search of 4096 games run on the same allocation, sized by the SUM of the trees, not by games × the
+// largest tree.  On a move (tree reuse, search/play.rs:26-43) the kept subtree is copied breadth-first into fresh
+// chunks — the copy is its own work queue (Cheney), so no depth or width limit — and the old chunks go back to
+// the ring (published to allocators at the next kernel boundary).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,7 +27,7 @@ struct NodeHot {
     uint32_t visits, virt;
 };
 struct NodeCold {
-    uint32_t child;   // index of the first child in the same arena (0 = no children)
+    uint32_t child;   // pool index of the first child (0 = no children; chunk 0 is never handed out)
     uint16_t mv;      // move that leads here (TgMove)
     uint16_t nres;    // n_children (12 bits) | TgResult << 12
 };
@@ -30,13 +37,13 @@ constexpr int MAX_DEPTH = 256;       // longest selection path kept per game
 constexpr int EX_MOVES = 512;        // = TG_MAX_MOVES
 
 enum : uint32_t {
-    ERRF_ARENA = 1u,     // node arena full
+    ERRF_ARENA = 1u,     // node pool exhausted
     ERRF_NAN = 2u,       // NaN upper confidence bound (reference panics, mcts.rs:110)
     ERRF_DEPTH = 4u,     // selection path longer than MAX_DEPTH
     ERRF_CTAB = 8u,      // visit count beyond the exploration-rate table
     ERRF_MOVE = 16u,     // move not among the root's children / unmapped policy index
     ERRF_EXAMPLES = 32u, // a game produced more examples than its staging area holds
-    ERRF_QUEUE = 64u,    // re-root queue overflow
+    ERRF_MOVES = 64u,    // a position with more than TG_MAX_MOVES legal moves
     ERRF_PICK = 128u     // WeightedIndex over all-zero visits (reference panics, play.rs:62)
 };
 
@@ -49,11 +56,19 @@ struct ExampleRec {
 };
 
 struct SearchDev {
-    // trees
-    NodeHot* hot;        // [G][2][cap]
-    NodeCold* cold;      // [G][2][cap]
-    uint8_t* sel;        // [G] active arena
-    uint32_t* alloc;     // [G] next free node in the active arena
+    // trees: one pool of n_chunks << chunk_shift nodes
+    NodeHot* hot;        // [pool]
+    NodeCold* cold;      // [pool]
+    uint32_t* root;      // [G] pool index of the game's root
+    uint32_t* alloc;     // [G][2] next free node and end of the game's open chunk
+    uint32_t* chunk_head;// [G] the game's most recently taken chunk; its chunks are chained through chunk_link
+    uint32_t* chunk_link;// [n_chunks] the chunk the same game took before this one (0 = none)
+    uint32_t* chunk_fwd; // [n_chunks] re-root copy only: the chunk taken after this one …
+    uint32_t* chunk_used;// [n_chunks] … and how many of this chunk's nodes were filled when it was closed
+    uint32_t* free_ring; // [n_chunks] ids of free chunks
+    unsigned long long* pool_ctl;  // [0] chunks taken, [1] chunks returned, [2] returned-and-published (visible to takers)
+    uint32_t n_chunks;
+    int chunk_shift;
     // games
     uint8_t* root_state; // [G][state bytes]
     uint8_t* alive;      // [G]
@@ -76,7 +91,7 @@ struct SearchDev {
     uint32_t* err;       // error flag word
     unsigned long long* counters;  // [G][2] per game: expansions, evals (summed on read; a single shared word would
                                    // serialise 2·G same-address atomics per iteration, ≈ 11 ns each)
-    int G, cap, n, cin_pad, P, ctab_size, legacy5, evaluator;
+    int G, n, cin_pad, P, ctab_size, legacy5, evaluator;
     int batch, pass;     // virtual rollouts per tree and iteration; the one this launch performs (leaf slot = g·batch + pass)
     uint32_t slot_base;
     uint64_t seed;

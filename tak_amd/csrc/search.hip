@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 
 #include "engine.h"
 #include "kernels.h"
@@ -15,7 +16,7 @@ namespace tg {
 struct Search {
     TgSearchConfig cfg;
     SearchDev d;
-    DevBuf hot, cold, sel, alloc, root_state, alive, generation, path_len, path, leaf_kind, leaf_hash, planes, leaf_state, policy, eval,
+    DevBuf hot, cold, root, alloc, chunk_head, chunk_link, chunk_fwd, chunk_used, free_ring, pool_ctl, root_state, alive, generation, path_len, path, leaf_kind, leaf_hash, planes, leaf_state, policy, eval,
         ctab, err, counters, op, active, noise;
     DevBuf r_moves, r_visits, r_prior, r_q, r_counts, r_rv, r_rq, s_moves;
     // self-play
@@ -24,7 +25,7 @@ struct Search {
     SelfPlayDev p;
     DevBuf st_hdr, st_state, st_moves, st_visits, st_count, out_hdr, out_state, out_moves, out_visits, fin, recycle, out_off, chosen,
         mask, stats;
-    unsigned long long drained = 0;
+    unsigned long long drained = 0, dropped = 0;
 };
 
 void search_destroy(Search* s) { delete s; }
@@ -35,14 +36,14 @@ static int describe_errors(uint32_t bits) {
     auto add = [&](uint32_t b, const char* m, int c) {
         if (bits & b) { if (!msg.empty()) msg += "; "; msg += m; code = c; }
     };
-    add(ERRF_DEPTH, "selection path deeper than MAX_DEPTH", TG_ERR_ARENA_OVERFLOW);
-    add(ERRF_CTAB, "visit count beyond the exploration table", TG_ERR_ARENA_OVERFLOW);
-    add(ERRF_EXAMPLES, "a game produced more examples than its staging area holds", TG_ERR_ARENA_OVERFLOW);
-    add(ERRF_QUEUE, "re-root queue overflow", TG_ERR_ARENA_OVERFLOW);
+    add(ERRF_DEPTH, "selection path deeper than 256 plies (TG_LIMIT_DEPTH)", TG_ERR_LIMIT);
+    add(ERRF_CTAB, "a node was visited more than 2^22 times (TG_LIMIT_VISITS)", TG_ERR_LIMIT);
+    add(ERRF_EXAMPLES, "a game lasted more than 512 plies (TG_LIMIT_GAME_PLIES)", TG_ERR_LIMIT);
+    add(ERRF_MOVES, "a position has more than TG_MAX_MOVES legal moves", TG_ERR_LIMIT);
     add(ERRF_PICK, "pick_move on a root without visits", TG_ERR_STATE);
     add(ERRF_MOVE, "move is not a child of the root / has no policy index", TG_ERR_ILLEGAL_MOVE);
     add(ERRF_NAN, "NaN upper confidence bound (reference: \"tried comparing nan\")", TG_ERR_NAN);
-    add(ERRF_ARENA, "MCTS node arena full (raise TgSearchConfig.arena_nodes)", TG_ERR_ARENA_OVERFLOW);
+    add(ERRF_ARENA, "MCTS node pool exhausted (raise TgSearchConfig.arena_nodes)", TG_ERR_ARENA_OVERFLOW);
     return fail(code, msg);
 }
 
@@ -70,6 +71,30 @@ static int upload_mask(TgEngine* e, const uint8_t* active, const uint8_t** d_out
     return TG_OK;
 }
 
+// Every chunk but chunk 0 free, no game owning one: the state after create and after tg_search_reset (which drops every
+// tree, and with them a pool that an exhaustion has left inconsistent).  search_reset_trees then gives each game its root chunk.
+static int pool_init(TgEngine* e, Search* s) {
+    const size_t G = (size_t)s->cfg.games, n_chunks = s->d.n_chunks;
+    const int chunk_shift = s->d.chunk_shift;
+    std::vector<uint32_t> ring(n_chunks, 0u);
+    for (size_t i = 0; i + 1 < n_chunks; i++) ring[i] = (uint32_t)(i + 1);
+    const unsigned long long ctl[4] = {0ull, (unsigned long long)(n_chunks - 1), (unsigned long long)(n_chunks - 1), 0ull};
+    // everything on the engine's (non-blocking) stream: a legacy-stream hipMemset would not be ordered against the
+    // kernels that follow on it
+    hipStream_t st = e->stream;
+    TG_HIP(hipMemcpyAsync(s->free_ring.p, ring.data(), n_chunks * 4, hipMemcpyHostToDevice, st));
+    TG_HIP(hipMemcpyAsync(s->pool_ctl.p, ctl, sizeof ctl, hipMemcpyHostToDevice, st));
+    TG_HIP(hipMemsetAsync(s->chunk_head.p, 0, G * 4, st));
+    TG_HIP(hipMemsetAsync(s->chunk_link.p, 0, n_chunks * 4, st));
+    TG_HIP(hipMemsetAsync(s->root.p, 0, G * 4, st));
+    TG_HIP(hipMemsetAsync(s->alloc.p, 0, G * 8, st));
+    // chunk 0 is where a not-yet-reset game's root index (0) points: an empty node without children
+    TG_HIP(hipMemsetAsync(s->hot.p, 0, sizeof(NodeHot) << chunk_shift, st));
+    TG_HIP(hipMemsetAsync(s->cold.p, 0, sizeof(NodeCold) << chunk_shift, st));
+    TG_HIP(hipStreamSynchronize(st));  // `ring` / `ctl` are host temporaries
+    return TG_OK;
+}
+
 static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     if (!e) return fail(TG_ERR_INVALID_ARG, "null engine");
     if (!cfg || cfg->games <= 0 || cfg->games > e->cfg.max_batch) return fail(TG_ERR_INVALID_ARG, "games must be in 1..max_batch");
@@ -87,23 +112,39 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     std::unique_ptr<Search> sp(new Search());
     Search* s = sp.get();
     s->cfg = *cfg;
+    // One node pool for all games (search.cuh).  arena_nodes is the AVERAGE budget per game: pool = games × arena_nodes,
+    // and a single tree may grow far beyond it while others are small.  0 = auto: half of the free device memory,
+    // at most 2^20 nodes per game and at most what a 32-bit node index addresses.
+    const size_t node_bytes = sizeof(NodeHot) + sizeof(NodeCold);
+    size_t pool_nodes;
     if (s->cfg.arena_nodes == 0) {
-        // auto: the largest power of two that keeps the arenas (two per game) inside half of the free device memory, between
-        // 2^14 and 2^19 nodes (2^19 ran 400 plies of 4096 5×5 games at 400 rollouts; the HBM is there to be used)
         size_t free_b = 0, total_b = 0;
         TG_HIP(hipMemGetInfo(&free_b, &total_b));
-        const size_t per_node = 2 * (sizeof(NodeHot) + sizeof(NodeCold)) * (size_t)cfg->games;
-        int cap = 1 << 19;
-        while (cap > (1 << 14) && (size_t)cap * per_node > free_b / 2) cap >>= 1;
-        s->cfg.arena_nodes = cap;
+        pool_nodes = std::min<size_t>({free_b / 2 / node_bytes, (size_t)cfg->games << 20, (size_t)0xFFFF0000u});
+        pool_nodes = std::max<size_t>(pool_nodes, (size_t)cfg->games << 12);
+        s->cfg.arena_nodes = (int32_t)std::min<size_t>(pool_nodes / (size_t)cfg->games, (size_t)1 << 30);
+    } else {
+        pool_nodes = (size_t)cfg->games * (size_t)cfg->arena_nodes;
+        if (pool_nodes > (size_t)0xFFFF0000u) return fail(TG_ERR_INVALID_ARG, "games x arena_nodes exceeds the 2^32 nodes a pool can hold");
     }
     cfg = &s->cfg;
-    const size_t G = (size_t)cfg->games, cap = (size_t)cfg->arena_nodes;
+    const size_t G = (size_t)cfg->games;
+    const int chunk_shift = pool_nodes / G >= 16384 ? 11 : 10;
+    // + 3 chunks per game: the open chunk's unused tail, the first chunk of a re-rooted copy while the old tree still
+    // holds its own, and chunk 0, which is never handed out (index 0 = "no children")
+    const size_t n_chunks = (pool_nodes >> chunk_shift) + 3 * G + 1;
+    if ((n_chunks << chunk_shift) > ((size_t)1 << 32)) return fail(TG_ERR_INVALID_ARG, "node pool exceeds 2^32 nodes");
     const int cin_pad = e->cin_pad;
-    TG_HIP(s->hot.ensure(G * 2 * cap * sizeof(NodeHot)));
-    TG_HIP(s->cold.ensure(G * 2 * cap * sizeof(NodeCold)));
-    TG_HIP(s->sel.ensure(G));
-    TG_HIP(s->alloc.ensure(G * 4));
+    TG_HIP(s->hot.ensure((n_chunks << chunk_shift) * sizeof(NodeHot)));
+    TG_HIP(s->cold.ensure((n_chunks << chunk_shift) * sizeof(NodeCold)));
+    TG_HIP(s->root.ensure(G * 4));
+    TG_HIP(s->alloc.ensure(G * 8));
+    TG_HIP(s->chunk_head.ensure(G * 4));
+    TG_HIP(s->chunk_link.ensure(n_chunks * 4));
+    TG_HIP(s->chunk_fwd.ensure(n_chunks * 4));
+    TG_HIP(s->chunk_used.ensure(n_chunks * 4));
+    TG_HIP(s->free_ring.ensure(n_chunks * 4));
+    TG_HIP(s->pool_ctl.ensure(4 * 8));
     TG_HIP(s->root_state.ensure(G * e->g.bytes));
     TG_HIP(s->alive.ensure(G));
     TG_HIP(s->generation.ensure(G * 4));
@@ -127,16 +168,16 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     if (e->cfg.evaluator == TG_EVAL_RESNET) {
         if (net_takes_states(e)) {
             TG_HIP(s->leaf_state.ensure(G * B * e->g.bytes));
-            TG_HIP(hipMemset(s->leaf_state.p, 0, s->leaf_state.bytes));
+            TG_HIP(hipMemsetAsync(s->leaf_state.p, 0, s->leaf_state.bytes, e->stream));
         } else
         TG_HIP(s->planes.ensure(G * B * e->g.nsq * cin_pad * 4));
         TG_HIP(s->policy.ensure(G * B * (size_t)e->policy_size * 4));
         TG_HIP(s->eval.ensure(G * B * 4));
-        if (s->planes.p) TG_HIP(hipMemset(s->planes.p, 0, s->planes.bytes));
+        if (s->planes.p) TG_HIP(hipMemsetAsync(s->planes.p, 0, s->planes.bytes, e->stream));
     }
     // exploration_rate(n) = ln((1 + n + base) / base) + init for integer visit counts (mcts.rs:10-12),
     // evaluated once on the host in f32 so that every GPU and the CPU agree on the last bit
-    const int ctab_size = 1 << 20;
+    const int ctab_size = 1 << 22;  // TG_LIMIT_VISITS
     std::vector<float> ctab(ctab_size);
     for (int i = 0; i < ctab_size; i++) {
         float nf = (float)i;
@@ -144,19 +185,26 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     }
     TG_HIP(s->ctab.ensure((size_t)ctab_size * 4));
     TG_HIP(hipMemcpy(s->ctab.p, ctab.data(), (size_t)ctab_size * 4, hipMemcpyHostToDevice));
-    TG_HIP(hipMemset(s->err.p, 0, 4));
-    TG_HIP(hipMemset(s->counters.p, 0, G * 16));
-    TG_HIP(hipMemset(s->generation.p, 0, G * 4));
-    TG_HIP(hipMemset(s->alive.p, 0, G));
+    TG_HIP(hipMemsetAsync(s->err.p, 0, 4, e->stream));
+    TG_HIP(hipMemsetAsync(s->counters.p, 0, G * 16, e->stream));
+    TG_HIP(hipMemsetAsync(s->generation.p, 0, G * 4, e->stream));
+    TG_HIP(hipMemsetAsync(s->alive.p, 0, G, e->stream));
     SearchDev& d = s->d;
-    d.hot = s->hot.as<NodeHot>(); d.cold = s->cold.as<NodeCold>(); d.sel = s->sel.as<uint8_t>(); d.alloc = s->alloc.as<uint32_t>();
+    d.hot = s->hot.as<NodeHot>(); d.cold = s->cold.as<NodeCold>(); d.root = s->root.as<uint32_t>(); d.alloc = s->alloc.as<uint32_t>();
+    d.chunk_head = s->chunk_head.as<uint32_t>(); d.chunk_link = s->chunk_link.as<uint32_t>(); d.chunk_fwd = s->chunk_fwd.as<uint32_t>();
+    d.chunk_used = s->chunk_used.as<uint32_t>(); d.free_ring = s->free_ring.as<uint32_t>();
+    d.pool_ctl = s->pool_ctl.as<unsigned long long>(); d.n_chunks = (uint32_t)n_chunks; d.chunk_shift = chunk_shift;
     d.root_state = s->root_state.as<uint8_t>(); d.alive = s->alive.as<uint8_t>(); d.generation = s->generation.as<uint32_t>();
     d.path_len = s->path_len.as<int32_t>(); d.path = s->path.as<uint32_t>(); d.leaf_kind = s->leaf_kind.as<uint8_t>();
     d.leaf_hash = s->leaf_hash.as<uint64_t>(); d.planes = s->planes.as<float>(); d.leaf_state = s->leaf_state.as<uint8_t>();
     d.policy = s->policy.as<float>();
     d.eval = s->eval.as<float>(); d.ctab = s->ctab.as<float>(); d.lut5 = e->lut5.as<int16_t>(); d.err = s->err.as<uint32_t>();
     d.counters = s->counters.as<unsigned long long>();
-    d.G = cfg->games; d.cap = cfg->arena_nodes; d.n = e->g.n; d.cin_pad = cin_pad; d.P = e->policy_size; d.ctab_size = ctab_size;
+    {
+        int prc = pool_init(e, s);
+        if (prc) return prc;
+    }
+    d.G = cfg->games; d.n = e->g.n; d.cin_pad = cin_pad; d.P = e->policy_size; d.ctab_size = ctab_size;
     d.legacy5 = e->legacy5 ? 1 : 0; d.evaluator = e->cfg.evaluator; d.slot_base = cfg->slot_base; d.seed = cfg->seed;
     d.batch = (int)B; d.pass = 0;
     d.logits = nullptr; d.logit_ld = 0;  // refreshed before every iteration (bind_logits)
@@ -169,7 +217,6 @@ static int search_reset_trees(TgEngine* e) {
     Search* s = e->search;
     const size_t G = (size_t)s->d.G;
     std::vector<int32_t> op(G, -2);
-    TG_HIP(hipMemsetAsync(s->sel.p, 0, G, e->stream));
     TG_HIP(hipMemcpyAsync(s->op.p, op.data(), G * 4, hipMemcpyHostToDevice, e->stream));
     launch_reroot(e->stream, s->d, s->op.as<int32_t>());
     TG_HIP(hipGetLastError());
@@ -219,9 +266,8 @@ static int search_iterate(TgEngine* e, const uint8_t* d_active) {
 // MFMA kernels of the other.  Per-game results do not depend on the batch a position is evaluated in, so trees are
 // identical to the single-stream schedule.  An iteration the profiler samples runs alone on the engine stream.
 static SearchDev half_view(const SearchDev& d, int g0, int count, size_t state_bytes) {
-    SearchDev v = d;
-    v.hot += (size_t)g0 * 2 * d.cap; v.cold += (size_t)g0 * 2 * d.cap;
-    v.sel += g0; v.alloc += g0;
+    SearchDev v = d;  // the node pool is shared: only the per-game arrays are offset
+    v.root += g0; v.alloc += 2 * (size_t)g0; v.chunk_head += g0;
     v.root_state += (size_t)g0 * state_bytes; v.alive += g0; v.generation += g0;
     v.path_len += g0; v.path += (size_t)g0 * MAX_DEPTH; v.leaf_kind += g0; v.leaf_hash += g0;
     v.leaf_state += (size_t)g0 * state_bytes; v.policy += (size_t)g0 * d.P; v.eval += g0;
@@ -349,6 +395,8 @@ int tg_search_reset(TgEngine* e, const void* states) {
     rc = validate_states(e, s->d.G, (const uint8_t*)states, "tg_search_reset");
     if (rc) return rc;
     const size_t G = (size_t)s->d.G;
+    rc = pool_init(e, s);
+    if (rc) return rc;
     TG_HIP(hipMemcpyAsync(s->root_state.p, states, G * e->g.bytes, hipMemcpyHostToDevice, e->stream));
     TG_HIP(hipMemsetAsync(s->alive.p, 1, G, e->stream));
     TG_HIP(hipMemsetAsync(s->err.p, 0, 4, e->stream));
@@ -452,52 +500,74 @@ int tg_search_dump(TgEngine* e, int game, TgNodeRecord* records, size_t capacity
     if (game < 0 || game >= s->d.G || !n_records) return fail(TG_ERR_INVALID_ARG, "tg_search_dump: bad arguments");
     rc = sync_and_check(e);
     if (rc) return rc;
-    uint8_t sel = 0;
-    uint32_t alloc = 0;
-    TG_HIP(hipMemcpy(&sel, s->sel.as<uint8_t>() + game, 1, hipMemcpyDeviceToHost));
-    TG_HIP(hipMemcpy(&alloc, s->alloc.as<uint32_t>() + game, 4, hipMemcpyDeviceToHost));
-    const size_t base = ((size_t)game * 2 + sel) * (size_t)s->d.cap;
-    std::vector<NodeHot> hot(alloc);
-    std::vector<NodeCold> cold(alloc);
-    TG_HIP(hipMemcpy(hot.data(), s->hot.as<NodeHot>() + base, (size_t)alloc * sizeof(NodeHot), hipMemcpyDeviceToHost));
-    TG_HIP(hipMemcpy(cold.data(), s->cold.as<NodeCold>() + base, (size_t)alloc * sizeof(NodeCold), hipMemcpyDeviceToHost));
+    // gather the game's chunks (its chain through chunk_link) and index the tree by pool index
+    uint32_t root = 0, head = 0;
+    TG_HIP(hipMemcpy(&root, s->root.as<uint32_t>() + game, 4, hipMemcpyDeviceToHost));
+    TG_HIP(hipMemcpy(&head, s->chunk_head.as<uint32_t>() + game, 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> link(s->d.n_chunks);
+    TG_HIP(hipMemcpy(link.data(), s->chunk_link.p, (size_t)s->d.n_chunks * 4, hipMemcpyDeviceToHost));
+    const int sh = s->d.chunk_shift;
+    const size_t CH = (size_t)1 << sh;
+    std::map<uint32_t, size_t> where;  // chunk id → position in the host copies
+    std::vector<NodeHot> hot_h;
+    std::vector<NodeCold> cold_h;
+    for (uint32_t c = head; c != 0; c = link[c]) {
+        if (c >= s->d.n_chunks || where.count(c)) return fail(TG_ERR_STATE, "tg_search_dump: corrupt chunk chain");
+        where[c] = hot_h.size();
+        hot_h.resize(hot_h.size() + CH);
+        cold_h.resize(cold_h.size() + CH);
+        TG_HIP(hipMemcpy(hot_h.data() + where[c], s->hot.as<NodeHot>() + ((size_t)c << sh), CH * sizeof(NodeHot), hipMemcpyDeviceToHost));
+        TG_HIP(hipMemcpy(cold_h.data() + where[c], s->cold.as<NodeCold>() + ((size_t)c << sh), CH * sizeof(NodeCold), hipMemcpyDeviceToHost));
+    }
+    bool corrupt = false;
+    auto at = [&](uint32_t nd) -> size_t {
+        auto it = where.find(nd >> sh);
+        if (it == where.end()) { corrupt = true; return 0; }
+        return it->second + (nd & (CH - 1));
+    };
+    if (where.empty()) return fail(TG_ERR_STATE, "tg_search_dump: the game has no tree");
     // depth-first in child order; uninitialised children become leaf records with n_children = 0xFFFF
     std::vector<TgNodeRecord> out;
     struct Frame { uint32_t node; uint32_t next; };
     std::vector<Frame> stack;
     auto emit = [&](uint32_t nd, bool is_root) {
+        const NodeHot& h = hot_h[at(nd)];
+        const NodeCold& c = cold_h[at(nd)];
         TgNodeRecord r;
-        r.move = is_root ? 0 : cold[nd].mv;
-        r.n_children = (uint16_t)(cold[nd].nres & 0xfff);
-        r.visits = hot[nd].visits;
-        r.virtual_visits = hot[nd].virt;
-        r.result = cold[nd].nres >> 12;
-        std::memcpy(&r.prior_bits, &hot[nd].prior, 4);
-        std::memcpy(&r.q_bits, &hot[nd].q, 4);
+        r.move = is_root ? 0 : c.mv;
+        r.n_children = (uint16_t)(c.nres & 0xfff);
+        r.visits = h.visits;
+        r.virtual_visits = h.virt;
+        r.result = c.nres >> 12;
+        std::memcpy(&r.prior_bits, &h.prior, 4);
+        std::memcpy(&r.q_bits, &h.q, 4);
         out.push_back(r);
     };
-    emit(0, true);
-    stack.push_back({0u, 0u});
-    while (!stack.empty()) {
+    emit(root, true);
+    stack.push_back({root, 0u});
+    while (!stack.empty() && !corrupt) {
         Frame& f = stack.back();
-        uint32_t nch = cold[f.node].nres & 0xfff;
+        const NodeCold& fc = cold_h[at(f.node)];
+        uint32_t nch = fc.nres & 0xfff;
         if (f.next >= nch) { stack.pop_back(); continue; }
-        uint32_t c = cold[f.node].child + f.next;
+        uint32_t c = fc.child + f.next;
         f.next++;
-        if (c >= alloc) return fail(TG_ERR_STATE, "tg_search_dump: corrupt tree (child index out of the arena)");
-        if (hot[c].visits != 0 || hot[c].virt != 0) {
+        const NodeHot& ch = hot_h[at(c)];
+        if (corrupt) break;
+        if (ch.visits != 0 || ch.virt != 0) {
             emit(c, false);
             stack.push_back({c, 0u});
         } else {
             TgNodeRecord r;
-            r.move = cold[c].mv;
+            r.move = cold_h[at(c)].mv;
             r.n_children = 0xFFFF;
             r.visits = 0; r.virtual_visits = 0; r.result = 0;
-            std::memcpy(&r.prior_bits, &hot[c].prior, 4);
-            std::memcpy(&r.q_bits, &hot[c].q, 4);
+            std::memcpy(&r.prior_bits, &ch.prior, 4);
+            std::memcpy(&r.q_bits, &ch.q, 4);
             out.push_back(r);
         }
     }
+    if (corrupt) return fail(TG_ERR_STATE, "tg_search_dump: corrupt tree (a child index points outside the game's chunks)");
     *n_records = out.size();
     if (out.size() > capacity || (!records && !out.empty())) return fail(TG_ERR_INVALID_ARG, "tg_search_dump: capacity too small");
     std::memcpy(records, out.data(), out.size() * sizeof(TgNodeRecord));
@@ -547,9 +617,9 @@ int tg_selfplay_create(TgEngine* e, const TgSearchConfig* scfg, const TgSelfPlay
     TG_HIP(s->chosen.ensure(G * 4));
     TG_HIP(s->mask.ensure(G));
     TG_HIP(s->stats.ensure(ST_COUNT * 8));
-    TG_HIP(hipMemset(s->st_count.p, 0, G * 4));
-    TG_HIP(hipMemset(s->stats.p, 0, ST_COUNT * 8));
-    TG_HIP(hipMemset(s->fin.p, 0, G));
+    TG_HIP(hipMemsetAsync(s->st_count.p, 0, G * 4, e->stream));
+    TG_HIP(hipMemsetAsync(s->stats.p, 0, ST_COUNT * 8, e->stream));
+    TG_HIP(hipMemsetAsync(s->fin.p, 0, G, e->stream));
     SelfPlayDev& p = s->p;
     p.st_hdr = s->st_hdr.as<ExampleRec>(); p.st_state = s->st_state.as<uint8_t>(); p.st_moves = s->st_moves.as<uint16_t>();
     p.st_visits = s->st_visits.as<uint32_t>(); p.st_count = s->st_count.as<int32_t>();
@@ -574,7 +644,7 @@ int tg_selfplay_create(TgEngine* e, const TgSearchConfig* scfg, const TgSelfPlay
     std::vector<uint8_t> all(G * sb);
     for (size_t g = 0; g < G; g++) std::memcpy(&all[g * sb], start.data(), sb);
     TG_HIP(hipMemcpy(s->root_state.p, all.data(), all.size(), hipMemcpyHostToDevice));
-    TG_HIP(hipMemset(s->alive.p, 1, G));
+    TG_HIP(hipMemsetAsync(s->alive.p, 1, G, e->stream));
     return search_reset_trees(e);
 }
 
@@ -621,6 +691,11 @@ int tg_selfplay_stats(TgEngine* e, TgSelfPlayStats* out) {
     out->games_finished = st[ST_FINISHED]; out->examples = st[ST_EXAMPLES]; out->plies = st[ST_PLIES];
     out->white_wins = st[ST_WHITE]; out->black_wins = st[ST_BLACK]; out->draws = st[ST_DRAWS]; out->instant_wins = st[ST_INSTANT];
     out->expansions = c[0]; out->evals = c[1];
+    {   // examples the ring has overwritten since the last drain count as dropped as soon as they are observable
+        const unsigned long long ME = (unsigned long long)s->p.max_examples;
+        unsigned long long lost = st[ST_EXAMPLES] - s->drained > ME ? st[ST_EXAMPLES] - s->drained - ME : 0ull;
+        out->dropped_examples = s->dropped + lost;
+    }
     return TG_OK;
 }
 
@@ -635,7 +710,10 @@ int tg_selfplay_drain(TgEngine* e, int cap, TgExampleHeader* headers, void* stat
     unsigned long long total = 0;
     TG_HIP(hipMemcpy(&total, s->stats.as<unsigned long long>() + ST_EXAMPLES, 8, hipMemcpyDeviceToHost));
     const unsigned long long ME = (unsigned long long)s->p.max_examples;
-    if (total - s->drained > ME) s->drained = total - ME;  // older ones were overwritten in the ring
+    if (total - s->drained > ME) {  // older ones were overwritten in the ring: skipped, and counted
+        s->dropped += total - ME - s->drained;
+        s->drained = total - ME;
+    }
     const size_t sb = (size_t)e->g.bytes;
     const unsigned long long avail = total - s->drained;
     const int k = (int)std::min<unsigned long long>((unsigned long long)cap, avail);

@@ -21,6 +21,31 @@ __device__ inline int game_of_wave() { return (int)(blockIdx.x * WPB + (threadId
 __device__ inline void flag(const SearchDev& S, uint32_t bit) { atomicOr(S.err, bit); }
 __device__ inline void wave_sync_mem() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 
+// ---- node pool (search.cuh): chunks of 2^chunk_shift nodes handed out from a ring of free chunk ids ----
+// Take one chunk for the calling wave (wave-uniform result, 0 = pool exhausted).  Only chunks whose return was
+// published before this kernel started are handed out, so a taker never reads a ring slot that a concurrent
+// pool_give of the same launch has reserved but not yet written.
+__device__ inline uint32_t pool_take(const SearchDev& S) {
+    uint32_t c = 0;
+    if (lane_id() == 0) {
+        const unsigned long long h = atomicAdd(&S.pool_ctl[0], 1ull);
+        if (h < S.pool_ctl[2]) c = S.free_ring[h % S.n_chunks];
+    }
+    return uni((uint32_t)__shfl((int)c, 0));
+}
+// Return every chunk of a game's chain (lane 0 walks it; a chain is a handful to a few hundred chunks, once per move)
+__device__ inline void pool_give_chain(const SearchDev& S, uint32_t head) {
+    if (lane_id() != 0) return;
+    for (uint32_t c = head; c != 0;) {
+        const uint32_t next = S.chunk_link[c];
+        const unsigned long long t = atomicAdd(&S.pool_ctl[1], 1ull);
+        S.free_ring[t % S.n_chunks] = c;
+        c = next;
+    }
+}
+// after a kernel that returned chunks: make them available to the following launches
+__global__ void k_pool_publish(SearchDev S) { S.pool_ctl[2] = S.pool_ctl[1]; }
+
 __device__ inline uint64_t ws_hash(const WState& s, const Geom& g) {
     // same function of the packed bytes as the CPU statement: stack words, meta bytes, 10 header bytes
     uint64_t h = 0x243F6A8885A308D3ull;
@@ -51,7 +76,7 @@ __device__ inline void update_concrete(NodeHot& h, float reward) {
 // the leaf encoded in the network input batch.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* __restrict__ active, const int g, const int pass,
-                                            uint32_t* path) {
+                                            uint32_t* path, uint16_t* mvl) {
     const int lane = lane_id();
     // leaf slot of this pass: `batch` virtual rollouts per tree and iteration (Player's batching, player.rs:77-93), pass p
     // writing slot g·batch + p
@@ -63,11 +88,11 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
     const Geom geo = make_geom(S.n);
     WState s;
     ws_load(s, S.root_state + (size_t)g * geo.bytes, geo);
-    const size_t base = ((size_t)g * 2 + S.sel[g]) * (size_t)S.cap;
-    NodeHot* hot = S.hot + base;
-    NodeCold* cold = S.cold + base;
+    NodeHot* hot = S.hot;
+    NodeCold* cold = S.cold;
+    const uint32_t root = uni(S.root[g]);
     const uint32_t root_color = s.to_move;
-    uint32_t node = 0;
+    uint32_t node = root;
     int depth = 0;
     uint32_t res = TG_ONGOING;
     bool terminal = false;
@@ -77,8 +102,8 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
     // costs ONE dependent memory round trip (the coalesced hot + cold records of all children).
     uint32_t vis, vv, nres, cbase;
     {
-        NodeHot nh = hot[0];
-        NodeCold nc = cold[0];
+        NodeHot nh = hot[root];
+        NodeCold nc = cold[root];
         vis = uni(nh.visits); vv = uni(nh.virt); nres = uni((uint32_t)nc.nres); cbase = uni(nc.child);
     }
     for (;;) {
@@ -87,27 +112,41 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
             res = ws_result(s, geo);
             uint32_t count = 0, cb = 0;
             if (res == TG_ONGOING) {
-                uint32_t a = uni(S.alloc[g]);
-                int room = S.cap - (int)a;
-                NodeCold* blk = cold + a;
-                count = (uint32_t)ws_movegen(s, geo, room, [&](int idx, uint32_t code) {
-                    NodeCold c;
-                    c.child = 0; c.mv = (uint16_t)code; c.nres = 0;
-                    blk[idx] = c;
-                });
-                if ((int)count > room || count > 0xfffu) {
-                    flag(S, ERRF_ARENA);
+                // the legal moves are staged in LDS so that the children block can be placed once its size is known
+                count = (uint32_t)ws_movegen(s, geo, EX_MOVES, [&](int idx, uint32_t code) { mvl[idx] = (uint16_t)code; });
+                if (count > (uint32_t)EX_MOVES) {
+                    flag(S, ERRF_MOVES);
                     if (lane == 0) S.leaf_kind[slot] = 0;
                     return;
                 }
-                float temp_policy = 1.0f / (float)count;
+                uint32_t a = uni(S.alloc[2 * g]), end = uni(S.alloc[2 * g + 1]);
+                if (a + count > end) {  // the block does not fit into the game's open chunk: take the next one
+                    const uint32_t c = pool_take(S);
+                    if (c == 0) {
+                        flag(S, ERRF_ARENA);
+                        if (lane == 0) S.leaf_kind[slot] = 0;
+                        return;
+                    }
+                    a = c << S.chunk_shift;
+                    end = a + (1u << S.chunk_shift);
+                    if (lane == 0) {
+                        S.chunk_link[c] = S.chunk_head[g];
+                        S.chunk_head[g] = c;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const float temp_policy = 1.0f / (float)count;
                 for (uint32_t i = lane; i < count; i += 64) {
+                    NodeCold cc;
+                    cc.child = 0; cc.mv = mvl[i]; cc.nres = 0;
+                    cold[a + i] = cc;
                     NodeHot c;
                     c.prior = temp_policy; c.q = 0.0f; c.visits = 0; c.virt = 0;
                     hot[a + i] = c;
                 }
                 cb = a;
-                if (lane == 0) S.alloc[g] = a + count;
+                if (lane == 0) { S.alloc[2 * g] = a + count; S.alloc[2 * g + 1] = end; }
             }
             if (lane == 0) {
                 cold[node].child = cb;
@@ -181,7 +220,7 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
     const bool winner = res >= TG_WHITE_ROAD && res <= TG_BLACK_FLAT;
     const uint32_t wcolor = (res == TG_WHITE_ROAD || res == TG_WHITE_FLAT) ? 0u : 1u;
     for (int d = lane; d <= depth; d += 64) {
-        uint32_t nd = d == 0 ? 0u : path[d - 1];
+        uint32_t nd = d == 0 ? root : path[d - 1];
         NodeHot h = hot[nd];
         if (terminal) {
             uint32_t curr = root_color ^ (uint32_t)(d & 1);
@@ -218,12 +257,13 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
 // L1 path; an agent-scope fence would write back the whole L2 per wave and cost more than the launches it replaces).
 __global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __restrict__ active) {
     __shared__ uint32_t path_lds[WPB][MAX_DEPTH];
+    __shared__ uint16_t mv_lds[WPB][EX_MOVES];
     const int g = game_of_wave();
     if (g >= S.G) return;
     uint32_t* path = path_lds[threadIdx.x >> 6];
     const int p0 = S.pass < 0 ? 0 : S.pass, p1 = S.pass < 0 ? S.batch : S.pass + 1;
     for (int p = p0; p < p1; p++) {
-        select_pass(S, active, g, p, path);
+        select_pass(S, active, g, p, path, mv_lds[threadIdx.x >> 6]);
         if (p + 1 < p1) wave_sync_mem();
     }
 }
@@ -236,12 +276,12 @@ __device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, con
     const size_t slot = (size_t)g * (size_t)S.batch + (size_t)pass;
     if (S.leaf_kind[slot] != 1) return;
     const int lane = lane_id();
-    const size_t base = ((size_t)g * 2 + S.sel[g]) * (size_t)S.cap;
-    NodeHot* hot = S.hot + base;
-    NodeCold* cold = S.cold + base;
+    NodeHot* hot = S.hot;
+    NodeCold* cold = S.cold;
+    const uint32_t root = uni(S.root[g]);
     const uint32_t* path = S.path + slot * MAX_DEPTH;
     const int L = S.path_len[slot];
-    const uint32_t leaf = L ? path[L - 1] : 0u;
+    const uint32_t leaf = L ? path[L - 1] : root;
     NodeCold lc = cold[leaf];
     const uint32_t nchild = uni((uint32_t)lc.nres) & 0xfffu, cb = uni(lc.child);
     float e;
@@ -270,7 +310,7 @@ __device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, con
     }
     if (__ballot(bad)) flag(S, ERRF_MOVE);
     for (int d = lane; d <= L; d += 64) {
-        uint32_t nd = d == 0 ? 0u : path[d - 1];
+        uint32_t nd = d == 0 ? root : path[d - 1];
         NodeHot h = hot[nd];
         h.virt -= 1;
         float ev = ((L - d) & 1) ? e : -e;  // the leaf sees -eval, its parent +eval, …
@@ -299,11 +339,12 @@ __global__ __launch_bounds__(256) void k_backup(SearchDev S) {
 // disappears.  Same device functions as the separate kernels → same trees.
 __global__ __launch_bounds__(256) void k_backup_select(SearchDev S) {
     __shared__ uint32_t path_lds[WPB][MAX_DEPTH];
+    __shared__ uint16_t mv_lds[WPB][EX_MOVES];
     const int g = game_of_wave();
     if (g >= S.G) return;
     backup_pass(S, g, 0);
     wave_sync_mem();
-    select_pass(S, nullptr, g, 0, path_lds[threadIdx.x >> 6]);
+    select_pass(S, nullptr, g, 0, path_lds[threadIdx.x >> 6], mv_lds[threadIdx.x >> 6]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -316,11 +357,11 @@ __global__ __launch_bounds__(64) void k_dirichlet(SearchDev S, const uint8_t* __
     const int lane = threadIdx.x;
     if (!S.alive[g] || (active && !active[g])) return;
     const Geom geo = make_geom(S.n);
-    const size_t base = ((size_t)g * 2 + S.sel[g]) * (size_t)S.cap;
-    NodeHot* hot = S.hot + base;
-    NodeCold rc = S.cold[base];
+    const uint32_t root = S.root[g];
+    NodeHot* hot = S.hot;
+    NodeCold rc = S.cold[root];
     const uint32_t nchild = (uint32_t)rc.nres & 0xfffu, cb = rc.child;
-    if (nchild == 0 || hot[0].visits == 0) return;  // reference asserts visits > 0
+    if (nchild == 0 || hot[root].visits == 0) return;  // reference asserts visits > 0
     const uint32_t* hdr = (const uint32_t*)(S.root_state + (size_t)g * geo.bytes + geo.bytes - 16);
     const uint32_t ply = hdr[0] >> 16;
     const uint32_t gen = S.generation[g];
@@ -345,9 +386,8 @@ __global__ __launch_bounds__(64) void k_apply_noise(SearchDev S, const uint8_t* 
     const int g = blockIdx.x;
     const int lane = threadIdx.x;
     if (!S.alive[g] || (active && !active[g])) return;
-    const size_t base = ((size_t)g * 2 + S.sel[g]) * (size_t)S.cap;
-    NodeHot* hot = S.hot + base;
-    NodeCold rc = S.cold[base];
+    NodeHot* hot = S.hot;
+    NodeCold rc = S.cold[S.root[g]];
     const uint32_t nchild = (uint32_t)rc.nres & 0xfffu, cb = rc.child;
     for (uint32_t i = lane; i < nchild && i < EX_MOVES; i += 64) {
         float p = hot[cb + i].prior;
@@ -357,90 +397,103 @@ __global__ __launch_bounds__(64) void k_apply_noise(SearchDev S, const uint8_t* 
 
 // ------------------------------------------------------------------------------------------------
 // tree reuse: Node::play, play.rs:26-43.  op[g]: -2 = reset the tree (Node::default()), -1 = nothing,
-// ≥ 0 = make that child the root.  The kept subtree is copied breadth-first into the other arena; each
-// block of children is written exactly once with its final child pointers.
+// ≥ 0 = make that child the root.  The kept subtree is copied breadth-first into fresh chunks and the game's
+// old chunks go back to the pool.  The copy is its own work queue (Cheney): a node is first copied with the OLD
+// index of its children block; a scan pointer follows the allocation pointer through the new chunks and, for
+// every copied node that has children, copies that block behind the allocation pointer and patches the index.
+// No queue in LDS, no limit on the width or depth of the tree.  One wave per game.
 // ------------------------------------------------------------------------------------------------
-struct QDesc { uint32_t old_start, new_start, count; };
-constexpr int QCAP = 4096;
-
 __global__ __launch_bounds__(64) void k_reroot(SearchDev S, const int32_t* __restrict__ op) {
-    __shared__ QDesc q[QCAP];
     const int g = blockIdx.x;
     const int lane = threadIdx.x;
     const int o = op[g];
     if (o == -1) return;
-    const uint32_t cur = S.sel[g];
-    const size_t base_old = ((size_t)g * 2 + cur) * (size_t)S.cap;
+    const uint32_t CH = 1u << S.chunk_shift;
+    const uint32_t old_root = S.root[g];
+    const uint32_t old_head = S.chunk_head[g];
+    NodeHot* hot = S.hot;
+    NodeCold* cold = S.cold;
     if (o == -2) {
+        pool_give_chain(S, old_head);
+        const uint32_t c = pool_take(S);
+        if (c == 0) { flag(S, ERRF_ARENA); return; }
+        const uint32_t a = c << S.chunk_shift;
         if (lane == 0) {
             NodeHot h; h.prior = 0.0f; h.q = 0.0f; h.visits = 0; h.virt = 0;
-            NodeCold c; c.child = 0; c.mv = 0; c.nres = 0;
-            S.hot[base_old] = h;
-            S.cold[base_old] = c;
-            S.alloc[g] = 1;
+            NodeCold cc; cc.child = 0; cc.mv = 0; cc.nres = 0;
+            hot[a] = h;
+            cold[a] = cc;
+            S.root[g] = a;
+            S.alloc[2 * g] = a + 1;
+            S.alloc[2 * g + 1] = a + CH;
+            S.chunk_link[c] = 0;
+            S.chunk_head[g] = c;
         }
         return;
     }
-    const size_t base_new = ((size_t)g * 2 + (cur ^ 1u)) * (size_t)S.cap;
-    const NodeHot* hot_o = S.hot + base_old;
-    const NodeCold* cold_o = S.cold + base_old;
-    NodeHot* hot_n = S.hot + base_new;
-    NodeCold* cold_n = S.cold + base_new;
-    NodeCold rc = cold_o[0];
+    const NodeCold rc = cold[old_root];
     const uint32_t rn = (uint32_t)rc.nres & 0xfffu;
     if ((uint32_t)o >= rn) { flag(S, ERRF_MOVE); return; }
     const uint32_t oc = rc.child + (uint32_t)o;
-    NodeCold cc = cold_o[oc];
-    uint32_t new_alloc = 1;
-    int head = 0, tail = 0;
-    const uint32_t cn = (uint32_t)cc.nres & 0xfffu;
+    uint32_t cur = pool_take(S);  // the chunk being filled
+    if (cur == 0) { flag(S, ERRF_ARENA); return; }
+    const uint32_t first = cur;
+    uint32_t aoff = 1;            // nodes used in `cur`
     if (lane == 0) {
-        hot_n[0] = hot_o[oc];
-        NodeCold c = cc;
-        c.child = cn ? 1u : 0u;
-        cold_n[0] = c;
-        if (cn) { q[0].old_start = cc.child; q[0].new_start = 1; q[0].count = cn; }
+        hot[first << S.chunk_shift] = hot[oc];
+        cold[first << S.chunk_shift] = cold[oc];  // .child still names the old block: patched when the scan reaches it
+        S.chunk_link[first] = 0;
     }
-    if (cn) { tail = 1; new_alloc = 1 + cn; }
-    __syncthreads();
-    bool overflow = false;
-    while (head != tail) {
-        QDesc d = q[head % QCAP];
-        head++;
-        for (uint32_t k0 = 0; k0 < d.count; k0 += 64) {
-            uint32_t k = k0 + lane;
-            bool on = k < d.count;
-            NodeCold c;
-            c.child = 0; c.mv = 0; c.nres = 0;
-            if (on) c = cold_o[d.old_start + k];
-            uint32_t nch = on ? ((uint32_t)c.nres & 0xfffu) : 0u;
-            int incl = wave_inclusive_scan((int)nch);
-            uint32_t my_new = new_alloc + (uint32_t)(incl - (int)nch);
-            uint64_t bb = __ballot(nch > 0);
-            if (nch > 0) {
-                int rank = __popcll(bb & ((1ull << lane) - 1ull));
-                if (tail + rank - head >= QCAP) overflow = true;
-                else {
-                    QDesc nd;
-                    nd.old_start = c.child; nd.new_start = my_new; nd.count = nch;
-                    q[(tail + rank) % QCAP] = nd;
-                }
-            }
-            if (on) {
-                hot_n[d.new_start + k] = hot_o[d.old_start + k];
-                c.child = nch ? my_new : 0u;
-                cold_n[d.new_start + k] = c;
-            }
-            new_alloc += (uint32_t)__shfl(incl, 63);
-            tail += __popcll(bb);
+    wave_sync_mem();
+    uint32_t scan_c = first, scan_off = 0;
+    for (;;) {
+        const uint32_t limit = scan_c == cur ? aoff : uni(S.chunk_used[scan_c]);
+        if (scan_off >= limit) {
+            if (scan_c == cur) break;
+            scan_c = uni(S.chunk_fwd[scan_c]);
+            scan_off = 0;
+            continue;
         }
-        __syncthreads();
-        if (__ballot(overflow)) { flag(S, ERRF_QUEUE); break; }
+        const uint32_t m = min(64u, limit - scan_off);
+        const uint32_t idx = (scan_c << S.chunk_shift) + scan_off + (uint32_t)lane;
+        const bool on = (uint32_t)lane < m;
+        NodeCold c;
+        c.child = 0; c.mv = 0; c.nres = 0;
+        if (on) c = cold[idx];
+        const uint32_t nch = on ? ((uint32_t)c.nres & 0xfffu) : 0u;
+        uint32_t my_new = 0;
+        bool failed = false;
+        for (uint64_t bb = __ballot(nch > 0); bb; bb &= bb - 1) {
+            const int l = __builtin_ctzll(bb);
+            const uint32_t cnt = uni((uint32_t)__shfl((int)nch, l));
+            const uint32_t src = uni((uint32_t)__shfl((int)c.child, l));
+            if (aoff + cnt > CH) {  // close the chunk, open the next
+                const uint32_t c2 = pool_take(S);
+                if (c2 == 0) { failed = true; break; }
+                if (lane == 0) { S.chunk_used[cur] = aoff; S.chunk_fwd[cur] = c2; S.chunk_link[c2] = cur; }
+                cur = c2;
+                aoff = 0;
+            }
+            const uint32_t dst = (cur << S.chunk_shift) + aoff;
+            for (uint32_t k = lane; k < cnt; k += 64) {
+                hot[dst + k] = hot[src + k];
+                cold[dst + k] = cold[src + k];
+            }
+            if (lane == l) my_new = dst;
+            aoff += cnt;
+        }
+        if (failed) { flag(S, ERRF_ARENA); return; }  // the error is sticky: the engine refuses further work until reset
+        if (nch > 0) cold[idx].child = my_new;
+        scan_off += m;
+        wave_sync_mem();  // the scan reads back what this wave has just written
     }
     if (lane == 0) {
-        S.sel[g] = (uint8_t)(cur ^ 1u);
-        S.alloc[g] = new_alloc;
+        S.root[g] = first << S.chunk_shift;
+        S.alloc[2 * g] = (cur << S.chunk_shift) + aoff;
+        S.alloc[2 * g + 1] = (cur + 1) << S.chunk_shift;
+        S.chunk_head[g] = cur;
     }
+    pool_give_chain(S, old_head);
 }
 
 // root children → host-visible arrays (Node::improved_policy, play.rs:13-21, plus priors / q)
@@ -448,15 +501,15 @@ __global__ __launch_bounds__(64) void k_root_stats(SearchDev S, uint16_t* moves,
                                                    int32_t* counts, uint32_t* root_visits, float* root_q) {
     const int g = blockIdx.x;
     const int lane = threadIdx.x;
-    const size_t base = ((size_t)g * 2 + S.sel[g]) * (size_t)S.cap;
-    NodeCold rc = S.cold[base];
-    NodeHot rh = S.hot[base];
+    const uint32_t root = S.root[g];
+    NodeCold rc = S.cold[root];
+    NodeHot rh = S.hot[root];
     const uint32_t nchild = (uint32_t)rc.nres & 0xfffu, cb = rc.child;
     if (lane == 0) { counts[g] = (int32_t)nchild; root_visits[g] = rh.visits; root_q[g] = rh.q; }
     for (uint32_t i = lane; i < nchild && i < EX_MOVES; i += 64) {
-        NodeHot h = S.hot[base + cb + i];
+        NodeHot h = S.hot[cb + i];
         size_t o = (size_t)g * EX_MOVES + i;
-        moves[o] = S.cold[base + cb + i].mv;
+        moves[o] = S.cold[cb + i].mv;
         visits[o] = h.visits;
         prior[o] = h.prior;
         q[o] = h.q;
@@ -471,14 +524,13 @@ __global__ __launch_bounds__(256) void k_play_move(SearchDev S, const uint16_t* 
     const int lane = lane_id();
     if (!S.alive[g] || (active && !active[g])) { if (lane == 0) op[g] = -1; return; }
     const Geom geo = make_geom(S.n);
-    const size_t base = ((size_t)g * 2 + S.sel[g]) * (size_t)S.cap;
-    NodeCold rc = S.cold[base];
+    NodeCold rc = S.cold[S.root[g]];
     const uint32_t nchild = uni((uint32_t)rc.nres) & 0xfffu, cb = uni(rc.child);
     const uint32_t mv = uni((uint32_t)moves[g]);
     int found = -1;
     for (uint32_t i0 = 0; i0 < nchild && found < 0; i0 += 64) {
         uint32_t i = i0 + lane;
-        bool hit = i < nchild && S.cold[base + cb + i].mv == mv;
+        bool hit = i < nchild && S.cold[cb + i].mv == mv;
         uint64_t bb = __ballot(hit);
         if (bb) found = (int)i0 + __builtin_ctzll(bb);
     }
@@ -671,10 +723,9 @@ __global__ __launch_bounds__(256) void k_sp_pick(SearchDev S, SelfPlayDev P, int
     if (lane == 0) { P.fin[g] = 0; op[g] = -1; }
     if (!S.alive[g]) return;
     const Geom geo = make_geom(S.n);
-    const size_t base = ((size_t)g * 2 + S.sel[g]) * (size_t)S.cap;
-    const NodeHot* hot = S.hot + base;
-    const NodeCold* cold = S.cold + base;
-    NodeCold rc = cold[0];
+    const NodeHot* hot = S.hot;
+    const NodeCold* cold = S.cold;
+    NodeCold rc = cold[S.root[g]];
     const uint32_t nchild = uni((uint32_t)rc.nres) & 0xfffu, cb = uni(rc.child);
     WState s;
     uint8_t* st = S.root_state + (size_t)g * geo.bytes;
@@ -758,7 +809,10 @@ void launch_dirichlet(hipStream_t st, const SearchDev& S, const uint8_t* active,
 void launch_apply_noise(hipStream_t st, const SearchDev& S, const uint8_t* active, const float* noise, float ratio) {
     hipLaunchKernelGGL(k_apply_noise, dim3(S.G), dim3(64), 0, st, S, active, noise, ratio);
 }
-void launch_reroot(hipStream_t st, const SearchDev& S, const int32_t* op) { hipLaunchKernelGGL(k_reroot, dim3(S.G), dim3(64), 0, st, S, op); }
+void launch_reroot(hipStream_t st, const SearchDev& S, const int32_t* op) {
+    hipLaunchKernelGGL(k_reroot, dim3(S.G), dim3(64), 0, st, S, op);
+    hipLaunchKernelGGL(k_pool_publish, dim3(1), dim3(1), 0, st, S);
+}
 void launch_root_stats(hipStream_t st, const SearchDev& S, uint16_t* moves, uint32_t* visits, float* prior, float* q, int32_t* counts,
                        uint32_t* root_visits, float* root_q) {
     hipLaunchKernelGGL(k_root_stats, dim3(S.G), dim3(64), 0, st, S, moves, visits, prior, q, counts, root_visits, root_q);

@@ -8,6 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtakgpu.so")
 
+TG_ABI_VERSION = 2
 TG_MAX_MOVES = 512
 HEAD_FC5, HEAD_CONV = 0, 1
 EVAL_RESNET, EVAL_DUMMY, EVAL_HASH = 0, 1, 2
@@ -51,7 +52,8 @@ class TgSelfPlayConfig(C.Structure):
 
 class TgSelfPlayStats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in (
-        "games_finished", "examples", "expansions", "evals", "plies", "white_wins", "black_wins", "draws", "instant_wins")]
+        "games_finished", "examples", "expansions", "evals", "plies", "white_wins", "black_wins", "draws", "instant_wins",
+        "dropped_examples")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -273,7 +275,7 @@ class Engine:
         self.n = board_size
         self.head = policy_head
         self.max_batch = max_batch
-        self.cfg = TgConfig(1, device, board_size, res_blocks, filters, policy_head, evaluator, max_batch)
+        self.cfg = TgConfig(TG_ABI_VERSION, device, board_size, res_blocks, filters, policy_head, evaluator, max_batch)
         self.h = C.c_void_p(None)
         self._check(self.lib.tg_engine_create(C.byref(self.cfg), C.byref(self.h)))
         self.sb = state_bytes(board_size)

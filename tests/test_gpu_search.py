@@ -145,6 +145,55 @@ def test_arena_overflow_is_reported(orc):
     with pytest.raises(tak_amd.TgError) as ei:
         e.search_root()
     assert ei.value.code == -5
+    # the error is sticky until the trees are reset; afterwards the pool is whole again
+    with pytest.raises(tak_amd.TgError):
+        e.search_run(1)
+        e.search_root()
+    e.search_reset(_roots(orc, 5, 2, seed=4, max_plies=30))
+    e.search_run(20)
+    assert (e.search_root()["root_visits"] == 20).all()
+    e.close()
+
+
+def test_one_pool_for_all_trees(orc):
+    """All trees live in one node pool handed out in chunks (search.cuh): one game may grow far beyond the average budget
+    while the others stay small, and the chunks of discarded subtrees are reused — 60 plies of search + tree reuse allocate
+    many times the pool.  Trees stay bit-identical to the oracle's throughout."""
+    import tak_amd
+
+    n, games = 5, 12
+    e = _mk(n, tak_amd.EVAL_HASH, games)
+    e.search_create(games, arena_nodes=3072, seed=21)  # pool = 36 864 nodes + slack, chunks of 1024
+    s = orc.Search(n, head=orc.HEAD_FC5, evaluator=orc.EVAL_HASH, seed=21)
+    sts = _roots(orc, n, games, seed=8, max_plies=12)
+    e.search_reset(sts)
+    s.reset(sts)
+    only0 = np.zeros(games, np.uint8)
+    only0[0] = 1
+    e.search_run(400, only0)  # ≈ 25 000 nodes in ONE tree: eight times the per-game average
+    s.run(400, only0)
+    e.search_run(30)
+    s.run(30)
+    _assert_same_trees(e, s, games)
+    assert len(e.search_dump(0)) > 5 * 3072
+    expansions = 0
+    for ply in range(60):
+        r = e.search_root()
+        mv = np.array([_best(r, g) if r["counts"][g] else 0 for g in range(games)], np.uint16)
+        nxt, _ = orc.play(n, e.search_states(), mv)
+        act = ((orc.result(n, nxt) == 0) & (r["counts"] > 0)).astype(np.uint8)
+        if not act.any():
+            break
+        e.search_play(mv, act)
+        s.play(mv, act)
+        e.search_run(40, act)
+        s.run(40, act)
+        expansions += 40 * int(act.sum())
+        if ply % 8 == 7:
+            _assert_same_trees(e, s, games)
+    _assert_same_trees(e, s, games)
+    assert e.search_counters() == s.counters()
+    assert expansions * 30 > 4 * games * 3072  # far more nodes were allocated than the pool holds at once
     e.close()
 
 
@@ -367,8 +416,8 @@ def test_examples_written_in_reference_text_format(orc, tmp_path):
 
 
 def test_arena_auto_sizing(orc):
-    """arena_nodes = 0: the engine sizes the per-game arenas from the free device memory (2^14 … 2^19 nodes) — a search that
-    overflows a 2^10 arena runs through"""
+    """arena_nodes = 0: the engine sizes the node pool from the free device memory (up to 2^20 nodes per game) — a search that
+    exhausts a pool of 2^10 nodes per game runs through"""
     import tak_amd
 
     e = _mk(5, tak_amd.EVAL_HASH, 8)

@@ -405,8 +405,11 @@ int tg_train_create(TgEngine* e, const TgTrainConfig* cfg);
  * the host (a reachable state, 1 ≤ n_moves ≤ TG_MAX_MOVES, at least one visit) → TG_ERR_INVALID_ARG. */
 int tg_train_chunk(TgEngine* e, int n, const void* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
                    const float* results, float* loss_p, float* loss_z, int32_t* stepped);
-/* Network::train (network.rs:37-56): fresh Adam state, shuffle (Philox keyed by seed; the reference uses
- * thread_rng), chunks_exact(chunk_size) → tg_train_chunk each.  mean losses over the chunks are returned. */
+/* Network::train (network.rs:37-56): fresh Adam state and zeroed gradients, shuffle (Philox keyed by seed; the reference
+ * uses thread_rng), chunks_exact(chunk_size) → tg_train_chunk each.  mean losses over the chunks are returned.  Every
+ * example is validated before the first chunk, so that with several ranks an argument error cannot strand the others in a
+ * collective; tg_train_chunk validates only its own chunk — a data-parallel caller of tg_train_chunk must agree on errors
+ * across ranks itself before the chunk that completes an optimiser step. */
 int tg_train(TgEngine* e, int n, const void* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
              const float* results, uint64_t seed, float* mean_loss_p, float* mean_loss_z, int32_t* steps);
 /* opt.step(); opt.zero_grad() now (network.rs:92-96), whatever the chunk counter says */
@@ -424,6 +427,18 @@ int tg_train_commit(TgEngine* e);
  * to every rank (any host transport); then every rank calls tg_train_comm_init. */
 int tg_comm_unique_id(void* id128);
 int tg_train_comm_init(TgEngine* e, int rank, int world_size, const void* id128);
+/* The same reduction through a caller-supplied function instead of RCCL — ranks that share one GPU (RCCL refuses duplicate
+ * devices), a host transport (gloo, MPI, a socket from Rust), or a test.  The optimiser step calls
+ * fn(ctx, d_buf, count, stream) with the flat gradient buffer (device memory, `count` floats); on return — or, if fn only
+ * enqueues work, in the order of `stream` (the engine's hipStream_t) — d_buf must hold the SUM over all world_size ranks.
+ * The step then applies Adam to d_buf / world_size, so every rank that saw the same sum ends with bit-identical parameters.
+ * tg_train_commit reduces the BatchNorm running statistics through the same function.  fn returns 0 or an error code
+ * (→ TG_ERR_STATE).  fn = NULL removes the hook.  Mutually exclusive with tg_train_comm_init. */
+typedef int (*TgAllReduceFn)(void* ctx, float* d_buf, size_t count, void* hip_stream);
+int tg_train_set_allreduce(TgEngine* e, TgAllReduceFn fn, void* ctx, int world_size);
+/* device address and length (floats) of the flat gradient buffer the reduction operates on: parameters in the creation
+ * order of tg_net_set_tensor's names, BatchNorm buffers excluded */
+int tg_train_grad_buffer(TgEngine* e, float** d_grads, size_t* count);
 
 /* ---------------------------------------------------------------------------------------
  * Pit (replaces `pit`, train/src/pit.rs:15-96): the new network against the old one,

@@ -100,9 +100,11 @@ struct Trainer {
     bool packed = false;
     uint64_t adam_t = 0;
     int chunk_num = 0;
-    // communicator
+    // communicator (RCCL) or caller-supplied reduction (tg_train_set_allreduce)
     void* comm = nullptr;
     int world = 1, rank = 0;
+    TgAllReduceFn hook = nullptr;
+    void* hook_ctx = nullptr;
     ~Trainer() {
         if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
     }
@@ -257,14 +259,32 @@ int backward_train(TgEngine* e, int B) {
     return TG_OK;
 }
 
+// Sum a device buffer over the ranks, in place, ordered on the engine stream: the caller's hook if one is set, else RCCL.
+// Returns false through *reduced when the trainer is single-rank (nothing to do).
+static int all_reduce_sum(TgEngine* e, float* d_buf, size_t count, const char* what, bool* reduced) {
+    Trainer* t = e->trainer;
+    *reduced = false;
+    if (t->hook) {
+        int rc = t->hook(t->hook_ctx, d_buf, count, (void*)e->stream);
+        if (rc) return fail(TG_ERR_STATE, std::string("all-reduce hook failed (") + what + "), code " + std::to_string(rc));
+        *reduced = true;
+    } else if (t->comm) {
+        int rc = g_rccl.AllReduce(d_buf, d_buf, count, NCCL_FLOAT32, NCCL_SUM, t->comm, e->stream);
+        if (rc) return fail(TG_ERR_HIP, std::string("ncclAllReduce (") + what + "): " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
+        *reduced = true;
+    }
+    return TG_OK;
+}
+
 int optimizer_step(TgEngine* e) {
     Trainer* t = e->trainer;
     hipStream_t st = e->stream;
     float gscale = 1.0f;
-    if (t->comm) {
-        int rc = g_rccl.AllReduce(t->grads.p, t->grads.p, t->n_params, NCCL_FLOAT32, NCCL_SUM, t->comm, st);
-        if (rc) return fail(TG_ERR_HIP, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
-        gscale = 1.0f / (float)t->world;
+    {
+        bool reduced;
+        int rc = all_reduce_sum(e, t->grads.as<float>(), t->n_params, "gradients", &reduced);
+        if (rc) return rc;
+        if (reduced) gscale = 1.0f / (float)t->world;
     }
     t->adam_t++;
     const double b1 = t->cfg.beta1, b2 = t->cfg.beta2;
@@ -521,8 +541,17 @@ int tg_train(TgEngine* e, int n, const void* states, const int32_t* n_moves, con
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!states || !n_moves || !moves || !visits || !results))) return fail(TG_ERR_INVALID_ARG, "tg_train: bad arguments");
     Trainer* t = e->trainer;
-    // a fresh optimiser per call (network.rs:40-45); gradients left over from an incomplete step of the previous
-    // call stay in place, exactly as the .grad tensors of the reference's VarStore do
+    // every example is checked before the first chunk: with several ranks a validation error in the middle of the loop
+    // would leave the other ranks waiting in the optimiser step's all-reduce
+    for (int i = 0; i < n; i++) {
+        rc = validate_states(e, 1, (const uint8_t*)states + (size_t)i * e->g.bytes, "training example");
+        if (rc) return rc;
+        if (n_moves[i] < 1 || n_moves[i] > TG_MAX_MOVES) return fail(TG_ERR_INVALID_ARG, "tg_train: example " + std::to_string(i) + " has no moves / too many");
+    }
+    // a fresh optimiser per call (network.rs:40-45) on fresh gradients: the reference trains a fresh copy of the network
+    // each round (train/src/main.rs `copy`: save + load into a new VarStore), so the gradients an incomplete last step
+    // left behind (n / chunk_size not a multiple of chunks_in_step) never reach the next call's first step
+    TG_HIP(hipMemsetAsync(t->grads.p, 0, t->n_params * 4, e->stream));
     TG_HIP(hipMemsetAsync(t->adam_m.p, 0, t->n_params * 4, e->stream));
     TG_HIP(hipMemsetAsync(t->adam_v.p, 0, t->n_params * 4, e->stream));
     t->adam_t = 0;
@@ -602,15 +631,16 @@ int tg_train_commit(TgEngine* e) {
     int rc = need_trainer(e);
     if (rc) return rc;
     Trainer* t = e->trainer;
-    if (t->comm && t->n_buffers) {  // data parallel: every rank normalised with its own batches → average the running statistics
-        int r = g_rccl.AllReduce(t->bnbuf.p, t->bnbuf.p, t->n_buffers, NCCL_FLOAT32, NCCL_SUM, t->comm, e->stream);
-        if (r) return fail(TG_ERR_HIP, "ncclAllReduce (BN running statistics) failed");
+    bool averaged = false;
+    if (t->n_buffers) {  // data parallel: every rank normalised with its own batches → average the running statistics
+        rc = all_reduce_sum(e, t->bnbuf.as<float>(), t->n_buffers, "BatchNorm running statistics", &averaged);
+        if (rc) return rc;
     }
     TG_HIP(hipStreamSynchronize(e->stream));
     std::vector<float> hp(t->n_params), hb(t->n_buffers);
     TG_HIP(hipMemcpy(hp.data(), t->params.p, t->n_params * 4, hipMemcpyDeviceToHost));
     TG_HIP(hipMemcpy(hb.data(), t->bnbuf.p, t->n_buffers * 4, hipMemcpyDeviceToHost));
-    if (t->comm) {
+    if (averaged) {
         for (float& v : hb) v /= (float)t->world;
         TG_HIP(hipMemcpy(t->bnbuf.p, hb.data(), t->n_buffers * 4, hipMemcpyHostToDevice));
     }
@@ -619,6 +649,28 @@ int tg_train_commit(TgEngine* e) {
         if (rc) return rc;
     }
     return net_finalize(e);
+}
+
+int tg_train_set_allreduce(TgEngine* e, TgAllReduceFn fn, void* ctx, int world_size) {
+    int rc = need_trainer(e);
+    if (rc) return rc;
+    if (world_size < 1) return fail(TG_ERR_INVALID_ARG, "tg_train_set_allreduce: world_size must be ≥ 1");
+    Trainer* t = e->trainer;
+    if (t->comm && fn) return fail(TG_ERR_STATE, "tg_train_set_allreduce: an RCCL communicator is already attached (tg_train_comm_init)");
+    t->hook = fn;
+    t->hook_ctx = ctx;
+    if (fn) t->world = world_size;
+    else if (!t->comm) t->world = 1;
+    return TG_OK;
+}
+
+int tg_train_grad_buffer(TgEngine* e, float** d_grads, size_t* count) {
+    int rc = need_trainer(e);
+    if (rc) return rc;
+    if (!d_grads || !count) return fail(TG_ERR_INVALID_ARG, "null argument");
+    *d_grads = e->trainer->grads.as<float>();
+    *count = e->trainer->n_params;
+    return TG_OK;
 }
 
 int tg_comm_unique_id(void* id128) {
@@ -637,6 +689,7 @@ int tg_train_comm_init(TgEngine* e, int rank, int world_size, const void* id128)
     rc = rccl_load();
     if (rc) return rc;
     Trainer* t = e->trainer;
+    if (t->hook) return fail(TG_ERR_STATE, "tg_train_comm_init: a reduction hook is set (tg_train_set_allreduce)");
     if (t->comm) { g_rccl.CommDestroy(t->comm); t->comm = nullptr; }
     Id128 id;
     std::memcpy(id.bytes, id128, 128);

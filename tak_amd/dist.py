@@ -41,6 +41,16 @@ def reduce_time_and_count(dist, dt_local, count_local, device="cpu"):
     return float(t.item()), int(c.item())
 
 
+def reduce_min(dist, value, device="cpu"):
+    if dist is None:
+        return value
+    import torch
+
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return t.item()
+
+
 def training_shard(n_examples, rank, world, chunk_size):
     """[begin, end) of a rank's examples for data-parallel training: every rank gets the same number of WHOLE chunks
     (the gradient all-reduce inside tg_train_chunk's optimiser step must be entered equally often on every rank);
@@ -62,3 +72,21 @@ def broadcast_unique_id(dist, make_id, device="cpu"):
         buf.copy_(torch.frombuffer(bytearray(make_id()), dtype=torch.uint8))
     dist.broadcast(buf, src=0)
     return bytes(buf.cpu().numpy().tobytes())
+
+
+def host_allreduce_hook(dist):
+    """A reduction for Engine.train_set_allreduce that sums over the ranks of a torch.distributed group on the HOST
+    (gloo): device buffer → host, all_reduce(SUM), host → device.  For ranks that share one GPU (RCCL refuses duplicate
+    devices) and for CPU-side rehearsals of the data-parallel path; real multi-GPU training uses tg_train_comm_init (RCCL)."""
+    import torch
+
+    from . import engine as eng
+
+    def fn(d_buf, count, stream):
+        host = eng.device_to_host(d_buf, count, stream)
+        t = torch.from_numpy(host)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        eng.host_to_device(d_buf, t.numpy())
+        return 0
+
+    return fn

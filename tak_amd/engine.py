@@ -90,9 +90,32 @@ ABI_SYMBOLS = [
     "tg_profile_enable", "tg_profile_read", "tg_board_pass_bench",
     "tg_augment_examples",
     "tg_train_create", "tg_train_chunk", "tg_train", "tg_train_step", "tg_train_forward", "tg_train_get_tensor",
-    "tg_train_get_grad", "tg_train_commit", "tg_comm_unique_id", "tg_train_comm_init", "tg_pit",
+    "tg_train_get_grad", "tg_train_commit", "tg_comm_unique_id", "tg_train_comm_init", "tg_train_set_allreduce",
+    "tg_train_grad_buffer", "tg_pit",
     "tg_format_move", "tg_parse_move", "tg_format_tps", "tg_parse_tps", "tg_format_example", "tg_parse_example",
 ]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+def device_to_host(d_ptr, count, stream=None):
+    """`count` floats of device memory as a numpy array (after synchronising `stream`); HIP runtime through the
+    library's own dependency (no torch involved)."""
+    lib = load_library()
+    if stream is not None:
+        rc = lib.hipStreamSynchronize(C.c_void_p(stream))
+        assert rc == 0, f"hipStreamSynchronize: {rc}"
+    out = np.empty(count, np.float32)
+    rc = lib.hipMemcpy(_p(out), C.c_void_p(d_ptr), C.c_size_t(count * 4), 2)  # hipMemcpyDeviceToHost
+    assert rc == 0, f"hipMemcpy D2H: {rc}"
+    return out
+
+
+def host_to_device(d_ptr, array):
+    a = np.ascontiguousarray(array, np.float32)
+    rc = load_library().hipMemcpy(C.c_void_p(d_ptr), _p(a), C.c_size_t(a.size * 4), 1)  # hipMemcpyHostToDevice
+    assert rc == 0, f"hipMemcpy H2D: {rc}"
 
 
 def build_library():
@@ -410,6 +433,32 @@ class Engine:
 
     def train_commit(self):
         self._check(self.lib.tg_train_commit(self.h))
+
+    def train_set_allreduce(self, fn, world):
+        """Route the gradient / BatchNorm-statistics reduction through fn(d_ptr, count, stream) -> 0 | error instead of
+        RCCL (tg_train_set_allreduce).  fn must leave the SUM over all `world` ranks in the device buffer.  None removes it."""
+        if fn is None:
+            self._allreduce_cb = None
+            self._check(self.lib.tg_train_set_allreduce(self.h, None, None, 1))
+            return
+
+        def cb(ctx, d_buf, count, stream):
+            try:
+                return int(fn(d_buf, count, stream) or 0)
+            except Exception:  # an exception must not unwind through the C caller
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        self._allreduce_cb = ALLREDUCE_FN(cb)  # kept alive as long as the engine uses it
+        self._check(self.lib.tg_train_set_allreduce(self.h, self._allreduce_cb, None, int(world)))
+
+    def train_grad_buffer(self):
+        """(device address, float count) of the flat gradient buffer"""
+        ptr, cnt = C.c_void_p(0), C.c_size_t(0)
+        self._check(self.lib.tg_train_grad_buffer(self.h, C.byref(ptr), C.byref(cnt)))
+        return ptr.value, cnt.value
 
     def train_comm_init(self, rank, world, unique_id):
         uid = np.frombuffer(bytes(unique_id), np.uint8).copy()

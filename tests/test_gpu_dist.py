@@ -1,0 +1,132 @@
+"""The multi-GPU path driven through the PRODUCT (libtakgpu), on one card: SURVEY.md §8(e) partitions self-play by game
+(rank r owns global slots [r·G, (r+1)·G), TgSearchConfig.slot_base, weights replicated, no data-path collective) and
+trains data-parallel with one gradient all-reduce per optimiser step.  Two OS processes — two ranks, both on device 0,
+torch.distributed/gloo as the host transport (RCCL refuses two ranks on one device; with one GPU per rank the same
+code path runs tg_train_comm_init instead of the host hook) — must reproduce a single process that owns all the games."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import torch_ref
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N, BLOCKS, FILTERS, G, PLIES = 5, 2, 32, 6, 110
+KW = dict(rollouts=16, noise_plies=8, exploit_plies=6, total_games=0, seed=13, arena_nodes=1 << 14, max_examples=1 << 13)
+
+
+def _keyed(h, s, m, v):
+    return {(int(h["game_id"][i]), s[i].tobytes()): (m[i].tobytes(), v[i].tobytes(), float(h["result"][i])) for i in range(len(h))}
+
+
+def test_slot_base_shard_equals_the_slots_of_a_full_run(orc):
+    # one process: an engine that owns slots G…2G-1 (slot_base = G) against one that owns 0…2G-1, hash evaluator and network
+    import tak_amd
+
+    net = torch_ref.make_net(N, BLOCKS, FILTERS, "fc5", seed=2)
+    for evaluator in (tak_amd.EVAL_HASH, tak_amd.EVAL_RESNET):
+        runs = []
+        for games, base in ((2 * G, 0), (G, G), (G, 0)):
+            e = tak_amd.Engine(N, res_blocks=BLOCKS, filters=FILTERS, evaluator=evaluator, max_batch=64)
+            if evaluator == tak_amd.EVAL_RESNET:
+                e.load_state_dict(torch_ref.abi_tensors(net))
+            e.selfplay_create(games, slot_base=base, **KW)
+            e.selfplay_step(PLIES)
+            runs.append((e.selfplay_stats(), e.selfplay_drain(1 << 13), e.search_states()))
+            e.close()
+        (full_st, full_ex, full_roots), (hi_st, hi_ex, hi_roots), (lo_st, lo_ex, lo_roots) = runs
+        assert full_st["examples"] > 0 and full_st["examples"] == hi_st["examples"] + lo_st["examples"]
+        assert full_st["expansions"] == hi_st["expansions"] + lo_st["expansions"]
+        slot = full_ex[0]["game_id"] & 0xFFFFF
+        for part, keep in ((hi_ex, slot >= G), (lo_ex, slot < G)):
+            # the shard's examples ARE the full run's examples of its slots, in the same order
+            assert np.array_equal(part[0], full_ex[0][keep])
+            for a, b in zip(part[1:], full_ex[1:]):
+                assert np.array_equal(a, b[keep])
+        assert np.array_equal(full_roots[G:], hi_roots) and np.array_equal(full_roots[:G], lo_roots)
+        if evaluator == tak_amd.EVAL_HASH:  # and the oracle agrees on the shard
+            okw = {k: v for k, v in KW.items() if k not in ("arena_nodes", "max_examples")}
+            sp = orc.SelfPlay(N, G, head=orc.HEAD_FC5, evaluator=orc.EVAL_HASH, slot_base=G, **okw)
+            sp.step(PLIES)
+            oh, os_, om, ov = sp.drain(1 << 13)
+            assert np.array_equal(oh, hi_ex[0]) and np.array_equal(os_, hi_ex[1]) and np.array_equal(ov, hi_ex[3])
+
+
+WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import tak_amd
+import torch_ref
+from tak_amd import dist as tdist
+rank, world, _ = tdist.env_rank()
+dist = tdist.init("gloo", rank, world)
+N, BLOCKS, FILTERS, G, PLIES = {cfg!r}
+KW = {kw!r}
+net = torch_ref.make_net(N, BLOCKS, FILTERS, "fc5", seed=2)
+e = tak_amd.Engine(N, res_blocks=BLOCKS, filters=FILTERS, evaluator=tak_amd.EVAL_RESNET, max_batch=64)
+e.load_state_dict(torch_ref.abi_tensors(net))
+# ---- self-play shard: no collective on the data path ----
+e.selfplay_create(G, slot_base=tdist.slot_base(rank, G), **KW)
+dist.barrier()
+e.selfplay_step(PLIES)
+st = e.selfplay_stats()
+hdr, states, moves, visits = e.selfplay_drain(1 << 13)
+_, total = tdist.reduce_time_and_count(dist, 1.0, st["expansions"])
+# ---- data-parallel training on the rank's own examples: Σ grads over ranks ÷ world → Adam, every `chunks_in_step` chunks ----
+count = 16
+k = (min(len(hdr), 64) // count) * count
+k = int(tdist.reduce_min(dist, k))          # the same number of whole chunks on every rank
+e.train_create(learning_rate=1e-3, weight_decay=1e-2, chunk_size=count, chunks_in_step=2)
+e.train_set_allreduce(tdist.host_allreduce_hook(dist), world)
+lp, lz, steps = e.train(states[:k], hdr["n_moves"][:k], moves[:k], visits[:k], hdr["result"][:k], seed=5)
+shapes = {{torch_ref.abi_name(n_): tuple(v.shape) for n_, v in net.named_parameters()}}
+params = {{n_: e.train_get_tensor(n_, s) for n_, s in shapes.items()}}
+e.train_commit()
+bn = e.train_get_tensor("bn0.running_mean", (FILTERS,))
+pe = e.policy_eval(states[:4])
+np.savez(os.path.join({out!r}, f"rank{{rank}}.npz"), hdr=hdr, states=states, moves=moves, visits=visits, total=total,
+         local=st["expansions"], k=k, steps=steps, lp=lp, bn=bn, pol=pe[0], ev=pe[1], **{{"p_" + n_: v for n_, v in params.items()}})
+e.close()
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_on_one_gpu_selfplay_and_training(orc):
+    import tak_amd
+
+    with tempfile.TemporaryDirectory() as tmp:
+        script = os.path.join(tmp, "worker.py")
+        open(script, "w").write(WORKER.format(root=ROOT, out=tmp, cfg=(N, BLOCKS, FILTERS, G, PLIES), kw=KW))
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs = [subprocess.Popen([sys.executable, script], env=dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0")) for r in range(2)]
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+        shards = [dict(np.load(os.path.join(tmp, f"rank{r}.npz"))) for r in range(2)]
+    # self-play: the union of the two ranks' examples = a single engine that owns all 2G slots
+    net = torch_ref.make_net(N, BLOCKS, FILTERS, "fc5", seed=2)
+    e = tak_amd.Engine(N, res_blocks=BLOCKS, filters=FILTERS, evaluator=tak_amd.EVAL_RESNET, max_batch=64)
+    e.load_state_dict(torch_ref.abi_tensors(net))
+    e.selfplay_create(2 * G, slot_base=0, **KW)
+    e.selfplay_step(PLIES)
+    single = _keyed(*e.selfplay_drain(1 << 13))
+    assert e.selfplay_stats()["expansions"] == int(shards[0]["total"]) == int(shards[0]["local"]) + int(shards[1]["local"])
+    e.close()
+    union = {}
+    for sh in shards:
+        assert len(sh["hdr"]) > 0
+        union.update(_keyed(sh["hdr"], sh["states"], sh["moves"], sh["visits"]))
+    assert union == single
+    # training: both ranks took the same number of steps and hold bit-identical parameters, BatchNorm statistics and outputs
+    assert int(shards[0]["steps"]) == int(shards[1]["steps"]) >= 1 and int(shards[0]["k"]) == int(shards[1]["k"])
+    for key in shards[0]:
+        if key.startswith("p_") or key in ("bn",):
+            assert np.array_equal(shards[0][key], shards[1][key]), key
+    assert float(shards[0]["lp"]) != float(shards[1]["lp"])  # … although they trained on different examples
+    changed = max(np.abs(shards[0]["p_" + torch_ref.abi_name(k)] - v.detach().numpy()).max() for k, v in net.named_parameters())
+    assert 0 < changed <= 1e-3 * int(shards[0]["steps"]) * 1.001

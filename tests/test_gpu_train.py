@@ -300,3 +300,110 @@ def test_training_from_an_example_file(orc, tmp_path):
         out.append((lp, lz, steps, e.train_get_tensor("value.weight", (1, filters * n * n))))
         e.close()
     assert out[0][:3] == out[1][:3] and out[0][2] == 3 and np.array_equal(out[0][3], out[1][3])
+
+
+def test_data_parallel_two_ranks_on_one_gpu(orc):
+    """Config C5's exchange on one card: two trainer engines (= two ranks, one thread each) whose optimiser steps sum their
+    flat gradient buffers through tg_train_set_allreduce (the hook RCCL's ncclAllReduce normally fills), divide by the world
+    size and apply Adam (network.rs:89-96 per rank).  Both ranks must end with bit-identical parameters; those must equal a
+    single engine that accumulated the same chunks and stepped on (Σ grads)/2, and a PyTorch step on the same; and
+    tg_train_commit must leave both with the average of their BatchNorm running statistics."""
+    import threading
+
+    import torch
+
+    import tak_amd
+
+    n, blocks, filters, head, count, K, steps = 5, 2, 32, "fc5", 12, 2, 2
+    lr, wd = 1e-3, 1e-2
+    net = torch_ref.make_net(n, blocks, filters, head, seed=8)
+    tensors = torch_ref.abi_tensors(net)
+    shapes = _shapes(net)
+    data = [[[_examples(orc, n, count, seed=500 + 100 * r + 10 * s + k) for k in range(K)] for s in range(steps)] for r in range(2)]
+    bn_names = [k for k in tensors if "running_" in k]
+    barrier = threading.Barrier(2)
+    mailbox = [None, None]
+    out = [dict(), dict()]
+    errors = []
+
+    def make_hook(rank):
+        def fn(d_buf, count_, stream):  # all-reduce(sum) between the two threads, through the host
+            mailbox[rank] = tak_amd.engine.device_to_host(d_buf, count_, stream)
+            barrier.wait(timeout=60)
+            total = mailbox[0] + mailbox[1]  # same operand order on both ranks → same bits
+            barrier.wait(timeout=60)
+            tak_amd.engine.host_to_device(d_buf, total)
+            return 0
+        return fn
+
+    def run(rank):
+        try:
+            e = _engine(n, blocks, filters, head)
+            e.load_state_dict(tensors)
+            e.train_create(learning_rate=lr, weight_decay=wd, chunk_size=count, chunks_in_step=K)
+            e.train_set_allreduce(make_hook(rank), 2)
+            for s in range(steps):
+                for k in range(K):
+                    _, _, stepped = e.train_chunk(*data[rank][s][k])
+                    assert stepped == (k == K - 1)  # the reduction ran inside the chunk that completed the step
+                out[rank][f"params{s}"] = {k_: e.train_get_tensor(k_, shapes[k_]) for k_ in shapes}
+            out[rank]["bn_before"] = {k_: e.train_get_tensor(k_, tensors[k_].shape) for k_ in bn_names}
+            e.train_commit()
+            out[rank]["bn_after"] = {k_: e.train_get_tensor(k_, tensors[k_].shape) for k_ in bn_names}
+            out[rank]["eval"] = e.policy_eval(data[0][0][0][0][:8])
+            e.close()
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    for s in range(steps):
+        for k_ in shapes:
+            assert np.array_equal(out[0][f"params{s}"][k_], out[1][f"params{s}"][k_]), (s, k_)
+    # the ranks normalised with different batches: their running statistics differ before the commit, and are the mean after
+    assert any(not np.array_equal(out[0]["bn_before"][k_], out[1]["bn_before"][k_]) for k_ in bn_names)
+    for k_ in bn_names:
+        want = (out[0]["bn_before"][k_] + out[1]["bn_before"][k_]) / np.float32(2)
+        assert np.array_equal(out[0]["bn_after"][k_], want) and np.array_equal(out[1]["bn_after"][k_], want), k_
+    assert np.array_equal(out[0]["eval"][0], out[1]["eval"][0]) and np.array_equal(out[0]["eval"][1], out[1]["eval"][1])
+
+    # one engine, the same chunks in rank order, one step per 2K chunks on (Σ grads) / 2 (identity "reduction", world 2)
+    c = _engine(n, blocks, filters, head)
+    c.load_state_dict(tensors)
+    c.train_create(learning_rate=lr, weight_decay=wd, chunk_size=count, chunks_in_step=2 * K)
+    c.train_set_allreduce(lambda d_buf, count_, stream: 0, 2)
+    opt = torch_ref.make_adam(net, lr=lr, wd=wd)
+    for s in range(steps):
+        opt.zero_grad()
+        for r in range(2):
+            for k in range(K):
+                c.train_chunk(*data[r][s][k])
+                if s == 0:
+                    planes, pi, z, _ = _targets(orc, n, head, data[r][s][k])
+                    torch_ref.train_chunk(net, planes, pi, z)
+        for k_ in shapes:
+            d = np.abs(c.train_get_tensor(k_, shapes[k_]) - out[0][f"params{s}"][k_])
+            # same sums up to the association of the adds; amplified only where g + wd·p cancels to the order of Adam's eps
+            assert d.max() <= 1.001 * lr * (s + 1), (s, k_, float(d.max()))
+            if not (k_.endswith(".bias") and "conv" in k_):  # (zero true gradient in front of a BatchNorm: Adam normalises noise)
+                # (elements whose g + wd·p cancels down to Adam's eps take a step of either sign — up to 2·lr apart, a few per
+                # thousand over two steps; everything else agrees to rounding)
+                assert np.median(d) <= 2e-7 * (s + 1), (s, k_, float(np.median(d)))
+                assert np.quantile(d, 0.99) <= 0.02 * lr * (s + 1), (s, k_, float(np.quantile(d, 0.99)))
+        if s == 0:
+            with torch.no_grad():
+                for p in net.parameters():
+                    p.grad.mul_(0.5)
+            opt.step()
+            for k, p in net.named_parameters():
+                k_ = torch_ref.abi_name(k)
+                d = np.abs(out[0]["params0"][k_] - p.detach().numpy())
+                assert d.max() <= 1.001 * lr, k_
+                if not (k_.endswith(".bias") and "conv" in k_):
+                    assert np.quantile(d, 0.999) <= 0.02 * lr, (k_, float(np.quantile(d, 0.999)))
+    c.close()

@@ -52,6 +52,11 @@ __device__ __forceinline__ void conv_mainloop(const f32x4* __restrict__ lds4, co
                                                  int LS4, int rows, int n, int rho0, int q, const int (&vmask)[NM],
                                                  f32x4 (&acc)[RTW]) {
     static_assert(NM >= RTW, "tap masks for every row tile");
+    // TG_PROBE (scripts/probes/tower_stamps.hip only): bit 0 = every tap reads its shifted row (no zero-row reads),
+    // bit 1 = no weight stream (w0 reused), bit 2 = no tap switch (offsets of tap 0 throughout).  Wrong results, same shape.
+#ifndef TG_PROBE
+#define TG_PROBE 0
+#endif
     constexpr int total = 9 * CH;
     constexpr int H1 = (RTW + 1) / 2;
     const int zero4 = rows * LS4 + q;
@@ -61,7 +66,7 @@ __device__ __forceinline__ void conv_mainloop(const f32x4* __restrict__ lds4, co
     {
         const int sh = tap_shift(0);
 #pragma unroll
-        for (int j = 0; j < RTW; j++) aoff[j] = (vmask[j] & 1) ? base0 + j * 16 * LS4 + sh : zero4;
+        for (int j = 0; j < RTW; j++) aoff[j] = ((vmask[j] & 1) || (TG_PROBE & 1)) ? base0 + j * 16 * LS4 + (sh < 0 && (TG_PROBE & 1) ? 0 : sh) : zero4;
     }
     f32x4 a[RTW];
 #pragma unroll
@@ -69,14 +74,20 @@ __device__ __forceinline__ void conv_mainloop(const f32x4* __restrict__ lds4, co
     f32x4 w0 = wp[0];
     f32x4 w1 = wp[wstride4];
     int kk = 0;
+#if defined(TG_UNROLL_TAPS) && TG_UNROLL_TAPS == 9
+#pragma unroll
+#elif defined(TG_UNROLL_TAPS) && TG_UNROLL_TAPS == 3
+#pragma unroll 3
+#else
 #pragma unroll 1
+#endif
     for (int tap = 0; tap < 9; tap++) {
 #pragma unroll
         for (int kc = 0; kc < CH; kc++) {
-            if (kc == 0 && tap > 0) {
-                const int sh = tap_shift(tap);
+            if (kc == 0 && tap > 0 && !(TG_PROBE & 4)) {
+                const int sh = (TG_PROBE & 1) ? (tap % 3) * LS4 : tap_shift(tap);
 #pragma unroll
-                for (int j = H1; j < RTW; j++) aoff[j] = ((vmask[j] >> tap) & 1) ? base0 + j * 16 * LS4 + sh : zero4;
+                for (int j = H1; j < RTW; j++) aoff[j] = (((vmask[j] >> tap) & 1) || (TG_PROBE & 1)) ? base0 + j * 16 * LS4 + sh : zero4;
             }
 #pragma unroll
             for (int j = H1; j < RTW; j++) a[j] = lds4[aoff[j] + kc * 4];
@@ -87,14 +98,15 @@ __device__ __forceinline__ void conv_mainloop(const f32x4* __restrict__ lds4, co
                 for (int j = 0; j < H1; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t], a[j][t], acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             const int k2 = kk + 2 < total ? kk + 2 : total - 1;
-            const f32x4 w2 = wp[(size_t)k2 * wstride4];
+            const f32x4 w2 = (TG_PROBE & 2) ? w0 : wp[(size_t)k2 * wstride4];
             if (kc + 1 < CH) {
 #pragma unroll
                 for (int j = 0; j < H1; j++) a[j] = lds4[aoff[j] + (kc + 1) * 4];
             } else if (tap + 1 < 9) {
-                const int sh = tap_shift(tap + 1);
+                const int sh = (TG_PROBE & 1) ? ((tap + 1) % 3) * LS4 : tap_shift(tap + 1);
 #pragma unroll
-                for (int j = 0; j < H1; j++) aoff[j] = ((vmask[j] >> (tap + 1)) & 1) ? base0 + j * 16 * LS4 + sh : zero4;
+                for (int j = 0; j < H1; j++)
+                    if (!(TG_PROBE & 4)) aoff[j] = (((vmask[j] >> (tap + 1)) & 1) || (TG_PROBE & 1)) ? base0 + j * 16 * LS4 + sh : zero4;
 #pragma unroll
                 for (int j = 0; j < H1; j++) a[j] = lds4[aoff[j]];
             }
@@ -109,6 +121,78 @@ __device__ __forceinline__ void conv_mainloop(const f32x4* __restrict__ lds4, co
             kk++;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same loop over the HALO image (k_tower_halo, layers ≥ 1).  Every board row is stored with one zero cell behind
+// it and every position with a zero row (+ 1 cell) behind it, so a tap is the same cell offset for every square of
+// every position — on or off the board — and an off-board neighbour is simply a zero cell:
+//     cell(p, y, x) = (NB + 2) + p·PS + y·(NB + 1) + x,   tap (dy, dx) → cell + dy·(NB + 1) + dx.
+// A lane therefore keeps ONE address per row tile for the whole layer and every (tap, chunk) is an immediate of
+// ds_read_b128: no per-tap address arithmetic, no validity masks, no select against a zero row (what cost the
+// masked loop 8 % of a layer: scripts/probes/tower_stamps.hip), and — with the squares dealt to tile slots by the
+// residue of their cell index (tower_halo_slotmap) — no bank conflicts either.  Row pitch = F + 4 floats
+// (4·CH + 1 slots of 16 B).  addr4[j] = (cell − (NB + 2))·pitch4 + q.  Fully unrolled: 9·CH steps.
+// Same products in the same order as conv_mainloop → identical bits.
+// ------------------------------------------------------------------------------------------------
+// `turn` (0 / 1, wave-uniform): the two waves that share a SIMD take turns at s_setprio 1, one chunk each.  Left alone the
+// arbiter prefers the older wave throughout: it finishes its tiles at ≈ 3/4 of the layer and the younger one runs the
+// last quarter alone, where nothing fills the gaps between its own MFMA groups (37 instead of 33 cycles per MFMA).
+template <int RTW, int CH, int NB, int NM>
+__device__ __forceinline__ void conv_mainloop_halo(const f32x4* __restrict__ lds4, const float* __restrict__ wlayer, uint32_t wlane,
+                                                   const int (&addr4)[NM], f32x4 (&acc)[RTW], const int turn) {
+    static_assert(NM >= RTW, "an address for every row tile");
+    constexpr int P4 = 4 * CH + 1, RS = NB + 1, total = 9 * CH;
+    constexpr int H1 = (RTW + 1) / 2;
+    constexpr size_t WCHUNK = (size_t)16 * CH * 4 * 16;  // bytes of one 16-k chunk of the layer's weights: [F][4 slots][16 B]
+#ifndef TG_PRIO_PERIOD
+#define TG_PRIO_PERIOD 2
+#endif
+#define TG_HALO_OFF(step) ((((step) / CH) / 3 * RS + ((step) / CH) % 3) * P4 + ((step) % CH) * 4)
+    // weights through a buffer descriptor of the layer: the chunk is the scalar offset (one s_movk per load), this lane's
+    // constant 16 B inside a chunk the vector offset — no vector address arithmetic in the loop
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wlayer, 0, (int)(9 * CH * WCHUNK), 0x00020000);
+#define TG_HALO_W(chunk) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, (int)((chunk) * WCHUNK), 0))
+    f32x4 a[RTW];
+#pragma unroll
+    for (int j = 0; j < H1; j++) a[j] = lds4[addr4[j] + TG_HALO_OFF(0)];
+    f32x4 w0 = TG_HALO_W(0);
+    f32x4 w1 = TG_HALO_W(1);
+#pragma unroll
+    for (int s = 0; s < total; s++) {
+#ifndef TG_NO_PRIO_TURNS
+        if (s % TG_PRIO_PERIOD == 0) {
+            if (((s / TG_PRIO_PERIOD) & 1) == turn) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
+#pragma unroll
+        for (int j = H1; j < RTW; j++) a[j] = lds4[addr4[j] + TG_HALO_OFF(s)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int j = 0; j < H1; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t], a[j][t], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 w2 = TG_HALO_W(s + 2 < total ? s + 2 : total - 1);
+        if (s + 1 < total) {
+#pragma unroll
+            for (int j = 0; j < H1; j++) a[j] = lds4[addr4[j] + TG_HALO_OFF(s + 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int j = H1; j < RTW; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t], a[j][t], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        w0 = w1;
+        w1 = w2;
+    }
+#ifndef TG_NO_PRIO_TURNS
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#undef TG_HALO_OFF
+#undef TG_HALO_W
 }
 
 }  // namespace tg

@@ -30,7 +30,13 @@ struct TowerParams {
     int nlayers;          // 1 + 2·R
     int cin_pad;          // channels of the input planes (layer 0)
     int F;                // channels of every later layer (= CoutP of every layer)
+    // halo image of the large-batch kernel (k_tower_halo): tile slot → cell | row << 16, position stride in cells
+    const uint32_t* slotmap;
+    int halo_pw, halo_ps;
 };
+// geometry of the halo image for a supported topology (positions per workgroup, position stride) and the slot table
+bool tower_halo_geometry(int n, int F, int* pw, int* ps);
+void tower_halo_slotmap(int n, int pw, int ps, uint32_t* out /* ceil(pw·n²/16)·16 entries */);
 bool tower_supported(int n, int F, int cin_pad);
 hipError_t launch_tower(hipStream_t st, const float* in, const TowerParams& T, float* out, int B, int n);
 hipError_t launch_tower_states(hipStream_t st, const uint8_t* states, const TowerParams& T, float* out, int B, int n);

@@ -34,6 +34,7 @@ struct Net {
     DevBuf x, y, logits, planes_nhwc, planes_nchw;
     bool fused = false;  // whole tower in one launch (k_tower)
     TowerParams tower;
+    DevBuf halo_map;                   // tile slot → square table of the halo tower (k_tower_halo)
     size_t logit_row = 0;              // floats per position in `logits`
     int precision = TG_PRECISION_F32;  // tg_net_set_precision
     bool s3 = false;                   // split-bf16 tower in use
@@ -287,6 +288,15 @@ int net_finalize(TgEngine* e) {
         for (int i = 0; i < R; i++) {
             T.w[1 + 2 * i] = n->res1[i].w.as<float>(); T.b[1 + 2 * i] = n->res1[i].b.as<float>();
             T.w[2 + 2 * i] = n->res2[i].w.as<float>(); T.b[2 + 2 * i] = n->res2[i].b.as<float>();
+        }
+        T.slotmap = nullptr; T.halo_pw = 0; T.halo_ps = 0;
+        int pw, ps;
+        if (tower_halo_geometry(e->g.n, F, &pw, &ps)) {
+            std::vector<uint32_t> map((size_t)((pw * nsq + 15) / 16) * 16);
+            tower_halo_slotmap(e->g.n, pw, ps, map.data());
+            TG_HIP(n->halo_map.ensure(map.size() * 4));
+            TG_HIP(hipMemcpy(n->halo_map.p, map.data(), map.size() * 4, hipMemcpyHostToDevice));
+            T.slotmap = n->halo_map.as<uint32_t>(); T.halo_pw = pw; T.halo_ps = ps;
         }
     }
     n->s3 = false;

@@ -16,6 +16,9 @@
 // and ReLU are fused into the accumulator epilogue.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <vector>
 
 #include "board.cuh"
 #include "conv_mainloop.cuh"
@@ -23,6 +26,19 @@
 #include "kernels.h"
 
 namespace tg {
+
+// Diagnostic build only (scripts/probes/tower_stamps.hip, -DTG_TOWER_STAMPS): s_memtime stamps of workgroup 0's waves at
+// the phase boundaries of every layer, written to a buffer nothing else reads.  The product build compiles none of it.
+#ifdef TG_TOWER_STAMPS
+__device__ unsigned long long* g_tower_stamps = nullptr;  // [layer][wave][8]
+#define TG_STAMP(layer, slot)                                                                                       \
+    do {                                                                                                            \
+        if (blockIdx.x == 0 && g_tower_stamps && (threadIdx.x & 63) == 0)                                           \
+            g_tower_stamps[((size_t)(layer) * 16 + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define TG_STAMP(layer, slot) do { } while (0)
+#endif
 
 
 // Workgroup = 4 waves as 2 (rows) × 2 (cols); each wave owns RT×CT tiles of 32×32.
@@ -330,7 +346,16 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
     }
     __syncthreads();
 
-    const int rho0 = rg * RTW * 16 + r16;
+    // Row tiles of a full workgroup are dealt to the NWAVES / CTW row groups as evenly as they go (25 = 13 + 12 with two
+    // groups, 7 + 6 + 6 + 6 with four): the first `rem` groups own RTW tiles, the others RTW - 1 and run the loop
+    // specialised for that count instead of issuing a whole tile of zero MFMAs (wave-uniform branch).  The waves of one
+    // channel tile (wave % CTW) land on one SIMD, so every SIMD carries all the row tiles whatever the split.
+    const int NRG = NWAVES / CTW;
+    const int ntiles = (PW * nsq + 15) >> 4;
+    const int tbase = ntiles / NRG, trem = ntiles - tbase * NRG;
+    const int my_tiles = tbase + (rg < trem ? 1 : 0);
+    const int rho0 = (rg * tbase + min(rg, trem)) * 16 + r16;
+    const bool short_group = my_tiles < RTW;
 
     // Skip connection without any storage of its own: after conv1 of a block every wave reads the block input X
     // of exactly the tiles it owns back from the LDS image (just before it overwrites them with conv1's output)
@@ -340,13 +365,12 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
     for (int j = 0; j < RTW; j++) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     int vmask[RTW];  // board geometry is the same for every layer
     conv_tap_masks<RTW>(rows, n, nsq, rho0, vmask);
+    if (short_group) vmask[RTW - 1] = 0;  // that tile belongs to the next row group
 
     for (int layer = 0; layer < T.nlayers; layer++) {
         const f32x4* wp = (const f32x4*)T.w[layer] + ((size_t)(ch0 + r16) * 4 + q);
-        // the last row group may own one tile less (25 = 13 + 12 on 5×5): it runs the loop specialised for
-        // RTW-1 tiles instead of issuing a whole tile of zero MFMAs (wave-uniform branch)
-        const bool short_group = (rg * RTW + RTW - 1) * 16 >= rows && RTW > 1;
-        if (short_group) {
+        TG_STAMP(layer, 0);
+        if (RTW > 1 && short_group) {
             f32x4 (&acs)[RTW - 1] = *reinterpret_cast<f32x4 (*)[RTW - 1]>(&acc[0]);
             if (layer == 0) conv_mainloop<RTW - 1, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acs);
             else conv_mainloop<RTW - 1, CH>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acs);
@@ -354,6 +378,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
             if (layer == 0) conv_mainloop<RTW, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acc);
             else conv_mainloop<RTW, CH>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acc);
         }
+        TG_STAMP(layer, 1);
         // ---- epilogue on the accumulators: lane holds out[row][ch0 + 4q .. 4q+3] ----
         const f32x4 bv = *(const f32x4*)&T.b[layer][ch0 + 4 * q];
 #pragma unroll
@@ -365,10 +390,12 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
         if (layer + 1 == T.nlayers) {
 #pragma unroll
             for (int j = 0; j < RTW; j++)
-                if (rho0 + j * 16 < rows) *(f32x4*)&out[((size_t)pos0 * nsq + rho0 + j * 16) * F + ch0 + 4 * q] = acc[j];
+                if (j < my_tiles && rho0 + j * 16 < rows) *(f32x4*)&out[((size_t)pos0 * nsq + rho0 + j * 16) * F + ch0 + 4 * q] = acc[j];
             break;
         }
+        TG_STAMP(layer, 2);
         __syncthreads();  // every wave has finished reading the previous image
+        TG_STAMP(layer, 3);
         const int LS4n = (F + LDS_PAD16) >> 2;
         const bool conv1 = (layer & 1) == 1;  // next layer is conv2 of the same block: it starts from the block input
         Cpad = F;
@@ -378,7 +405,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < RTW; j++) {
             f32x4 x0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (rho0 + j * 16 < rows) {
+            if (j < my_tiles && rho0 + j * 16 < rows) {
                 const int at = (rho0 + j * 16) * LS4 + (ch0 >> 2) + q;
                 if (conv1) x0 = lds4[at];
                 lds4[at] = acc[j];
@@ -387,7 +414,181 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
         }
         if (layer == 0)
             for (int idx = tid; idx < LS4; idx += NWAVES * 64) lds4[rows * LS4 + idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        TG_STAMP(layer, 4);
         __syncthreads();
+        TG_STAMP(layer, 5);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The fused tower for full batches: as k_tower, but from layer 1 on the resident image is the HALO image of
+// conv_mainloop.cuh (zero cells between board rows and between positions), so the 3×3 taps are immediates and the main
+// loop is nothing but ds_read_b128 / MFMA / one weight load per chunk.  Layer 0 (other pitch, once per launch) runs
+// the masked loop on the plain image and writes its output straight into halo cells.  From layer 1 on the squares
+// are dealt to (row tile, lane) slots by T.slotmap (tower_halo_slotmap): a permutation of the GEMM's M dimension,
+// invisible in the results, that keeps every ds_read_b128 of the loop off its neighbours' banks.
+// Per-element arithmetic (taps, chunks, k-steps, bias, ReLU, skip) in k_tower's order → identical bits.
+// ------------------------------------------------------------------------------------------------
+template <int RTW, int NWAVES, int CH0, int CH, int NB, bool FROM_STATES>
+__global__ __launch_bounds__(NWAVES * 64) void k_tower_halo(const float* __restrict__ in, TowerParams T, float* __restrict__ out,
+                                                            int B, int PW, int CTW) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    f32x4* lds4 = (f32x4*)lds;
+    constexpr int n = NB, nsq = NB * NB, RS = NB + 1, LEAD = NB + 2, F = 16 * CH, P4 = 4 * CH + 1;
+    const int PS = T.halo_ps;
+    const int tid = threadIdx.x;
+    const int pos0 = blockIdx.x * PW;
+    const int npos = min(PW, B - pos0);
+    const int rows = npos * nsq;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int ct = wave % CTW, rg = wave / CTW;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int ch0 = ct * 16;
+
+    // ---- stage the input planes: plain image, row pitch cin_pad + 8 floats, one zero row behind it ----
+    const int Cpad = T.cin_pad;
+    const int LS4 = (Cpad + LDS_PAD16) >> 2;
+    if (FROM_STATES) {
+        const Geom geo = make_geom(n);
+        const uint8_t* states = (const uint8_t*)in;
+        const int C = input_channels(n);
+        for (int p = wave; p < npos; p += NWAVES) {  // one wave encodes one position at a time, lane = square
+            WState ws;
+            ws_load(ws, states + (size_t)(pos0 + p) * geo.bytes, geo);
+            const float fcd = fcd_value(ws, geo);
+            const RowMask m = ws_row_mask(ws, geo);
+            if (lane < nsq) {
+                f32x4* row = lds4 + (size_t)(p * nsq + lane) * LS4;
+                for (int k = 0; k < (Cpad >> 2); k++) {
+                    float4 v = row_mask_value(m, k, C, fcd);
+                    row[k] = f32x4{v.x, v.y, v.z, v.w};
+                }
+            }
+        }
+    } else {
+        const int vpr = Cpad >> 2;
+        const f32x4* src = (const f32x4*)(in + (size_t)pos0 * nsq * Cpad);
+        const int total = rows * vpr;
+        for (int idx = tid; idx < total; idx += NWAVES * 64) {
+            int r = idx / vpr, v = idx - r * vpr;
+            lds4[r * LS4 + v] = src[idx];
+        }
+    }
+    for (int idx = tid; idx < LS4; idx += NWAVES * 64) lds4[rows * LS4 + idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    __syncthreads();
+
+    // row tiles dealt to the row groups as in k_tower
+    const int NRG = NWAVES / CTW;
+    const int ntiles = (PW * nsq + 15) >> 4;
+    const int tbase = ntiles / NRG, trem = ntiles - tbase * NRG;
+    const int my_tiles = tbase + (rg < trem ? 1 : 0);
+    const int tile0 = rg * tbase + min(rg, trem);
+    const bool short_group = my_tiles < RTW;
+
+    f32x4 acc[RTW];
+#pragma unroll
+    for (int j = 0; j < RTW; j++) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // ---- layer 0 on the plain image: tile t = rows 16t … 16t + 15 ----
+    {
+        const int rho0 = tile0 * 16 + r16;
+        int vmask[RTW];
+        conv_tap_masks<RTW>(rows, n, nsq, rho0, vmask);
+        if (short_group) vmask[RTW - 1] = 0;
+        const f32x4* wp = (const f32x4*)T.w[0] + ((size_t)(ch0 + r16) * 4 + q);
+        TG_STAMP(0, 0);
+        if (RTW > 1 && short_group) {
+            f32x4 (&acs)[RTW - 1] = *reinterpret_cast<f32x4 (*)[RTW - 1]>(&acc[0]);
+            conv_mainloop<RTW - 1, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acs);
+        } else {
+            conv_mainloop<RTW, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acc);
+        }
+        TG_STAMP(0, 1);
+        const f32x4 bv = *(const f32x4*)&T.b[0][ch0 + 4 * q];
+#pragma unroll
+        for (int j = 0; j < RTW; j++) {
+            f32x4 v = acc[j] + bv;
+            v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f);
+            acc[j] = v;
+        }
+        TG_STAMP(0, 2);
+        __syncthreads();  // every wave has finished reading the input planes
+        TG_STAMP(0, 3);
+        // the halo image replaces them: zero cells first (they are never written again), then this layer's output
+        const int cells = LEAD + PW * PS;
+        for (int idx = tid; idx < cells * P4; idx += NWAVES * 64) {
+            const int c = idx / P4 - LEAD;
+            const int o = c < 0 ? n * RS : c % PS;  // offset inside the position block; rows of RS cells, then the zero row
+            if (o >= n * RS || o % RS == n) lds4[idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int j = 0; j < RTW; j++) {
+            const int rho = rho0 + j * 16;
+            if (j < my_tiles && rho < PW * nsq) {
+                const int p = rho / nsq, sq = rho - p * nsq, y = sq / n, x = sq - y * n;
+                lds4[(LEAD + p * PS + y * RS + x) * P4 + (ch0 >> 2) + q] = acc[j];
+            }
+            acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        TG_STAMP(0, 4);
+        __syncthreads();
+        TG_STAMP(0, 5);
+    }
+
+    // ---- layers 1 … : slot (tile, lane) → square through the slot table ----
+    int cell4[RTW], rowid[RTW], addr4[RTW];
+#pragma unroll
+    for (int j = 0; j < RTW; j++) {
+        const uint32_t e = j < my_tiles ? T.slotmap[(tile0 + j) * 16 + r16] : 0xFFFF0000u;
+        rowid[j] = (int)(e >> 16);                                      // 0xFFFF: slot without a square
+        const int cell = rowid[j] == 0xFFFF ? LEAD + n * RS : (int)(e & 0xFFFFu);  // (such a slot reads around a zero cell)
+        cell4[j] = cell * P4 + (ch0 >> 2) + q;                          // where this lane's 4 output channels of the square live
+        addr4[j] = (cell - LEAD) * P4 + q;                              // B-operand base: tap (-1,-1), chunk 0
+    }
+    const int turn = (wave >> 2) & 1;  // waves w and w + 4 share a SIMD
+    const uint32_t wlane = (uint32_t)(((ch0 + r16) * 4 + q) * 16);  // this lane's 16 B inside a chunk of weights
+    for (int layer = 1; layer < T.nlayers; layer++) {
+        // the addresses are the same in every layer, but the compiler must not know: it would hoist all 9·RTW
+        // (address + tap offset) sums out of the layer loop and spill them instead of using ds_read immediates
+#pragma unroll
+        for (int j = 0; j < RTW; j++) asm volatile("" : "+v"(addr4[j]));
+        TG_STAMP(layer, 0);
+        if (RTW > 1 && short_group) {
+            f32x4 (&acs)[RTW - 1] = *reinterpret_cast<f32x4 (*)[RTW - 1]>(&acc[0]);
+            conv_mainloop_halo<RTW - 1, CH, NB>(lds4, T.w[layer], wlane, addr4, acs, turn);
+        } else {
+            conv_mainloop_halo<RTW, CH, NB>(lds4, T.w[layer], wlane, addr4, acc, turn);
+        }
+        TG_STAMP(layer, 1);
+        const f32x4 bv = *(const f32x4*)&T.b[layer][ch0 + 4 * q];
+#pragma unroll
+        for (int j = 0; j < RTW; j++) {
+            f32x4 v = acc[j] + bv;
+            v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f);
+            acc[j] = v;
+        }
+        if (layer + 1 == T.nlayers) {
+#pragma unroll
+            for (int j = 0; j < RTW; j++)
+                if (rowid[j] < rows) *(f32x4*)&out[((size_t)pos0 * nsq + rowid[j]) * F + ch0 + 4 * q] = acc[j];
+            break;
+        }
+        TG_STAMP(layer, 2);
+        __syncthreads();  // every wave has finished reading the previous image
+        TG_STAMP(layer, 3);
+        const bool conv1 = (layer & 1) == 1;  // next layer is conv2 of the same block: it starts from the block input
+#pragma unroll
+        for (int j = 0; j < RTW; j++) {
+            f32x4 x0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (rowid[j] != 0xFFFF) {
+                if (conv1) x0 = lds4[cell4[j]];
+                lds4[cell4[j]] = acc[j];
+            }
+            acc[j] = x0;
+        }
+        TG_STAMP(layer, 4);
+        __syncthreads();
+        TG_STAMP(layer, 5);
     }
 }
 
@@ -851,6 +1052,80 @@ static hipError_t launch_tower_t(hipStream_t st, const float* in, const TowerPar
     return hipGetLastError();
 }
 
+
+// ---- halo image (k_tower_halo): geometry and the square → tile-slot table -------------------------
+bool tower_halo_geometry(int n, int F, int* pw, int* ps) {
+    // position strides found by simulating the ds_read_b128 bank groups over all tiles / taps (conflict factor ≤ 1.11)
+    if (n == 5 && F == 64) { *pw = 16; *ps = 36; return true; }   // 158 576 B of LDS
+    if (n == 5 && F == 128) { *pw = 8; *ps = 37; return true; }   // 159 984 B
+    if (n == 6 && F == 128) { *pw = 4; *ps = 51; return true; }   // 111 936 B
+    return false;
+}
+
+void tower_halo_slotmap(int n, int pw, int ps, uint32_t* out) {
+    // ds_read_b128 serves lanes {0-3, 12-15} of one 16-byte slot q together with lanes {4-11} of slot q + 1 (and vice
+    // versa).  With a pitch of F + 4 floats the bank quad of a read is (cell + q + 4·chunk) mod 16, so a tile whose 8
+    // "outer" lanes and 8 "inner" lanes each hold 8 cells with distinct residues of ONE parity is conflict free for every
+    // tap and chunk (a tap shifts all cells alike).  Greedy: per tile take one square per residue of the richer parity.
+    const int nsq = n * n, RS = n + 1, LEAD = n + 2, rows = pw * nsq, tiles = (rows + 15) / 16;
+    std::vector<std::vector<int>> bucket(16);
+    std::vector<int> cell(rows);
+    for (int r = rows - 1; r >= 0; r--) {
+        const int p = r / nsq, sq = r % nsq;
+        cell[r] = LEAD + p * ps + (sq / n) * RS + sq % n;
+        bucket[cell[r] % 16].push_back(r);
+    }
+    static const int outer[8] = {0, 1, 2, 3, 12, 13, 14, 15}, inner[8] = {4, 5, 6, 7, 8, 9, 10, 11};
+    for (int t = 0; t < tiles; t++) {
+        size_t left[2] = {0, 0};
+        for (int r = 0; r < 16; r++) left[r & 1] += bucket[r].size();
+        const int par = left[0] >= left[1] ? 0 : 1;
+        for (const int* slots : {outer, inner}) {
+            int missing[8], nm = 0;
+            for (int k = 0; k < 8; k++) {
+                std::vector<int>& b = bucket[2 * k + par];
+                if (!b.empty()) { out[t * 16 + slots[k]] = (uint32_t)cell[b.back()] | ((uint32_t)b.back() << 16); b.pop_back(); }
+                else missing[nm++] = slots[k];
+            }
+            for (int m = 0; m < nm; m++) {
+                int big = 0;
+                for (int r = 1; r < 16; r++) if (bucket[r].size() > bucket[big].size()) big = r;
+                if (!bucket[big].empty()) {
+                    out[t * 16 + missing[m]] = (uint32_t)cell[bucket[big].back()] | ((uint32_t)bucket[big].back() << 16);
+                    bucket[big].pop_back();
+                } else out[t * 16 + missing[m]] = 0xFFFF0000u;  // no square left: the slot idles
+            }
+        }
+    }
+}
+
+template <int RTW, int NWAVES, int CH0, int CH, int NB, bool FROM_STATES>
+static hipError_t launch_tower_halo_t(hipStream_t st, const float* in, const TowerParams& T, float* out, int B, int CTW) {
+    const int PW = T.halo_pw;
+    const size_t plain = (size_t)(PW * NB * NB + 1) * (T.cin_pad + LDS_PAD16) * sizeof(float);
+    const size_t halo = (size_t)(NB + 2 + PW * T.halo_ps) * (16 * CH + 4) * sizeof(float);
+    const size_t lds = plain > halo ? plain : halo;
+    static size_t configured = 0;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_tower_halo<RTW, NWAVES, CH0, CH, NB, FROM_STATES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    hipLaunchKernelGGL((k_tower_halo<RTW, NWAVES, CH0, CH, NB, FROM_STATES>), dim3((B + PW - 1) / PW), dim3(NWAVES * 64), lds, st, in, T, out, B, PW, CTW);
+    return hipGetLastError();
+}
+
+// full batches of the three BASELINE topologies run on the halo image (identical bits, see k_tower_halo)
+template <bool FROM_STATES>
+static bool launch_tower_halo(hipStream_t st, const float* in, const TowerParams& T, float* out, int B, int n, hipError_t* err) {
+    static const bool off = getenv("TG_NO_HALO_TOWER") != nullptr;
+    if (off || !T.slotmap) return false;
+    if (n == 5 && T.F == 64 && T.cin_pad == 80 && B > 2048) { *err = launch_tower_halo_t<13, 8, 5, 4, 5, FROM_STATES>(st, in, T, out, B, 4); return true; }
+    if (n == 6 && T.F == 128 && T.cin_pad == 96 && B > 512) { *err = launch_tower_halo_t<9, 8, 6, 8, 6, FROM_STATES>(st, in, T, out, B, 8); return true; }
+    if (n == 5 && T.F == 128 && T.cin_pad == 80 && B > 1024) { *err = launch_tower_halo_t<13, 8, 5, 8, 5, FROM_STATES>(st, in, T, out, B, 8); return true; }
+    return false;
+}
+
 bool tower_supported(int n, int F, int cin_pad) {
     if (n == 5 && F == 64 && cin_pad == 80) return true;   // config C2
     if (n == 6 && F == 128 && cin_pad == 96) return true;  // config C3
@@ -859,6 +1134,10 @@ bool tower_supported(int n, int F, int cin_pad) {
 }
 
 hipError_t launch_tower(hipStream_t st, const float* in, const TowerParams& T, float* out, int B, int n) {
+    {
+        hipError_t herr;
+        if (launch_tower_halo<false>(st, in, T, out, B, n, &herr)) return herr;
+    }
     // A workgroup's run time is that of its positions' row tiles, whatever the batch: with 16 positions per workgroup a
     // 32-position call (the reference's BATCH_SIZE) ran 2 workgroups for as long as 4096 positions take.  Small batches
     // therefore use instantiations with fewer positions (row tiles) per workgroup; the per-element arithmetic — taps,
@@ -887,12 +1166,19 @@ hipError_t launch_tower(hipStream_t st, const float* in, const TowerParams& T, f
 // same, with the input planes encoded in-kernel from packed game states
 hipError_t launch_tower_states(hipStream_t st, const uint8_t* states, const TowerParams& T, float* out, int B, int n) {
     const float* in = (const float*)states;
+    {
+        hipError_t herr;
+        if (launch_tower_halo<true>(st, in, T, out, B, n, &herr)) return herr;
+    }
     if (n == 5 && T.F == 64 && T.cin_pad == 80) {
         // fewer positions per workgroup for small batches (see tower_small_batch below): identical bits, shorter critical path
         if (B <= 256) return launch_tower_t<2, 4, 5, 4, true>(st, in, T, out, B, n, 1, 4);
         if (B <= 512) return launch_tower_t<4, 4, 5, 4, true>(st, in, T, out, B, n, 2, 4);
         if (B <= 1024) return launch_tower_t<7, 4, 5, 4, true>(st, in, T, out, B, n, 4, 4);
         if (B <= 2048) return launch_tower_t<13, 4, 5, 4, true>(st, in, T, out, B, n, 8, 4);
+        static const int variant = getenv("TG_TOWER_VARIANT") ? atoi(getenv("TG_TOWER_VARIANT")) : 0;
+        if (variant == 16) return launch_tower_t<7, 16, 5, 4, true>(st, in, T, out, B, n, 16, 4);
+        if (variant == 4) return launch_tower_t<25, 4, 5, 4, true>(st, in, T, out, B, n, 16, 4);
         return launch_tower_t<13, 8, 5, 4, true>(st, in, T, out, B, n, 16, 4);
     }
     if (n == 6 && T.F == 128 && T.cin_pad == 96) {

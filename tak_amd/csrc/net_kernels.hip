@@ -759,6 +759,7 @@ __global__ __launch_bounds__(512) void k_fc_lds(const float* __restrict__ A, int
     }
 }
 
+
 // The same FC for SMALL batches (host-driven MCTS evaluates 16–32 leaves per call; Player, pit): k_fc_lds gives a row block
 // of 128 positions to one workgroup and needs ≥ 4096 rows to fill the chip, so a 32-row call took as long as a 4096-row
 // one.  Here a wave owns one 16-row tile × 2 output tiles and streams both operands straight from global (no LDS, no

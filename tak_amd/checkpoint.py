@@ -33,9 +33,13 @@ _LEAVES = {"conv": ("weight", "bias"), "linear": ("weight", "bias"), "head": ("w
            "bn": ("weight", "bias", "running_mean", "running_var")}
 
 
-def tch_names(res_blocks, conv_order=("bias", "weight"), bn_order=("weight", "bias", "running_mean", "running_var")):
-    """[(abi_name, tch_variable_name)] for a network of `res_blocks` blocks, emitting the intra-layer creation order given
-    (default: what tch 0.7's nn::conv2d / nn::linear / nn::batch_norm2d are believed to do)."""
+def tch_names(res_blocks, conv_order=("bias", "weight"), bn_order=("running_mean", "running_var", "weight", "bias")):
+    """[(abi_name, tch_variable_name)] for a network of `res_blocks` blocks, emitting the intra-layer creation order given.
+    Default = tch 0.7's constructors as recalled from its source (not vendored in the reference, so unconfirmed here):
+    nn::conv2d / nn::linear create `bias` then `weight`; nn::batch_norm2d creates `running_mean`, `running_var`, then
+    `weight`, `bias`.  The suffix is the creation index, so with this order the first BatchNorm of a network is
+    running_mean, running_var, weight__4, bias__5 — the names VarStore::load of the reference binary looks up.  The READER
+    below does not depend on this choice; the WRITER does, and tests/test_checkpoint.py pins the exact list."""
     names, taken, out = [], set(), []
     for kind, prefix in _layers(res_blocks):
         for leaf in (bn_order if kind == "bn" else conv_order):

@@ -17,8 +17,18 @@ def test_round_trip_and_order_robustness(tmp_path, n, blocks, filters, head):
     net = torch_ref.make_net(n, blocks, filters, head, seed=2)
     tensors = torch_ref.abi_tensors(net)
     names = checkpoint.tch_names(blocks)
-    assert [a for a, _ in names][:6] == ["conv0.bias", "conv0.weight", "bn0.weight", "bn0.bias", "bn0.running_mean", "bn0.running_var"]
-    assert [t for _, t in names][:6] == ["bias", "weight", "weight__2", "bias__3", "running_mean", "running_var"]
+    # the writer's names, pinned: tch's suffix is the creation index; conv / linear create bias then weight, batch_norm2d its
+    # running statistics first (tch 0.7) — the names the reference's VarStore::load looks up
+    assert names[:16] == [
+        ("conv0.bias", "bias"), ("conv0.weight", "weight"),
+        ("bn0.running_mean", "running_mean"), ("bn0.running_var", "running_var"), ("bn0.weight", "weight__4"), ("bn0.bias", "bias__5"),
+        ("res0.conv1.bias", "bias__6"), ("res0.conv1.weight", "weight__7"), ("res0.conv2.bias", "bias__8"), ("res0.conv2.weight", "weight__9"),
+        ("res0.bn1.running_mean", "running_mean__10"), ("res0.bn1.running_var", "running_var__11"),
+        ("res0.bn1.weight", "weight__12"), ("res0.bn1.bias", "bias__13"),
+        ("res0.bn2.running_mean", "running_mean__14"), ("res0.bn2.running_var", "running_var__15"),
+    ]
+    assert names[-4:] == [("policy.bias", f"bias__{len(names) - 4}"), ("policy.weight", f"weight__{len(names) - 3}"),
+                          ("value.bias", f"bias__{len(names) - 2}"), ("value.weight", f"weight__{len(names) - 1}")]
     assert len(names) == len(tensors)
     bn_orders = [("weight", "bias", "running_mean", "running_var"), ("running_mean", "running_var", "weight", "bias"),
                  ("bias", "running_var", "weight", "running_mean")]
@@ -31,7 +41,8 @@ def test_round_trip_and_order_robustness(tmp_path, n, blocks, filters, head):
             import torch
 
             params = dict(torch.jit.load(path).named_parameters())
-            assert set(params) == {t for _, t in names} and not any(p.requires_grad for p in params.values())
+            want = {t for _, t in checkpoint.tch_names(blocks, conv_order=conv_order, bn_order=bn_order)}
+            assert set(params) == want and not any(p.requires_grad for p in params.values())
         for k in tensors:
             assert back[k].shape == tensors[k].shape and np.array_equal(back[k], tensors[k]), (k, conv_order, bn_order)
 

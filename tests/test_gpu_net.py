@@ -207,3 +207,32 @@ def test_result_does_not_depend_on_the_batch_size(orc, n, blocks, filters, head,
         p, v = e.policy_eval(sts[:k])
         assert np.array_equal(p, p_ref[:k]) and np.array_equal(v, v_ref[:k]), k
     e.close()
+
+
+@pytest.mark.parametrize("n,blocks,filters,head", [(5, 2, 32, "fc5"), (6, 2, 32, "conv")])
+def test_checkpoint_archive_loads_into_the_engine(orc, tmp_path, n, blocks, filters, head):
+    """N4: a tch VarStore archive (Network::save, net5.rs:95-104) written by tak_amd.checkpoint → read back → tg_net_set_tensor →
+    tg_policy_eval: the same outputs as the engine fed the source tensors directly, and as PyTorch on them; and
+    tg_net_get_tensor returns what was loaded (what Network::save would write).  Still not a file written by tch itself."""
+    import tak_amd
+    from tak_amd import checkpoint
+
+    net = torch_ref.make_net(n, blocks, filters, head, seed=21)
+    tensors = torch_ref.abi_tensors(net)
+    path = str(tmp_path / "net.model")
+    checkpoint.save_tch_varstore(path, tensors, blocks)
+    loaded = checkpoint.load_tch_varstore(path, blocks)
+    sts = orc.random_positions(n, 96, seed=5, max_plies=40, half_komi=4)
+    outs = []
+    for src in (tensors, loaded):
+        e = tak_amd.Engine(n, res_blocks=blocks, filters=filters, policy_head=tak_amd.HEAD_FC5 if head == "fc5" else tak_amd.HEAD_CONV,
+                           evaluator=tak_amd.EVAL_RESNET, max_batch=128)
+        e.load_state_dict(src)
+        outs.append(e.policy_eval(sts))
+        if src is loaded:
+            for k, v in tensors.items():
+                assert np.array_equal(e.get_tensor(k, v.shape), v), k
+        e.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    p_ref, v_ref = torch_ref.forward(net, orc.encode(n, sts))
+    assert np.abs(outs[1][0] - p_ref).max() <= 1e-4 and np.abs(outs[1][1] - v_ref).max() <= 1e-4

@@ -39,10 +39,11 @@ def make_weights(n, blocks, filters, head, seed=0):
     return net, torch_ref.abi_tensors(net)
 
 
-def cpu_baseline(args, net, seconds_budget=20.0):
-    """The CPU port (oracle/: scalar MCTS + AoS rules, PyTorch-CPU fp32 network) on the host cores, on a
-    bounded sample of the same workload: `cpu_games` of the 4096 games, one full ply (1 + rollouts
-    lock-step iterations)."""
+def cpu_baseline(args, net, seconds_budget=22.0, dummy_budget=8.0):
+    """The CPU port (oracle/: scalar MCTS + AoS rules, PyTorch-CPU fp32 network) on the host cores, on a bounded sample of
+    the same workload: `cpu_games` of the 4096 games, as many whole plies (1 + rollouts lock-step iterations each) as fit
+    in ≈ `seconds_budget`.  `value` excludes the first ply (cold caches, empty trees).  A second, shorter sample with the
+    reference's DummyNet (alpha-tak/src/search/tests.rs:29-34: uniform policy, eval 0) times board + MCTS alone."""
     import torch
 
     import torch_ref
@@ -53,33 +54,43 @@ def cpu_baseline(args, net, seconds_budget=20.0):
     # the GPU box gives one GPU's worth of host cores (16); PyTorch's default of one thread per visible core
     # (128+) oversubscribes them on these small convolutions
     torch.set_num_threads(min(args.cpu_threads, os.cpu_count() or 1))
+    threads = int(torch.get_num_threads())
 
     def py_eval(states):
         return torch_ref.forward(net, orc.encode(n, states))
 
-    sp = orc.SelfPlay(n, args.cpu_games, head=head, py_eval=py_eval, seed=args.seed, rollouts=args.rollouts)
-    sp.set_threads(torch.get_num_threads())  # the per-game MCTS phases under OpenMP, the network under PyTorch's pool
-    t0 = time.perf_counter()
-    plies = 0
-    while True:
-        sp.step(1)
-        plies += 1
-        dt = time.perf_counter() - t0
-        if dt > seconds_budget or plies >= 2:
-            break
-    st = sp.stats()
+    def sample(sp, budget, max_plies):
+        sp.set_threads(threads)  # the per-game MCTS phases under OpenMP, the network under PyTorch's pool
+        marks = [(0.0, 0)]
+        t0 = time.perf_counter()
+        while True:
+            sp.step(1)
+            marks.append((time.perf_counter() - t0, sp.stats()["expansions"]))
+            per_ply = marks[-1][0] / (len(marks) - 1)
+            if marks[-1][0] + per_ply > budget or len(marks) - 1 >= max_plies:
+                return marks
+
+    marks = sample(orc.SelfPlay(n, args.cpu_games, head=head, py_eval=py_eval, seed=args.seed, rollouts=args.rollouts), seconds_budget, 64)
+    (t1, e1), (tn, en) = marks[1], marks[-1]
+    steady = (en - e1) / (tn - t1) if len(marks) > 2 else en / tn
+    dummy = sample(orc.SelfPlay(n, args.games, head=head, evaluator=orc.EVAL_DUMMY, seed=args.seed, rollouts=args.rollouts), dummy_budget, 16)
     return {
-        "value": st["expansions"] / dt,
+        "value": steady,
         "unit": "node-expansions/s",
-        "cores": int(torch.get_num_threads()),
+        "cores": threads,
         "kind": "port",
-        "sample": f"{args.cpu_games} of the {args.games} games, {plies} ply(ies) = {st['expansions']} expansions "
-                  f"in {dt:.1f} s; oracle scalar MCTS (OpenMP over games, {torch.get_num_threads()} threads) + PyTorch-CPU fp32 {args.blocks}x{args.filters} net "
-                  f"({torch.get_num_threads()} threads)",
+        "sample": f"{args.cpu_games} of the {args.games} games, {len(marks) - 1} plies = {en} expansions in {tn:.1f} s ({en / tn:.0f}/s with the cold "
+                  f"first ply, `value` without it); oracle scalar MCTS (OpenMP over games, {threads} threads) + PyTorch-CPU fp32 "
+                  f"{args.blocks}x{args.filters} net ({threads} threads)",
+        "board_and_mcts_only": {
+            "value": dummy[-1][1] / dummy[-1][0], "unit": "node-expansions/s", "cores": threads,
+            "sample": f"all {args.games} games, {len(dummy) - 1} ply(ies) = {dummy[-1][1]} expansions in {dummy[-1][0]:.1f} s with the reference's DummyNet "
+                      f"(uniform policy, eval 0): rules + tree work alone, no network",
+        },
     }
 
 
-def measured_deviation(args, tensors, device, count=512):
+def measured_deviation(args, tensors, device, count=4096, max_ply=150):
     """max deviation of the split-bf16 forward from the exact-f32 forward on `count` positions reached by random play through the
     engine's own rules kernels (no checker involved) — the figure `alt_precision` quotes"""
     import tak_amd
@@ -101,18 +112,21 @@ def measured_deviation(args, tensors, device, count=512):
             st[:, hdr + 4], st[:, hdr + 5], st[:, hdr + 6], st[:, hdr + 7] = stones, caps, stones, caps
             st[:, hdr + 8] = 4
             rng = np.random.default_rng(args.seed)
-            for ply in range(24):  # positions at plies 0..23, a different depth per position
+            target = np.arange(count) % (max_ply + 1)  # position i stops at ply ≈ i mod 151 (earlier if its game ends)
+            for ply in range(max_ply):
                 moves, counts = e.movegen(st)
                 pick = (rng.random(count) * np.maximum(counts, 1)).astype(np.int64)
                 nxt, status = e.play(st, moves[np.arange(count), pick])
                 res = e.result(nxt)
-                go = (np.arange(count) % 24 > ply) & (status == 0) & (res == 0) & (counts > 0)
+                go = (target > ply) & (status == 0) & (res == 0) & (counts > 0)
                 st[go] = nxt[go]
+            plies = st[:, hdr + 2].astype(np.int32) | (st[:, hdr + 3].astype(np.int32) << 8)
         out.append(e.policy_eval(st))
         e.close()
     (p0, v0), (p1, v1) = out
     return {"policy_rel": float((np.abs(p1 - p0) / p0).max()), "policy_abs": float(np.abs(p1 - p0).max()),
-            "eval_abs": float(np.abs(v1 - v0).max()), "gate": 1e-4, "positions": count}
+            "eval_abs": float(np.abs(v1 - v0).max()), "gate": 1e-4, "positions": count,
+            "plies": {"min": int(plies.min()), "median": int(np.median(plies)), "max": int(plies.max())}}
 
 
 def tak_amd_supports_bf16x3(args):
@@ -131,7 +145,9 @@ def main():
     ap.add_argument("--filters", type=int, default=64)
     ap.add_argument("--head", default="fc5", choices=["fc5", "conv"])
     ap.add_argument("--arena", type=int, default=0,
-                    help="MCTS nodes per game arena; 0 = 2^17 for runs of up to 120 plies, 2^19 beyond (retained subtrees grow with the ply, DESIGN.md)")
+                    help="average MCTS node budget per game (all trees share one pool); 0 = sized by the engine from the free device memory")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra lines of the JSON (config C3, 16 384 games, the 120-ply sustained run)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-games", type=int, default=256)
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -166,8 +182,6 @@ def main():
 
     net, tensors = make_weights(args.board, args.blocks, args.filters, args.head, seed=args.seed)
     steps_total = args.steps + args.warmup
-    if args.arena <= 0:
-        args.arena = 1 << 17 if steps_total <= 120 else 1 << 19
 
     def barrier(eng):
         eng.sync()
@@ -175,25 +189,34 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def run(precision, profile_every):
-        """W untimed + K timed plies of self-play on a fresh engine → (seconds, expansions, evals, profile)"""
-        eng = tak_amd.Engine(args.board, res_blocks=args.blocks, filters=args.filters,
-                             policy_head=tak_amd.HEAD_FC5 if args.head == "fc5" else tak_amd.HEAD_CONV,
-                             evaluator=tak_amd.EVAL_RESNET, max_batch=args.games, device=local_rank)
+    def run(precision, profile_every, cfg=None, steps=None, warmup=None, drain_every=0):
+        """W untimed + K timed plies of self-play on a fresh engine → (seconds, expansions, evals, profile).  cfg =
+        (board, blocks, filters, head, games, weights) overrides the command line (the extra lines); drain_every > 0
+        fetches the finished examples every so many plies inside the timed region, as a training loop would."""
+        board, blocks, filters, head, games, weights = cfg or (args.board, args.blocks, args.filters, args.head, args.games, tensors)
+        steps = args.steps if steps is None else steps
+        warmup = args.warmup if warmup is None else warmup
+        eng = tak_amd.Engine(board, res_blocks=blocks, filters=filters,
+                             policy_head=tak_amd.HEAD_FC5 if head == "fc5" else tak_amd.HEAD_CONV,
+                             evaluator=tak_amd.EVAL_RESNET, max_batch=games, device=local_rank)
         if precision != "f32":
             eng.set_precision(precision)
-        eng.load_state_dict(tensors)
-        eng.selfplay_create(args.games, arena_nodes=args.arena, seed=args.seed, rollouts=args.rollouts,
-                            max_examples=max(1 << 14, args.games * (steps_total + 2)), slot_base=tdist.slot_base(rank, args.games))
-        for _ in range(args.warmup):
+        eng.load_state_dict(weights)
+        ring = games * (min(steps + warmup, drain_every + 8 if drain_every else steps + warmup) + 2)
+        eng.selfplay_create(games, arena_nodes=args.arena, seed=args.seed, rollouts=args.rollouts,
+                            max_examples=max(1 << 14, ring), slot_base=tdist.slot_base(rank, games))
+        for _ in range(warmup):
             eng.selfplay_step(1)
         barrier(eng)
         s0 = eng.selfplay_stats()
         if profile_every:
             eng.profile_enable(profile_every)
+        drained = 0
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for k in range(steps):
             eng.selfplay_step(1)
+            if drain_every and (k + 1) % drain_every == 0:
+                drained += len(eng.selfplay_drain(games * (drain_every + 2))[0])
         eng.sync()
         torch.cuda.synchronize()
         dt_local = time.perf_counter() - t0
@@ -204,6 +227,7 @@ def main():
             eng.profile_enable(0)
         s1 = eng.selfplay_stats()
         eng.close()
+        run.last = {"games_finished": s1["games_finished"], "examples": s1["examples"], "drained": drained, "dropped_examples": s1["dropped_examples"]}
         return dt_local, s1["expansions"] - s0["expansions"], s1["evals"] - s0["evals"], prof
 
     dt_local, expansions, evals, prof = run(args.precision, args.profile_every)
@@ -242,7 +266,7 @@ def main():
                 except Exception:
                     traffic = None
             if args.precision == "f32":
-                kernel, peak = "k_tower (fused conv0 + residual tower, f32 MFMA 16x16x4; one launch = 1+2R 3x3 convs)", F32_MFMA_PEAK_TFLOPS
+                kernel, peak = "k_tower_halo (fused conv0 + residual tower on a halo LDS image, f32 MFMA 16x16x4; one launch = 1+2R 3x3 convs)", F32_MFMA_PEAK_TFLOPS
             else:  # three bf16 MFMA passes per algorithmic product: the ceiling for algorithmic FLOPs is a third of the bf16 peak
                 kernel, peak = "k_tower_s3 (fused tower, 3 x bf16 MFMA 16x16x32 per product; peak = 2500 TFLOP/s dense bf16 / 3)", 2500.0 / 3
             out["roofline"] = {
@@ -268,6 +292,28 @@ def main():
                 out["alt_precision"] = alt
             except Exception as ex:
                 out["alt_precision"] = {"error": repr(ex)}
+        if world == 1 and args.precision == "f32" and not args.no_extras:
+            # more lines than the headline, same engine, same timing discipline (fresh engine, warm-up ply, sync on both sides):
+            # the other single-GPU BASELINE config, the north star's "≥ 10 k concurrent games", and a long run with drains
+            extras = {}
+            try:
+                dt3, exp3, _, _ = run("f32", 0, steps=120, warmup=0, drain_every=10)
+                extras["sustained_120_plies"] = {"value": exp3 / dt3, "unit": "node-expansions/s", "plies": 120, "seconds": dt3,
+                                                 "what": "the headline config from ply 0 for 120 plies, finished examples drained every 10 plies", **run.last}
+                dt4, exp4, _, _ = run("f32", 0, cfg=(args.board, args.blocks, args.filters, args.head, 4 * args.games, tensors), steps=2, warmup=1)
+                extras["games_x4"] = {"value": exp4 / dt4, "unit": "node-expansions/s", "games": 4 * args.games, "ms_per_step": 1000.0 * dt4 / 2}
+                if (args.board, args.blocks, args.filters) == (5, 6, 64):
+                    net3, w3 = make_weights(6, 10, 128, "conv", seed=args.seed)
+                    dt5, exp5, _, p5 = run("f32", 1, cfg=(6, 10, 128, "conv", args.games, w3), steps=2, warmup=1)
+                    c3 = {"value": exp5 / dt5, "unit": "node-expansions/s", "ms_per_step": 1000.0 * dt5 / 2,
+                          "workload": f"BASELINE config C3: 6x6 Tak, {args.games} games, {args.rollouts} sims/move, 10-block x 128-filter resnet, conv policy head",
+                          "fp32_ceiling": F32_MFMA_PEAK_TFLOPS * 1e12 / 240_795_648}
+                    if p5 and p5["conv_launches"]:
+                        c3["tower_frac_of_f32_mfma_peak"] = p5["conv_flops"] / (p5["conv_ms"] / p5["conv_launches"] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS
+                    extras["config_c3"] = c3
+            except Exception as ex:
+                extras["error"] = repr(ex)
+            out["extra"] = extras
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, net)

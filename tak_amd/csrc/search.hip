@@ -120,12 +120,15 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     if (s->cfg.arena_nodes == 0) {
         size_t free_b = 0, total_b = 0;
         TG_HIP(hipMemGetInfo(&free_b, &total_b));
-        pool_nodes = std::min<size_t>({free_b / 2 / node_bytes, (size_t)cfg->games << 20, (size_t)0xFFFF0000u});
+        // (a 32-bit node index addresses 2^32 nodes; the slack chunks added below count against that)
+        const size_t index_limit = ((size_t)1 << 32) - (((size_t)3 * cfg->games + 2) << 11);
+        pool_nodes = std::min<size_t>({free_b / 2 / node_bytes, (size_t)cfg->games << 20, index_limit});
         pool_nodes = std::max<size_t>(pool_nodes, (size_t)cfg->games << 12);
         s->cfg.arena_nodes = (int32_t)std::min<size_t>(pool_nodes / (size_t)cfg->games, (size_t)1 << 30);
     } else {
         pool_nodes = (size_t)cfg->games * (size_t)cfg->arena_nodes;
-        if (pool_nodes > (size_t)0xFFFF0000u) return fail(TG_ERR_INVALID_ARG, "games x arena_nodes exceeds the 2^32 nodes a pool can hold");
+        if (pool_nodes > ((size_t)1 << 32) - (((size_t)3 * cfg->games + 2) << 11))
+            return fail(TG_ERR_INVALID_ARG, "games x arena_nodes exceeds the 2^32 nodes a pool can hold");
     }
     cfg = &s->cfg;
     const size_t G = (size_t)cfg->games;

@@ -271,9 +271,9 @@ typedef struct TgSearchConfig {
                                  others are small.  A rollout adds one node per legal move of the expanded leaf (≈ 45 on
                                  5×5, ≈ 80 on 6×6); the subtree under the move played is kept (tree reuse) and the rest
                                  returns to the pool.  The reference's own workload — 32 games × 10 000 rollouts on 6×6 —
-                                 needs ≈ 2^20 per game (0.8 GB in all); 4096 5×5 games at 400 rollouts ≈ 2^16 – 2^17.
+                                 peaks at ≈ 2^20 per game (31 M nodes, 0.75 GB in all: profiles/r02_soak_reference_workload.log); 4096 5×5 games at 400 rollouts ≈ 2^16 – 2^17.
                                  Exhausting the pool → TG_ERR_ARENA_OVERFLOW (sticky until reset).
-                                 0 = auto: half of the free device memory, at most 2^20 nodes per game */
+                                 0 = auto: half of the free device memory, at most 2^22 nodes per game and 2^32 in all */
     float exploration_base;   /* EXPLORATION_BASE 500 (mcts.rs:7) */
     float exploration_init;   /* EXPLORATION_INIT 4   (mcts.rs:8) */
     uint64_t seed;            /* counter-based RNG key (noise, move sampling, openings)      */
@@ -324,6 +324,9 @@ int tg_search_dump(TgEngine* e, int game, TgNodeRecord* records, size_t capacity
 /* counters since tg_search_create: expansions = completed rollouts (terminal ones included,
  * as in the reference's ROLLOUTS loop), evals = leaves sent to the network */
 int tg_search_counters(TgEngine* e, uint64_t* expansions, uint64_t* evals);
+/* occupancy of the node pool (for sizing TgSearchConfig.arena_nodes): nodes the pool holds, nodes in chunks currently owned
+ * by trees, and the largest number of nodes ever owned at once since tg_search_create / tg_search_reset.  Synchronises. */
+int tg_search_pool(TgEngine* e, uint64_t* nodes_total, uint64_t* nodes_in_use, uint64_t* nodes_peak);
 
 /* ---------------------------------------------------------------------------------------
  * Self-play driver (replaces self_play_parallel, train/src/self_play.rs:96-262).

@@ -19,7 +19,8 @@ ap.add_argument("--board", type=int, default=5)
 ap.add_argument("--games", type=int, default=4096)
 ap.add_argument("--rollouts", type=int, default=400)
 ap.add_argument("--plies", type=int, default=200)
-ap.add_argument("--arena", type=int, default=1 << 19, help="nodes per game arena (2^17 overflows after ~180 plies with a real network)")
+ap.add_argument("--arena", type=int, default=0, help="average node budget per game (one shared pool); 0 = sized from the free device memory")
+ap.add_argument("--every", type=int, default=10, help="plies per progress line / drain")
 ap.add_argument("--evaluator", default="hash", choices=["hash", "dummy", "resnet"])
 ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"])
 ap.add_argument("--blocks", type=int, default=6)
@@ -38,11 +39,13 @@ e.selfplay_create(args.games, arena_nodes=args.arena, seed=1, rollouts=args.roll
 t0 = time.time()
 drained = 0
 lens = []
-for p in range(0, args.plies, 10):
-    e.selfplay_step(10)
+for p in range(0, args.plies, args.every):
+    e.selfplay_step(args.every)
     st = e.selfplay_stats()  # synchronises and raises on any device error flag
     hdr, states, moves, visits = e.selfplay_drain(1 << 18)
     drained += len(hdr)
-    print(json.dumps({"ply": p + 10, "t": round(time.time() - t0, 1), **st, "drained": drained}), flush=True)
+    pool = e.search_pool()
+    print(json.dumps({"ply": p + args.every, "t": round(time.time() - t0, 1), **st, "drained": drained,
+                      "pool_nodes_in_use": pool["in_use"], "pool_nodes_peak": pool["peak"], "pool_nodes_total": pool["total"]}), flush=True)
 assert drained == st["examples"] or st["examples"] - drained <= 0
 print("soak ok")

@@ -132,7 +132,7 @@ __device__ __forceinline__ void conv_mainloop(const f32x4* __restrict__ lds4, co
 // ds_read_b128: no per-tap address arithmetic, no validity masks, no select against a zero row (what cost the
 // masked loop 8 % of a layer: scripts/probes/tower_stamps.hip), and — with the squares dealt to tile slots by the
 // residue of their cell index (tower_halo_slotmap) — no bank conflicts either.  Row pitch = F + 4 floats
-// (4·CH + 1 slots of 16 B).  addr4[j] = (cell − (NB + 2))·pitch4 + q.  Fully unrolled: 9·CH steps.
+// (4·CH + 1 slots of 16 B).  addr4[j] = (cell − (NB + 2))·pitch4 + q.
 // Same products in the same order as conv_mainloop → identical bits.
 // ------------------------------------------------------------------------------------------------
 // `turn` (0 / 1, wave-uniform): the two waves that share a SIMD take turns at s_setprio 1, one chunk each.  Left alone the
@@ -154,40 +154,63 @@ __device__ __forceinline__ void conv_mainloop_halo(const f32x4* __restrict__ lds
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wlayer, 0, (int)(9 * CH * WCHUNK), 0x00020000);
 #define TG_HALO_W(chunk) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, (int)((chunk) * WCHUNK), 0))
     f32x4 a[RTW];
+    // One board row of taps (dy) per trip of a 3-trip loop, the 3·CH steps of a row unrolled: a third of the code of the
+    // full unroll (the two loop instances of a workgroup fit the instruction cache with room to spare) at 13 vector adds
+    // per row switch.  The software pipeline runs across the row switch.
+    constexpr int ROW = 3 * CH;
+#define TG_HALO_OFF2(step) (((step) / CH) * P4 + ((step) % CH) * 4)
+    int ad[RTW];
 #pragma unroll
-    for (int j = 0; j < H1; j++) a[j] = lds4[addr4[j] + TG_HALO_OFF(0)];
+    for (int j = 0; j < RTW; j++) ad[j] = addr4[j];
+#pragma unroll
+    for (int j = 0; j < H1; j++) a[j] = lds4[ad[j] + TG_HALO_OFF2(0)];
     f32x4 w0 = TG_HALO_W(0);
     f32x4 w1 = TG_HALO_W(1);
+    int wchunk = 2;  // next chunk of weights to request
+#pragma unroll 1
+    for (int dy = 0; dy < 3; dy++) {
 #pragma unroll
-    for (int s = 0; s < total; s++) {
+        for (int s = 0; s < ROW; s++) {
 #ifndef TG_NO_PRIO_TURNS
-        if (s % TG_PRIO_PERIOD == 0) {
-            if (((s / TG_PRIO_PERIOD) & 1) == turn) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-        }
+            if (s % TG_PRIO_PERIOD == 0) {
+                if ((((s / TG_PRIO_PERIOD) + dy) & 1) == turn) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
 #endif
 #pragma unroll
-        for (int j = H1; j < RTW; j++) a[j] = lds4[addr4[j] + TG_HALO_OFF(s)];
-        __builtin_amdgcn_sched_barrier(0);
+            for (int j = H1; j < RTW; j++) a[j] = lds4[ad[j] + TG_HALO_OFF2(s)];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 4; t++)
+            for (int t = 0; t < 4; t++)
 #pragma unroll
-            for (int j = 0; j < H1; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t], a[j][t], acc[j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        const f32x4 w2 = TG_HALO_W(s + 2 < total ? s + 2 : total - 1);
-        if (s + 1 < total) {
+                for (int j = 0; j < H1; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t], a[j][t], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 w2 = TG_HALO_W(wchunk < total ? wchunk : total - 1);
+            wchunk++;
+            if (s + 1 < ROW) {
 #pragma unroll
-            for (int j = 0; j < H1; j++) a[j] = lds4[addr4[j] + TG_HALO_OFF(s + 1)];
+                for (int j = 0; j < H1; j++) a[j] = lds4[ad[j] + TG_HALO_OFF2(s + 1)];
+            } else {
+                // row switch: the second half's fragments of this step are already in registers (or in flight with the
+                // old addresses); from here on every read is of the next row of taps
+#pragma unroll
+                for (int j = H1; j < RTW; j++) ad[j] += RS * P4;
+                if (dy < 2) {
+#pragma unroll
+                    for (int j = 0; j < H1; j++) { ad[j] += RS * P4; a[j] = lds4[ad[j] + TG_HALO_OFF2(0)]; }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int j = H1; j < RTW; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t], a[j][t], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            w0 = w1;
+            w1 = w2;
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int j = H1; j < RTW; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t], a[j][t], acc[j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        w0 = w1;
-        w1 = w2;
     }
+#undef TG_HALO_OFF2
 #ifndef TG_NO_PRIO_TURNS
     __builtin_amdgcn_s_setprio(0);
 #endif

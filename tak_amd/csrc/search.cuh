@@ -66,7 +66,7 @@ struct SearchDev {
     uint32_t* chunk_fwd; // [n_chunks] re-root copy only: the chunk taken after this one …
     uint32_t* chunk_used;// [n_chunks] … and how many of this chunk's nodes were filled when it was closed
     uint32_t* free_ring; // [n_chunks] ids of free chunks
-    unsigned long long* pool_ctl;  // [0] chunks taken, [1] chunks returned, [2] returned-and-published (visible to takers)
+    unsigned long long* pool_ctl;  // [0] chunks taken, [1] chunks returned, [2] returned-and-published (visible to takers), [3] peak owned
     uint32_t n_chunks;
     int chunk_shift;
     // games

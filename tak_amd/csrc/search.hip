@@ -114,7 +114,8 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     s->cfg = *cfg;
     // One node pool for all games (search.cuh).  arena_nodes is the AVERAGE budget per game: pool = games × arena_nodes,
     // and a single tree may grow far beyond it while others are small.  0 = auto: half of the free device memory,
-    // at most 2^20 nodes per game and at most what a 32-bit node index addresses.
+    // at most 2^22 nodes per game (the reference's 10 000 rollouts on 6×6 peak at ≈ 2^20 per game) and at most what a
+    // 32-bit node index addresses.
     const size_t node_bytes = sizeof(NodeHot) + sizeof(NodeCold);
     size_t pool_nodes;
     if (s->cfg.arena_nodes == 0) {
@@ -122,7 +123,7 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
         TG_HIP(hipMemGetInfo(&free_b, &total_b));
         // (a 32-bit node index addresses 2^32 nodes; the slack chunks added below count against that)
         const size_t index_limit = ((size_t)1 << 32) - (((size_t)3 * cfg->games + 2) << 11);
-        pool_nodes = std::min<size_t>({free_b / 2 / node_bytes, (size_t)cfg->games << 20, index_limit});
+        pool_nodes = std::min<size_t>({free_b / 2 / node_bytes, (size_t)cfg->games << 22, index_limit});
         pool_nodes = std::max<size_t>(pool_nodes, (size_t)cfg->games << 12);
         s->cfg.arena_nodes = (int32_t)std::min<size_t>(pool_nodes / (size_t)cfg->games, (size_t)1 << 30);
     } else {
@@ -587,6 +588,23 @@ int tg_search_counters(TgEngine* e, uint64_t* expansions, uint64_t* evals) {
     if (rc) return rc;
     if (expansions) *expansions = c[0];
     if (evals) *evals = c[1];
+    return TG_OK;
+}
+
+int tg_search_pool(TgEngine* e, uint64_t* nodes_total, uint64_t* nodes_in_use, uint64_t* nodes_peak) {
+    int rc = need_search(e);
+    if (rc) return rc;
+    rc = sync_and_check(e);
+    if (rc) return rc;
+    Search* s = e->search;
+    unsigned long long ctl[4];
+    TG_HIP(hipMemcpy(ctl, s->pool_ctl.p, sizeof ctl, hipMemcpyDeviceToHost));
+    // chunks handed out so far minus chunks returned beyond the initial fill of the ring = chunks owned by trees
+    const unsigned long long initial = (unsigned long long)s->d.n_chunks - 1;
+    const unsigned long long owned = ctl[0] - (ctl[1] - initial);
+    if (nodes_total) *nodes_total = (uint64_t)initial << s->d.chunk_shift;
+    if (nodes_in_use) *nodes_in_use = (uint64_t)owned << s->d.chunk_shift;
+    if (nodes_peak) *nodes_peak = (uint64_t)ctl[3] << s->d.chunk_shift;
     return TG_OK;
 }
 

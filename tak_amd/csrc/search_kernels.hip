@@ -44,7 +44,13 @@ __device__ inline void pool_give_chain(const SearchDev& S, uint32_t head) {
     }
 }
 // after a kernel that returned chunks: make them available to the following launches
-__global__ void k_pool_publish(SearchDev S) { S.pool_ctl[2] = S.pool_ctl[1]; }
+// (also the high-water mark of chunks owned by trees, sampled here — after every re-root, when the trees are smallest — and
+// therefore taken BEFORE the returns of this launch are counted: the occupancy just before the move was played)
+__global__ void k_pool_publish(SearchDev S) {
+    const unsigned long long owned = S.pool_ctl[0] - (S.pool_ctl[2] - (unsigned long long)(S.n_chunks - 1));
+    if (owned > S.pool_ctl[3]) S.pool_ctl[3] = owned;
+    S.pool_ctl[2] = S.pool_ctl[1];
+}
 
 __device__ inline uint64_t ws_hash(const WState& s, const Geom& g) {
     // same function of the packed bytes as the CPU statement: stack words, meta bytes, 10 header bytes

@@ -85,7 +85,7 @@ ABI_SYMBOLS = [
     "tg_input_channels", "tg_policy_size", "tg_movegen", "tg_play", "tg_result", "tg_encode", "tg_move_index",
     "tg_perft", "tg_net_set_tensor", "tg_net_init_random", "tg_net_get_tensor", "tg_net_finalize", "tg_net_set_precision", "tg_policy_eval", "tg_forward_mcts", "tg_policy_eval_dev",
     "tg_search_create", "tg_search_reset", "tg_search_run", "tg_search_apply_dirichlet", "tg_search_apply_noise",
-    "tg_search_root", "tg_search_play", "tg_search_states", "tg_search_dump", "tg_search_counters",
+    "tg_search_root", "tg_search_play", "tg_search_states", "tg_search_dump", "tg_search_counters", "tg_search_pool",
     "tg_selfplay_create", "tg_selfplay_step", "tg_selfplay_stats", "tg_selfplay_drain",
     "tg_profile_enable", "tg_profile_read", "tg_board_pass_bench",
     "tg_augment_examples",
@@ -576,6 +576,12 @@ class Engine:
         return a.value, b.value
 
     # ---- measurement hooks ----------------------------------------------------------------------
+    def search_pool(self):
+        """node-pool occupancy: dict(total, in_use, peak) in nodes"""
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self._check(self.lib.tg_search_pool(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"total": a.value, "in_use": b.value, "peak": c.value}
+
     def profile_enable(self, sample_every):
         self._check(self.lib.tg_profile_enable(self.h, sample_every))
 

@@ -33,6 +33,10 @@ struct TowerParams {
     // halo image of the large-batch kernel (k_tower_halo): tile slot → cell | row << 16, position stride in cells
     const uint32_t* slotmap;
     int halo_pw, halo_ps;
+    // final activations in FRAGMENT-MAJOR order for the policy FC (FC-head networks): per (tile of 16 positions, 16-k
+    // chunk) one contiguous KB — lane (position, q) of the FC's B operand at ((pos/16·K/16 + chunk)·64 + (pos%16)·4 + q)·16 B —
+    // so that an FC wave's activation load is 8 whole cache lines instead of 16 half-used ones
+    int frag_out;
 };
 // geometry of the halo image for a supported topology (positions per workgroup, position stride) and the slot table
 bool tower_halo_geometry(int n, int F, int* pw, int* ps);
@@ -63,8 +67,10 @@ int fc_s3_cols(int NP);
 hipError_t launch_fc_s3(hipStream_t st, const float* act_split, const void* Wp, const float* bias, float* out, int M, int K, int NP,
                         int out_stride, int n_valid);
 hipError_t launch_value_head_s3(hipStream_t st, const float* act_split, const float* wv, float bv, int B, int len, float* eval);
+// a_frag: A is in the fragment-major order of TowerParams.frag_out (needs fc_frag_supported(K, NP))
 hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp, const float* bias, float* out, int M, int K,
-                       int NP, int out_stride, int n_valid);
+                       int NP, int out_stride, int n_valid, bool a_frag = false);
+bool fc_frag_supported(int K, int NP);
 hipError_t launch_value_head(hipStream_t st, const float* act, const float* wv, float bv, int B, int len, float* eval);
 hipError_t launch_softmax(hipStream_t st, const float* logits, int row_stride, bool conv_head, int nsq, int ch_stride, int P,
                           int B, float* policy, float* eval = nullptr);

@@ -290,6 +290,10 @@ int net_finalize(TgEngine* e) {
             T.w[2 + 2 * i] = n->res2[i].w.as<float>(); T.b[2 + 2 * i] = n->res2[i].b.as<float>();
         }
         T.slotmap = nullptr; T.halo_pw = 0; T.halo_ps = 0;
+        // FC-head networks whose value head rides in the FC's padding column: nothing but the policy FC reads the tower's
+        // output, so it is written in the FC's fragment order
+        T.frag_out = (e->cfg.policy_head == TG_HEAD_FC5 && n->value_in_fc && fc_frag_supported(nsq * F, n->policy_np) &&
+                      !getenv("TG_NO_FRAG_OUT")) ? 1 : 0;
         int pw, ps;
         if (tower_halo_geometry(e->g.n, F, &pw, &ps)) {
             std::vector<uint32_t> map((size_t)((pw * nsq + 15) / 16) * 16);
@@ -377,7 +381,7 @@ int net_finalize(TgEngine* e) {
         }
     }
     size_t mb = (size_t)e->cfg.max_batch;
-    TG_HIP(n->x.ensure(mb * nsq * F * 4));
+    TG_HIP(n->x.ensure(((mb + 15) / 16 * 16) * nsq * F * 4));  // (whole tiles of 16 positions: fragment-major FC input)
     TG_HIP(n->y.ensure(mb * nsq * F * 4));
     size_t logit_row = e->cfg.policy_head == TG_HEAD_CONV ? (size_t)nsq * n->policy_conv.cout_pad : (size_t)std::max(n->policy_np, n->s3_np);
     n->logit_row = logit_row;
@@ -493,7 +497,7 @@ static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const ui
         if (d_policy) TG_HIP(launch_softmax(st, logits, n->s3_np, false, nsq, 0, e->policy_size, nb, d_policy, n->value_in_fc ? d_eval : nullptr));
     } else {
         TG_HIP(launch_gemm(st, x, nsq * F, n->policy_w.as<float>(), n->policy_b.as<float>(), logits, nb, nsq * F, n->policy_np,
-                           n->policy_np, e->policy_size + (n->value_in_fc ? 1 : 0)));
+                           n->policy_np, e->policy_size + (n->value_in_fc ? 1 : 0), !n->s3 && n->fused && n->tower.frag_out));
         if (d_policy) TG_HIP(launch_softmax(st, logits, n->policy_np, false, nsq, 0, e->policy_size, nb, d_policy, n->value_in_fc ? d_eval : nullptr));
     }
     if (!d_policy && !(e->cfg.policy_head == TG_HEAD_FC5 && n->value_in_fc)) return fail(TG_ERR_STATE, "logits-only forward needs the FC head with the value column");

@@ -390,7 +390,13 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
         if (layer + 1 == T.nlayers) {
 #pragma unroll
             for (int j = 0; j < RTW; j++)
-                if (j < my_tiles && rho0 + j * 16 < rows) *(f32x4*)&out[((size_t)pos0 * nsq + rho0 + j * 16) * F + ch0 + 4 * q] = acc[j];
+                if (j < my_tiles && rho0 + j * 16 < rows) {
+                    const int rho = rho0 + j * 16;
+                    if (T.frag_out) {  // (tile of 16 positions, chunk = square·F/16 + channel tile) → one KB, lane (position, q)
+                        const int p = pos0 + rho / nsq, sq = rho % nsq;
+                        ((f32x4*)out)[((size_t)(p >> 4) * (nsq * (F >> 4)) + sq * (F >> 4) + ct) * 64 + (p & 15) * 4 + q] = acc[j];
+                    } else *(f32x4*)&out[((size_t)pos0 * nsq + rho) * F + ch0 + 4 * q] = acc[j];
+                }
             break;
         }
         TG_STAMP(layer, 2);
@@ -570,7 +576,12 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower_halo(const float* __restr
         if (layer + 1 == T.nlayers) {
 #pragma unroll
             for (int j = 0; j < RTW; j++)
-                if (rowid[j] < rows) *(f32x4*)&out[((size_t)pos0 * nsq + rowid[j]) * F + ch0 + 4 * q] = acc[j];
+                if (rowid[j] < rows) {
+                    if (T.frag_out) {
+                        const int p = pos0 + rowid[j] / nsq, sq = rowid[j] % nsq;
+                        ((f32x4*)out)[((size_t)(p >> 4) * (nsq * CH) + sq * CH + ct) * 64 + (p & 15) * 4 + q] = acc[j];
+                    } else *(f32x4*)&out[((size_t)pos0 * nsq + rowid[j]) * F + ch0 + 4 * q] = acc[j];
+                }
             break;
         }
         TG_STAMP(layer, 2);
@@ -684,7 +695,7 @@ constexpr int FC_PLANE = (FC_KSTEP / 16) * FC_COLS;  // 832 slots per k-quarter 
 
 __global__ __launch_bounds__(512) void k_fc_lds(const float* __restrict__ A, int lda, const float* __restrict__ Wp,
                                                 const float* __restrict__ bias, float* __restrict__ out, int M, int K, int NP,
-                                                int out_stride, int n_valid) {
+                                                int out_stride, int n_valid, int a_frag) {
     __shared__ f32x4 wl[2][4][FC_PLANE];  // [buffer][k-quarter][chunk*208 + col]  = 106.5 KB
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -694,7 +705,13 @@ __global__ __launch_bounds__(512) void k_fc_lds(const float* __restrict__ A, int
     const int n0 = blockIdx.y * FC_COLS;
     // loads are unconditional (rows past the end read a valid row and are never stored; the idle tail of the staging
     // round reads a clamped slot): hipcc puts s_waitcnt vmcnt(0) right behind an exec-masked global load
-    const f32x4* ap = (const f32x4*)(A + (size_t)(row_ok ? row : M - 1) * lda) + q;
+    // activations: row-major (one 16-B slot of its row per lane and chunk), or fragment-major (TowerParams.frag_out: the
+    // wave's 16 rows × 16 k of a chunk are one contiguous KB)
+    const int last_tile = (M - 1) >> 4;
+    const int my_tile = min(blockIdx.x * 8 + wave, last_tile);
+    const f32x4* ap = a_frag ? (const f32x4*)A + (size_t)my_tile * (K >> 4) * 64 + r16 * 4 + q
+                             : (const f32x4*)(A + (size_t)(row_ok ? row : M - 1) * lda) + q;
+    const size_t achunk = a_frag ? 64 : 4;  // f32x4 slots from one chunk to the next
     const f32x4* wg = (const f32x4*)Wp;  // slot (chunk, col, q) at (chunk*NP + col)*4 + q
     const int nsteps = K / FC_KSTEP;
 
@@ -727,12 +744,15 @@ __global__ __launch_bounds__(512) void k_fc_lds(const float* __restrict__ A, int
     __syncthreads();
     for (int step = 0; step < nsteps; step++) {
         const int buf = step & 1;
-        stage_load(step + 1 < nsteps ? step + 1 : step, stg);  // the last step reloads itself (unused)
+#ifndef TG_FC_PROBE
+#define TG_FC_PROBE 0  // scripts/probes/fc_stamps.hip: bit 0 = no weight staging, bit 1 = no activation stream (wrong results)
+#endif
+        if (!(TG_FC_PROBE & 1)) stage_load(step + 1 < nsteps ? step + 1 : step, stg);  // the last step reloads itself (unused)
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const int kc = step * 4 + c;
             const int kn = kc + 1 < nsteps * 4 ? kc + 1 : kc;
-            const f32x4 a_nxt = ap[(size_t)kn * 4];
+            const f32x4 a_nxt = (TG_FC_PROBE & 2) ? a_cur : ap[(size_t)kn * achunk];
             f32x4 w[FC_CT];
 #pragma unroll
             for (int j = 0; j < FC_CT; j++) w[j] = wl[buf][q][c * FC_COLS + j * 16 + r16];
@@ -769,14 +789,16 @@ constexpr int FCS_CT = 2;
 constexpr int FC_SMALL_ROWS = 512;  // up to here the small-batch kernel is the faster one (4 workgroups of k_fc_lds)
 __global__ __launch_bounds__(256) void k_fc_small(const float* __restrict__ A, int lda, const float* __restrict__ Wp,
                                                   const float* __restrict__ bias, float* __restrict__ out, int M, int K, int NP,
-                                                  int out_stride, int n_valid) {
+                                                  int out_stride, int n_valid, int a_frag) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r16 = lane & 15, q = lane >> 4;
     const int row = blockIdx.x * 16 + r16;
     const bool row_ok = row < M;
     const int n0 = (blockIdx.y * 4 + wave) * (FCS_CT * 16);
     if (n0 >= NP) return;
-    const f32x4* ap = (const f32x4*)(A + (size_t)(row_ok ? row : M - 1) * lda) + q;
+    const f32x4* ap = a_frag ? (const f32x4*)A + (size_t)blockIdx.x * (K >> 4) * 64 + r16 * 4 + q
+                             : (const f32x4*)(A + (size_t)(row_ok ? row : M - 1) * lda) + q;
+    const size_t achunk = a_frag ? 64 : 4;
     const f32x4* wg = (const f32x4*)Wp + ((size_t)(n0 + r16) * 4 + q);  // slot (chunk, col, q) at (chunk*NP + col)*4 + q
     const size_t wchunk = (size_t)NP * 4;
     const int nchunks = K >> 4;
@@ -785,7 +807,7 @@ __global__ __launch_bounds__(256) void k_fc_small(const float* __restrict__ A, i
 #pragma unroll
     for (int d = 0; d < D; d++) {
         const int kc = d < nchunks ? d : nchunks - 1;
-        a[d] = ap[(size_t)kc * 4];
+        a[d] = ap[(size_t)kc * achunk];
 #pragma unroll
         for (int j = 0; j < FCS_CT; j++) w[d][j] = wg[(size_t)kc * wchunk + j * 64];
     }
@@ -802,7 +824,7 @@ __global__ __launch_bounds__(256) void k_fc_small(const float* __restrict__ A, i
                     for (int j = 0; j < FCS_CT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[d][j][t], a[d][t], acc[j], 0, 0, 0);
             }
             const int kn = kc0 + d + D < nchunks ? kc0 + d + D : nchunks - 1;
-            a[d] = ap[(size_t)kn * 4];
+            a[d] = ap[(size_t)kn * achunk];
 #pragma unroll
             for (int j = 0; j < FCS_CT; j++) w[d][j] = wg[(size_t)kn * wchunk + j * 64];
         }
@@ -1196,16 +1218,19 @@ hipError_t launch_tower_states(hipStream_t st, const uint8_t* states, const Towe
     return hipErrorInvalidValue;
 }
 
+bool fc_frag_supported(int K, int NP) { return NP % FC_COLS == 0 && K % FC_KSTEP == 0 && NP % (FCS_CT * 16) == 0; }
+
 hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp, const float* bias, float* out, int M, int K,
-                       int NP, int out_stride, int n_valid) {
+                       int NP, int out_stride, int n_valid, bool a_frag) {
+    if (a_frag && !fc_frag_supported(K, NP)) return hipErrorInvalidValue;
     if (NP % FC_COLS == 0 && K % FC_KSTEP == 0 && M <= FC_SMALL_ROWS && NP % (FCS_CT * 16) == 0) {
         dim3 grid((M + 15) / 16, (NP / (FCS_CT * 16) + 3) / 4);
-        hipLaunchKernelGGL(k_fc_small, grid, dim3(256), 0, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid);
+        hipLaunchKernelGGL(k_fc_small, grid, dim3(256), 0, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid, a_frag ? 1 : 0);
         return hipGetLastError();
     }
     if (NP % FC_COLS == 0 && K % FC_KSTEP == 0) {
         dim3 grid((M + 127) / 128, NP / FC_COLS);
-        hipLaunchKernelGGL(k_fc_lds, grid, dim3(512), 0, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid);
+        hipLaunchKernelGGL(k_fc_lds, grid, dim3(512), 0, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid, a_frag ? 1 : 0);
         return hipGetLastError();
     }
     dim3 grid((M + 127) / 128, NP / 64);

@@ -742,8 +742,13 @@ __global__ __launch_bounds__(512) void k_fc_lds(const float* __restrict__ A, int
     stage_store(0, stg);
     f32x4 a_cur = ap[0];
     __syncthreads();
+    // (measured and discarded, scripts/probes/fc_stamps.hip + in-product A/B: a half-tile software pipeline as in the tower,
+    // activations one K-step or two chunks ahead, staging loads behind the first chunk, s_setprio turns — none faster.
+    // Per K-step the slower wave of a SIMD computes for 15.3 k cycles against 13.3 k of MFMA issue, then 1.8 k go to the
+    // staging stores, the barrier and the restart; without any global traffic the loop runs at 86 % of the peak.)
     for (int step = 0; step < nsteps; step++) {
         const int buf = step & 1;
+        TG_STAMP(step, 0);
 #ifndef TG_FC_PROBE
 #define TG_FC_PROBE 0  // scripts/probes/fc_stamps.hip: bit 0 = no weight staging, bit 1 = no activation stream (wrong results)
 #endif
@@ -762,8 +767,11 @@ __global__ __launch_bounds__(512) void k_fc_lds(const float* __restrict__ A, int
                 for (int j = 0; j < FC_CT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j][t], a_cur[t], acc[j], 0, 0, 0);
             a_cur = a_nxt;
         }
-        stage_store(buf ^ 1, stg);
+        TG_STAMP(step, 1);
+        if (!(TG_FC_PROBE & 1)) stage_store(buf ^ 1, stg);
+        TG_STAMP(step, 2);
         __syncthreads();
+        TG_STAMP(step, 3);
     }
     if (row_ok) {
 #pragma unroll

@@ -16,6 +16,8 @@ which = sys.argv[1]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 n, blocks, filters = CFG[which]
 e = tak_amd.Engine(n, res_blocks=blocks, filters=filters, max_batch=B)
+if os.environ.get("TG_PRECISION"):
+    e.set_precision(os.environ["TG_PRECISION"])
 e.init_random(seed=3)
 st = np.zeros((B, e.sb), np.uint8)
 hdr = e.sb - 16

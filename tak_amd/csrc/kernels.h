@@ -56,7 +56,12 @@ struct TowerS3Params {
     const float* head_b;  // bias[head_cout]
     float* head_out;      // logits [positions][squares][head_cout]
     int head_cout;
+    // halo image (k_tower_s3_halo): tile slot → cell | row << 16 for this topology's workgroup, position stride in cells
+    const uint32_t* slotmap;
+    int halo_ps;
 };
+// positions per workgroup and position stride of the split tower's halo image
+bool tower_s3_halo_geometry(int n, int F, int* pw, int* ps);
 bool tower_s3_supported(int n, int F);
 // out_split: write the final activations in the split row layout (per 8 channels 16 B hi, 16 B lo) for k_fc_s3
 hipError_t launch_tower_s3(hipStream_t st, const float* planes, const TowerS3Params& T, float* out, int B, int n, bool out_split);

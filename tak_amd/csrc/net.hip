@@ -35,6 +35,7 @@ struct Net {
     bool fused = false;  // whole tower in one launch (k_tower)
     TowerParams tower;
     DevBuf halo_map;                   // tile slot → square table of the halo tower (k_tower_halo)
+    DevBuf s3_halo_map;                // the same for the split tower's workgroup (k_tower_s3_halo)
     size_t logit_row = 0;              // floats per position in `logits`
     int precision = TG_PRECISION_F32;  // tg_net_set_precision
     bool s3 = false;                   // split-bf16 tower in use
@@ -323,6 +324,15 @@ int net_finalize(TgEngine* e) {
             TG_HIP(upload_conv_s3(g, F, F, F / 32, n->s3_w[2 + 2 * i]));
             T.w[1 + 2 * i] = n->s3_w[1 + 2 * i].p; T.b[1 + 2 * i] = n->res1[i].b.as<float>();
             T.w[2 + 2 * i] = n->s3_w[2 + 2 * i].p; T.b[2 + 2 * i] = n->res2[i].b.as<float>();
+        }
+        T.slotmap = nullptr; T.halo_ps = 0;
+        int pw3, ps3;
+        if (tower_s3_halo_geometry(e->g.n, F, &pw3, &ps3)) {
+            std::vector<uint32_t> map((size_t)((pw3 * nsq + 15) / 16) * 16);
+            tower_halo_slotmap(e->g.n, pw3, ps3, map.data());
+            TG_HIP(n->s3_halo_map.ensure(map.size() * 4));
+            TG_HIP(hipMemcpy(n->s3_halo_map.p, map.data(), map.size() * 4, hipMemcpyHostToDevice));
+            T.slotmap = n->s3_halo_map.as<uint32_t>(); T.halo_ps = ps3;
         }
         n->s3 = true;
         n->s3_fc_on = false;

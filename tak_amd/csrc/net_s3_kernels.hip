@@ -140,6 +140,105 @@ __device__ __forceinline__ void s3_mainloop(const u32x4* __restrict__ lds4, cons
     }
 }
 
+
+// The same layer over the HALO image (conv_mainloop.cuh: zero cells between board rows and positions, taps as immediates of
+// ds_read_b128, squares dealt to tile slots by tower_halo_slotmap).  Cell pitch = F/4 + 1 slots of 16 B (8·KC + 1): hi
+// slots q = 0..3 then lo slots of every 32-channel chunk, one slot of padding, so that the bank quad of a read is
+// (cell + slot) mod 16 as in the f32 kernel.  addr4[j] = (cell − (NB + 2))·pitch + q.  One board row of taps per trip.
+// Scheduling is pinned as in conv_mainloop_halo: the tiles in two halves, each half's fragments requested while the other
+// half's 6·H MFMAs run; weights through a buffer descriptor, two steps ahead.  (Left to itself the compiler sinks every
+// load to just before its first use to save registers and each wave then waits out the LDS and L2 latencies.  s_setprio
+// turns between the two waves of a SIMD, which pay in the f32 kernel, made no difference here.)
+#ifndef TG_S3_PROBE
+#define TG_S3_PROBE 0  // timing probes (wrong results): 1 = no fragment reads in the loop, 2 = no weight loads in the loop
+#endif
+template <int NT, int KC, int NB, int NM>
+__device__ __forceinline__ void s3_mainloop_halo(const u32x4* __restrict__ lds4, const void* __restrict__ wlayer, uint32_t wlane, int wstep,
+                                                 const int (&addr4)[NM], f32x4 (&acc)[NT][2]) {
+    static_assert(NM >= NT, "an address for every row tile");
+    constexpr int P4 = 8 * KC + 1, RS = NB + 1, ROW = 3 * KC, total = 9 * KC;
+    constexpr int H1 = (NT + 1) / 2;
+    // the layer's weights: step kk at byte kk·wstep; inside a step this lane's 16 B of the hi / lo halves of its two 16-channel tiles
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wlayer, 0, total * wstep, 0x00020000);
+    struct W4 { u32x4 h0, l0, h1, l1; };
+    auto load_w = [&](int kk) {
+        W4 w;
+        const int so = kk * wstep;
+        w.h0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, so, 0));
+        w.l0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + 1024, so, 0));
+        w.h1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + 2048, so, 0));
+        w.l1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + 3072, so, 0));
+        return w;
+    };
+#define TG_S3_OFF(step) (((step) / KC) * P4 + ((step) % KC) * 8)
+#define TG_S3_MFMA(J0, J1)                                                                                              \
+    _Pragma("unroll") for (int j = J0; j < J1; j++) {                                                                   \
+        acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w0.h0), as_bf(ah[j]), acc[j][0], 0, 0, 0);            \
+        acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w0.h1), as_bf(ah[j]), acc[j][1], 0, 0, 0);            \
+    }                                                                                                                   \
+    _Pragma("unroll") for (int j = J0; j < J1; j++) {                                                                   \
+        acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w0.h0), as_bf(al[j]), acc[j][0], 0, 0, 0);            \
+        acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w0.h1), as_bf(al[j]), acc[j][1], 0, 0, 0);            \
+    }                                                                                                                   \
+    _Pragma("unroll") for (int j = J0; j < J1; j++) {                                                                   \
+        acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w0.l0), as_bf(ah[j]), acc[j][0], 0, 0, 0);            \
+        acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w0.l1), as_bf(ah[j]), acc[j][1], 0, 0, 0);            \
+    }
+    int ad[NT];
+    u32x4 ah[NT], al[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) ad[j] = addr4[j];
+#pragma unroll
+    for (int j = 0; j < (TG_S3_PROBE & 1 ? NT : H1); j++) { ah[j] = lds4[ad[j] + TG_S3_OFF(0)]; al[j] = lds4[ad[j] + TG_S3_OFF(0) + 4]; }
+    W4 w0 = load_w(0);
+    W4 w1 = load_w(1);
+    int wnext = 2;
+#pragma unroll 1
+    for (int dy = 0; dy < 3; dy++) {
+#pragma unroll
+        for (int s = 0; s < ROW; s++) {
+#if !(TG_S3_PROBE & 1)
+#pragma unroll
+            for (int j = H1; j < NT; j++) { ah[j] = lds4[ad[j] + TG_S3_OFF(s)]; al[j] = lds4[ad[j] + TG_S3_OFF(s) + 4]; }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            TG_S3_MFMA(0, H1)
+            __builtin_amdgcn_sched_barrier(0);
+#if TG_S3_PROBE & 2
+            const W4 w2 = w0;
+#else
+            const W4 w2 = load_w(wnext < total ? wnext : total - 1);
+#endif
+            wnext++;
+#if TG_S3_PROBE & 1
+            if (false) {
+            } else if (s + 1 < ROW) {
+            } else if (false) {
+#else
+            if (s + 1 < ROW) {
+#endif
+#pragma unroll
+                for (int j = 0; j < H1; j++) { ah[j] = lds4[ad[j] + TG_S3_OFF(s + 1)]; al[j] = lds4[ad[j] + TG_S3_OFF(s + 1) + 4]; }
+            } else {
+                // row switch: the second half's fragments of this step are in registers or in flight with the old addresses
+#pragma unroll
+                for (int j = H1; j < NT; j++) ad[j] += RS * P4;
+                if (dy < 2) {
+#pragma unroll
+                    for (int j = 0; j < H1; j++) { ad[j] += RS * P4; ah[j] = lds4[ad[j] + TG_S3_OFF(0)]; al[j] = lds4[ad[j] + TG_S3_OFF(0) + 4]; }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            TG_S3_MFMA(H1, NT)
+            __builtin_amdgcn_sched_barrier(0);
+            w0 = w1;
+            w1 = w2;
+        }
+    }
+#undef TG_S3_MFMA
+#undef TG_S3_OFF
+}
+
 // RTW: row tiles of a full row group; NRG row groups × NCG channel groups (of 2 tiles) = NW waves.  With NW = 4 two
 // workgroups share a CU (one wave of each per SIMD): they drift apart, so one's epilogue / barrier phases overlap the other's MFMAs.
 // (the second launch bound caps the 4-wave variant at 256 registers so that two of its workgroups fit on a CU)
@@ -322,6 +421,243 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3(const voi
                         for (int j = 0; j < RTW; j++)
                             if (rho0 + j * 16 < rows)
                                 *(f32x4*)&T.head_out[((size_t)pos0 * nsq + rho0 + j * 16) * T.head_cout + hc0 + 16 * t + 4 * q] = acc[j][t] + bv;
+                    }
+                }
+            }
+            break;
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// k_tower_s3 on the halo image (full batches): layer 0 on the plain split image with the masked loop, then the
+// F-channel image in halo cells — see k_tower_halo (net_kernels.hip) for the layout, the slot table and why.
+// Same products in the same order as k_tower_s3 → identical bits.
+// ------------------------------------------------------------------------------------------------
+template <int RTW, int KC0, int KC, int NB, bool FROM_STATES, bool OUT_SPLIT, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(const void* __restrict__ in, TowerS3Params T, float* __restrict__ out,
+                                                                          int B, int PW, int NCG) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    u32x4* lds4 = (u32x4*)lds;
+    constexpr int n = NB, nsq = NB * NB, RS = NB + 1, LEAD = NB + 2, F = 32 * KC, P4 = 8 * KC + 1;
+    const int PS = T.halo_ps;
+    const int tid = threadIdx.x;
+    const int pos0 = blockIdx.x * PW;
+    const int npos = min(PW, B - pos0);
+    const int rows = npos * nsq;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int cg = wave % NCG, rg = wave / NCG;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int ch0 = cg * 32;
+
+    // ---- stage the input: plain image, CP0 = 32·KC0 channels per row, hi/lo split, pitch + 16 B, one zero row ----
+    constexpr int CP0 = 32 * KC0;
+    constexpr int LS4 = (CP0 >> 2) + 1;
+    if (FROM_STATES) {
+        const Geom geo = make_geom(n);
+        const uint8_t* states = (const uint8_t*)in;
+        const int C = input_channels(n);
+        for (int p = wave; p < npos; p += NW) {
+            WState ws;
+            ws_load(ws, states + (size_t)(pos0 + p) * geo.bytes, geo);
+            const float fcd = fcd_value(ws, geo);
+            const RowMask m = ws_row_mask(ws, geo);
+            if (lane < nsq) {
+                u32x4* row = lds4 + (size_t)(p * nsq + lane) * LS4;
+                for (int g8 = 0; g8 < (CP0 >> 3); g8++) {
+                    float4 a = row_mask_value(m, 2 * g8, C, fcd), b = row_mask_value(m, 2 * g8 + 1, C, fcd);
+                    u32x2 h0, l0, h1, l1;
+                    split4(f32x4{a.x, a.y, a.z, a.w}, h0, l0);
+                    split4(f32x4{b.x, b.y, b.z, b.w}, h1, l1);
+                    row[(g8 >> 2) * 8 + (g8 & 3)] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+                    row[(g8 >> 2) * 8 + 4 + (g8 & 3)] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+                }
+            }
+        }
+    } else {
+        const float* planes = (const float*)in;
+        const int cin = T.cin_pad;
+        const int groups = CP0 >> 3;
+        for (int idx = tid; idx < rows * groups; idx += NW * 64) {
+            int r = idx / groups, g8 = idx - r * groups;
+            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = a;
+            const float* src = planes + ((size_t)pos0 * nsq + r) * cin + 8 * g8;
+            if (8 * g8 < cin) a = *(const f32x4*)src;
+            if (8 * g8 + 4 < cin) b = *(const f32x4*)(src + 4);
+            u32x2 h0, l0, h1, l1;
+            split4(a, h0, l0);
+            split4(b, h1, l1);
+            lds4[r * LS4 + (g8 >> 2) * 8 + (g8 & 3)] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+            lds4[r * LS4 + (g8 >> 2) * 8 + 4 + (g8 & 3)] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+        }
+    }
+    for (int idx = tid; idx < LS4; idx += NW * 64) lds4[rows * LS4 + idx] = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+
+    // row tiles dealt to the row groups as evenly as they go (k_tower_halo)
+    const int NRG = NW / NCG;
+    const int ntiles = (PW * nsq + 15) >> 4;
+    const int tbase = ntiles / NRG, trem = ntiles - tbase * NRG;
+    const int my_tiles = tbase + (rg < trem ? 1 : 0);
+    const int tile0 = rg * tbase + min(rg, trem);
+    const bool short_group = my_tiles < RTW;
+
+    f32x4 acc[RTW][2];
+#pragma unroll
+    for (int j = 0; j < RTW; j++) acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int t1 = 128, wstride = (F >> 4) * 128;
+
+    // 8-byte half-slot of channel c inside a cell / row of the F-channel image: chunk c>>5, slot (c&31)>>3 (hi) / +4 (lo), half (c&7)>>2
+    auto half_slot = [&](int cell, int c) { return (u32x2*)(lds4 + (size_t)cell * P4 + (c >> 5) * 8 + ((c & 31) >> 3)) + ((c & 7) >> 2); };
+
+    // ---- layer 0 on the plain image: tile t = rows 16t … 16t + 15 ----
+    {
+        const int rho0 = tile0 * 16 + r16;
+        int vmask[RTW];
+        conv_tap_masks<RTW>(rows, n, nsq, rho0, vmask);
+        if (short_group) vmask[RTW - 1] = 0;
+        const u32x4* wp = (const u32x4*)T.w[0] + (size_t)(ch0 >> 4) * 128 + q * 16 + r16;
+        if (RTW > 1 && short_group) {
+            f32x4 (&acs)[RTW - 1][2] = *reinterpret_cast<f32x4 (*)[RTW - 1][2]>(&acc[0][0]);
+            s3_mainloop<RTW - 1, KC0>(lds4, wp, t1, wstride, LS4, rows, 0, n, rho0, q, vmask, acs);
+        } else {
+            s3_mainloop<RTW, KC0>(lds4, wp, t1, wstride, LS4, rows, 0, n, rho0, q, vmask, acc);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const f32x4 bv = *(const f32x4*)&T.b[0][ch0 + 16 * t + 4 * q];
+#pragma unroll
+            for (int j = 0; j < RTW; j++) {
+                f32x4 v = acc[j][t] + bv;
+                v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f);
+                acc[j][t] = v;
+            }
+        }
+        __syncthreads();  // every wave has finished reading the input image
+        const int cells = LEAD + PW * PS;
+        for (int idx = tid; idx < cells * P4; idx += NW * 64) {
+            const int c = idx / P4 - LEAD;
+            const int o = c < 0 ? n * RS : c % PS;
+            if (o >= n * RS || o % RS == n) lds4[idx] = u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int j = 0; j < RTW; j++) {
+            const int rho = rho0 + j * 16;
+            if (j < my_tiles && rho < PW * nsq) {
+                const int p = rho / nsq, sq = rho - p * nsq, y = sq / n, x = sq - y * n;
+                const int cell = LEAD + p * PS + y * RS + x;
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    u32x2 hi, lo;
+                    split4(acc[j][t], hi, lo);
+                    u32x2* hp = half_slot(cell, ch0 + 16 * t + 4 * q);
+                    hp[0] = hi;
+                    hp[8] = lo;
+                }
+            }
+            acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+    }
+    if (T.nlayers == 1) return;  // (never: a tower has at least one block)
+
+    // ---- layers 1 … : slot (tile, lane) → square through the slot table ----
+    const uint32_t wlane = (uint32_t)(((ch0 >> 4) * 128 + q * 16 + r16) * 16);  // this lane's 16 B inside a step of a layer's weights
+    int cell[RTW], rowid[RTW], addr4[RTW];
+#pragma unroll
+    for (int j = 0; j < RTW; j++) {
+        const uint32_t e = j < my_tiles ? T.slotmap[(tile0 + j) * 16 + r16] : 0xFFFF0000u;
+        rowid[j] = (int)(e >> 16);
+        cell[j] = rowid[j] == 0xFFFF ? LEAD + n * RS : (int)(e & 0xFFFFu);
+        addr4[j] = (cell[j] - LEAD) * P4 + q;
+    }
+    for (int layer = 1; layer < T.nlayers; layer++) {
+#pragma unroll
+        for (int j = 0; j < RTW; j++) asm volatile("" : "+v"(addr4[j]));  // keep the compiler from hoisting address sums out of the layer loop
+        if (RTW > 1 && short_group) {
+            f32x4 (&acs)[RTW - 1][2] = *reinterpret_cast<f32x4 (*)[RTW - 1][2]>(&acc[0][0]);
+            s3_mainloop_halo<RTW - 1, KC, NB>(lds4, T.w[layer], wlane, wstride * 16, addr4, acs);
+        } else {
+            s3_mainloop_halo<RTW, KC, NB>(lds4, T.w[layer], wlane, wstride * 16, addr4, acc);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const f32x4 bv = *(const f32x4*)&T.b[layer][ch0 + 16 * t + 4 * q];
+#pragma unroll
+            for (int j = 0; j < RTW; j++) {
+                f32x4 v = acc[j][t] + bv;
+                v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f);
+                acc[j][t] = v;
+            }
+        }
+        if (layer + 1 == T.nlayers && !OUT_SPLIT) {
+#pragma unroll
+            for (int j = 0; j < RTW; j++)
+                if (rowid[j] < rows) {
+                    float* o = out + ((size_t)pos0 * nsq + rowid[j]) * F + ch0 + 4 * q;
+                    *(f32x4*)o = acc[j][0];
+                    *(f32x4*)(o + 16) = acc[j][1];
+                }
+            break;
+        }
+        __syncthreads();  // every wave has finished reading the previous image
+        const bool conv1 = (layer & 1) == 1;
+        f32x4 nxt[RTW][2];
+#pragma unroll
+        for (int j = 0; j < RTW; j++)
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                nxt[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (conv1 && rowid[j] != 0xFFFF) {
+                    const u32x2* hp = half_slot(cell[j], ch0 + 16 * t + 4 * q);
+                    nxt[j][t] = join4(hp[0], hp[8]);
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < RTW; j++)
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+                if (rowid[j] != 0xFFFF) {
+                    u32x2 hi, lo;
+                    split4(acc[j][t], hi, lo);
+                    u32x2* hp = half_slot(cell[j], ch0 + 16 * t + 4 * q);
+                    hp[0] = hi;
+                    hp[8] = lo;
+                }
+#pragma unroll
+        for (int j = 0; j < RTW; j++) { acc[j][0] = nxt[j][0]; acc[j][1] = nxt[j][1]; }
+        __syncthreads();
+        if (OUT_SPLIT && layer + 1 == T.nlayers) {
+            // the image holds the final activations in the split cell layout: copy the real cells out row by row, 16 B per lane
+            const int spr = F >> 2;
+            u32x4* o = (u32x4*)out + (size_t)pos0 * nsq * spr;
+            for (int idx = tid; idx < rows * spr; idx += NW * 64) {
+                const int r = idx / spr, v = idx - r * spr;
+                const int p = r / nsq, sq = r - p * nsq, y = sq / n, x = sq - y * n;
+                o[idx] = lds4[(size_t)(LEAD + p * PS + y * RS + x) * P4 + v];
+            }
+            if (T.head_w) {  // conv policy head as one more 3×3 convolution over the resident image (k_tower_s3)
+                const int hstride = (T.head_cout >> 4) * 128;
+                for (int hc0 = cg * 32; hc0 < T.head_cout; hc0 += NCG * 32) {
+#pragma unroll
+                    for (int j = 0; j < RTW; j++) acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const uint32_t hlane = (uint32_t)(((hc0 >> 4) * 128 + q * 16 + r16) * 16);
+#pragma unroll
+                    for (int j = 0; j < RTW; j++) asm volatile("" : "+v"(addr4[j]));
+                    if (RTW > 1 && short_group) {
+                        f32x4 (&acs)[RTW - 1][2] = *reinterpret_cast<f32x4 (*)[RTW - 1][2]>(&acc[0][0]);
+                        s3_mainloop_halo<RTW - 1, KC, NB>(lds4, T.head_w, hlane, hstride * 16, addr4, acs);
+                    } else {
+                        s3_mainloop_halo<RTW, KC, NB>(lds4, T.head_w, hlane, hstride * 16, addr4, acc);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        const f32x4 bv = *(const f32x4*)&T.head_b[hc0 + 16 * t + 4 * q];
+#pragma unroll
+                        for (int j = 0; j < RTW; j++)
+                            if (rowid[j] < rows)
+                                *(f32x4*)&T.head_out[((size_t)pos0 * nsq + rowid[j]) * T.head_cout + hc0 + 16 * t + 4 * q] = acc[j][t] + bv;
                     }
                 }
             }
@@ -613,10 +949,39 @@ static hipError_t launch_s3_t(hipStream_t st, const void* in, const TowerS3Param
     return hipGetLastError();
 }
 
+
+template <int RTW, int KC0, int KC, int NB, bool FROM_STATES, bool OUT_SPLIT, int NW>
+static hipError_t launch_s3_halo_t(hipStream_t st, const void* in, const TowerS3Params& T, float* out, int B, int PW, int NCG) {
+    const size_t plain = (size_t)(PW * NB * NB + 1) * (32 * KC0 + 4) * sizeof(float);
+    const size_t halo = (size_t)(NB + 2 + PW * T.halo_ps) * (32 * KC + 4) * sizeof(float);
+    const size_t lds = std::max(plain, halo);
+    static size_t configured = 0;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_tower_s3_halo<RTW, KC0, KC, NB, FROM_STATES, OUT_SPLIT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    hipLaunchKernelGGL((k_tower_s3_halo<RTW, KC0, KC, NB, FROM_STATES, OUT_SPLIT, NW>), dim3((B + PW - 1) / PW), dim3(NW * 64), lds, st, in, T, out, B, PW, NCG);
+    return hipGetLastError();
+}
+
+bool tower_s3_halo_geometry(int n, int F, int* pw, int* ps) {
+    // positions per workgroup as in launch_s3; strides as tower_halo_geometry (same pitch of F/4 + 1 slots)
+    if (n == 5 && F == 64) { *pw = 8; *ps = 36; return true; }    // 80 240 B: two workgroups per CU
+    if (n == 5 && F == 128) { *pw = 8; *ps = 37; return true; }   // 159 984 B
+    if (n == 6 && F == 128) { *pw = 4; *ps = 51; return true; }   // 111 936 B
+    return false;
+}
 bool tower_s3_supported(int n, int F) { return (n == 5 && (F == 64 || F == 128)) || (n == 6 && F == 128); }
 
 template <bool FROM_STATES, bool OUT_SPLIT>
 static hipError_t launch_s3(hipStream_t st, const void* in, const TowerS3Params& T, float* out, int B, int n) {
+    static const bool no_halo = getenv("TG_NO_HALO_TOWER") != nullptr;
+    if (T.slotmap && !no_halo && B >= 256) {  // the halo image (same workgroup shapes as below; identical bits)
+        if (n == 5 && T.F == 64) return launch_s3_halo_t<7, 3, 2, 5, FROM_STATES, OUT_SPLIT, 4>(st, in, T, out, B, 8, 2);
+        if (n == 5 && T.F == 128) return launch_s3_halo_t<7, 3, 4, 5, FROM_STATES, OUT_SPLIT, 8>(st, in, T, out, B, 8, 4);
+        if (n == 6 && T.F == 128) return launch_s3_halo_t<5, 3, 4, 6, FROM_STATES, OUT_SPLIT, 8>(st, in, T, out, B, 4, 4);
+    }
     // 5×5, F = 64: 8 positions = 13 row tiles = 2 row groups (7,6) × 2 channel groups, 4 waves, two workgroups per CU
     if (n == 5 && T.F == 64) {
         static const bool wide = getenv("TG_S3_WIDE") != nullptr;  // A/B switch: one 8-wave workgroup of 16 positions per CU

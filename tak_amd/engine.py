@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtakgpu.so")
+LIB_PATH = os.environ.get("TAKGPU_LIB") or os.path.join(_HERE, "libtakgpu.so")  # TAKGPU_LIB: probe builds (scripts/probes)
 
 TG_ABI_VERSION = 2
 TG_MAX_MOVES = 512

@@ -191,15 +191,18 @@ def test_c_host_runs_selfplay_through_the_abi(tmp_path):
     (6, 2, 128, "conv", (5, 260, 520)),                   # C3 shape, conv head
     (5, 2, 64, "conv", (40, 500, 1100, 2100)),            # conv head on 5×5
 ])
-def test_result_does_not_depend_on_the_batch_size(orc, n, blocks, filters, head, sizes):
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_result_does_not_depend_on_the_batch_size(orc, n, blocks, filters, head, sizes, precision):
     """Small batches run instantiations with fewer positions per workgroup (and a barrier-free FC) so that a 32-leaf call does
-    not take as long as a 4096-leaf one; the per-element arithmetic is the same, so a position's outputs must be the same
-    BITS whatever batch it is evaluated in."""
+    not take as long as a 4096-leaf one, large ones the halo-image towers (k_tower_halo, k_tower_s3_halo); the per-element
+    arithmetic is the same, so a position's outputs must be the same BITS whatever batch it is evaluated in."""
     net = torch_ref.make_net(n, blocks, filters, head, seed=11)
     total = max(sizes)
     sts = orc.random_positions(n, 64, seed=9, max_plies=60, half_komi=4)
     sts = np.concatenate([sts] * ((total + 63) // 64))[:total]
     e = _engine(n, blocks, filters, head, max_batch=total)
+    if precision != "f32":
+        e.set_precision(precision)
     e.load_state_dict(torch_ref.abi_tensors(net))
     p_ref, v_ref = e.policy_eval(sts)
     assert np.array_equal(p_ref[:64], p_ref[64:128]) and np.abs(p_ref.sum(1) - 1).max() < 1e-5

@@ -139,10 +139,11 @@ __device__ __forceinline__ void conv_mainloop(const f32x4* __restrict__ lds4, co
 // arbiter prefers the older wave throughout: it finishes its tiles at ≈ 3/4 of the layer and the younger one runs the
 // last quarter alone, where nothing fills the gaps between its own MFMA groups (37 instead of 33 cycles per MFMA).
 template <int RTW, int CH, int NB, int NM>
-__device__ __forceinline__ void conv_mainloop_halo(const f32x4* __restrict__ lds4, const float* __restrict__ wlayer, uint32_t wlane,
-                                                   const int (&addr4)[NM], f32x4 (&acc)[RTW], const int turn) {
+__device__ __forceinline__ void conv_mainloop_halo(const f32x4* __restrict__ lds4, const float* __restrict__ wlayer,
+                                                   const float* __restrict__ wnext, uint32_t wlane, const int (&addr4)[NM],
+                                                   f32x4 (&acc)[RTW], const int turn, f32x4& w0, f32x4& w1) {
     static_assert(NM >= RTW, "an address for every row tile");
-    constexpr int P4 = 4 * CH + 1, RS = NB + 1, total = 9 * CH;
+    constexpr int P4 = 4 * CH + 1, RS = NB + 1;
     constexpr int H1 = (RTW + 1) / 2;
     constexpr size_t WCHUNK = (size_t)16 * CH * 4 * 16;  // bytes of one 16-k chunk of the layer's weights: [F][4 slots][16 B]
 #ifndef TG_PRIO_PERIOD
@@ -151,6 +152,9 @@ __device__ __forceinline__ void conv_mainloop_halo(const f32x4* __restrict__ lds
 #define TG_HALO_OFF(step) ((((step) / CH) / 3 * RS + ((step) / CH) % 3) * P4 + ((step) % CH) * 4)
     // weights through a buffer descriptor of the layer: the chunk is the scalar offset (one s_movk per load), this lane's
     // constant 16 B inside a chunk the vector offset — no vector address arithmetic in the loop
+    // The stream runs on into the next layer: w0 / w1 arrive holding this layer's chunks 0 and 1 (conv_halo_first_weights, or
+    // the previous call) and leave holding the next layer's, requested by the last two steps — the epilogue and the barriers
+    // between two layers hide that latency.
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wlayer, 0, (int)(9 * CH * WCHUNK), 0x00020000);
 #define TG_HALO_W(chunk) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, (int)((chunk) * WCHUNK), 0))
     f32x4 a[RTW];
@@ -164,8 +168,6 @@ __device__ __forceinline__ void conv_mainloop_halo(const f32x4* __restrict__ lds
     for (int j = 0; j < RTW; j++) ad[j] = addr4[j];
 #pragma unroll
     for (int j = 0; j < H1; j++) a[j] = lds4[ad[j] + TG_HALO_OFF2(0)];
-    f32x4 w0 = TG_HALO_W(0);
-    f32x4 w1 = TG_HALO_W(1);
     int wchunk = 2;  // next chunk of weights to request
 #pragma unroll 1
     for (int dy = 0; dy < 3; dy++) {
@@ -185,7 +187,14 @@ __device__ __forceinline__ void conv_mainloop_halo(const f32x4* __restrict__ lds
 #pragma unroll
                 for (int j = 0; j < H1; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t], a[j][t], acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            const f32x4 w2 = TG_HALO_W(wchunk < total ? wchunk : total - 1);
+            f32x4 w2;
+            if (s < ROW - 2) {
+                w2 = TG_HALO_W(wchunk);
+            } else {  // the last two steps of a row of taps — of the layer when dy = 2: on to the next layer's first chunks
+                const bool on = dy == 2;
+                const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(on ? wnext : wlayer), 0, (int)(9 * CH * WCHUNK), 0x00020000);
+                w2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, wlane, (int)((on ? s - (ROW - 2) : wchunk) * WCHUNK), 0));
+            }
             wchunk++;
             if (s + 1 < ROW) {
 #pragma unroll
@@ -216,6 +225,15 @@ __device__ __forceinline__ void conv_mainloop_halo(const f32x4* __restrict__ lds
 #endif
 #undef TG_HALO_OFF
 #undef TG_HALO_W
+}
+
+// chunks 0 and 1 of a layer's weights for the first conv_mainloop_halo call of a kernel
+template <int CH>
+__device__ __forceinline__ void conv_halo_first_weights(const float* __restrict__ wlayer, uint32_t wlane, f32x4& w0, f32x4& w1) {
+    constexpr size_t WCHUNK = (size_t)16 * CH * 4 * 16;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wlayer, 0, (int)(9 * CH * WCHUNK), 0x00020000);
+    w0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, 0, 0));
+    w1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, (int)WCHUNK, 0));
 }
 
 }  // namespace tg

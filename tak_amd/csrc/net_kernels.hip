@@ -495,6 +495,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower_halo(const float* __restr
 #pragma unroll
     for (int j = 0; j < RTW; j++) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
+    const uint32_t wlane = (uint32_t)(((ch0 + r16) * 4 + q) * 16);  // this lane's 16 B inside a chunk of weights
+    f32x4 w0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, w1 = w0;                // the weight stream's two chunks in flight between layers
     // ---- layer 0 on the plain image: tile t = rows 16t … 16t + 15 ----
     {
         const int rho0 = tile0 * 16 + r16;
@@ -510,6 +512,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower_halo(const float* __restr
             conv_mainloop<RTW, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acc);
         }
         TG_STAMP(0, 1);
+        if (T.nlayers > 1) conv_halo_first_weights<CH>(T.w[1], wlane, w0, w1);  // in flight during the change of images
         const f32x4 bv = *(const f32x4*)&T.b[0][ch0 + 4 * q];
 #pragma unroll
         for (int j = 0; j < RTW; j++) {
@@ -521,10 +524,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower_halo(const float* __restr
         __syncthreads();  // every wave has finished reading the input planes
         TG_STAMP(0, 3);
         // the halo image replaces them: zero cells first (they are never written again), then this layer's output
-        const int cells = LEAD + PW * PS;
+        const int cells = LEAD + PW * PS + 1;  // + the spare cell of the idle slots
         for (int idx = tid; idx < cells * P4; idx += NWAVES * 64) {
             const int c = idx / P4 - LEAD;
-            const int o = c < 0 ? n * RS : c % PS;  // offset inside the position block; rows of RS cells, then the zero row
+            const int o = c < 0 || c >= PW * PS ? n * RS : c % PS;  // offset inside the position block; rows of RS cells, then the zero row
             if (o >= n * RS || o % RS == n) lds4[idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
 #pragma unroll
@@ -547,23 +550,23 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower_halo(const float* __restr
     for (int j = 0; j < RTW; j++) {
         const uint32_t e = j < my_tiles ? T.slotmap[(tile0 + j) * 16 + r16] : 0xFFFF0000u;
         rowid[j] = (int)(e >> 16);                                      // 0xFFFF: slot without a square
-        const int cell = rowid[j] == 0xFFFF ? LEAD + n * RS : (int)(e & 0xFFFFu);  // (such a slot reads around a zero cell)
-        cell4[j] = cell * P4 + (ch0 >> 2) + q;                          // where this lane's 4 output channels of the square live
-        addr4[j] = (cell - LEAD) * P4 + q;                              // B-operand base: tap (-1,-1), chunk 0
+        const bool idle = rowid[j] == 0xFFFF;  // such a slot reads around a zero cell and writes the spare cell behind the image
+        cell4[j] = (idle ? LEAD + PW * PS : (int)(e & 0xFFFFu)) * P4 + (ch0 >> 2) + q;  // this lane's 4 output channels of the square
+        addr4[j] = ((idle ? LEAD + n * RS : (int)(e & 0xFFFFu)) - LEAD) * P4 + q;       // B-operand base: tap (-1,-1), chunk 0
     }
     const int turn = (wave >> 2) & 1;  // waves w and w + 4 share a SIMD
-    const uint32_t wlane = (uint32_t)(((ch0 + r16) * 4 + q) * 16);  // this lane's 16 B inside a chunk of weights
     for (int layer = 1; layer < T.nlayers; layer++) {
         // the addresses are the same in every layer, but the compiler must not know: it would hoist all 9·RTW
         // (address + tap offset) sums out of the layer loop and spill them instead of using ds_read immediates
 #pragma unroll
         for (int j = 0; j < RTW; j++) asm volatile("" : "+v"(addr4[j]));
         TG_STAMP(layer, 0);
+        const float* wnext = T.w[layer + 1 < T.nlayers ? layer + 1 : layer];
         if (RTW > 1 && short_group) {
             f32x4 (&acs)[RTW - 1] = *reinterpret_cast<f32x4 (*)[RTW - 1]>(&acc[0]);
-            conv_mainloop_halo<RTW - 1, CH, NB>(lds4, T.w[layer], wlane, addr4, acs, turn);
+            conv_mainloop_halo<RTW - 1, CH, NB>(lds4, T.w[layer], wnext, wlane, addr4, acs, turn, w0, w1);
         } else {
-            conv_mainloop_halo<RTW, CH, NB>(lds4, T.w[layer], wlane, addr4, acc, turn);
+            conv_mainloop_halo<RTW, CH, NB>(lds4, T.w[layer], wnext, wlane, addr4, acc, turn, w0, w1);
         }
         TG_STAMP(layer, 1);
         const f32x4 bv = *(const f32x4*)&T.b[layer][ch0 + 4 * q];
@@ -589,12 +592,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower_halo(const float* __restr
         TG_STAMP(layer, 3);
         const bool conv1 = (layer & 1) == 1;  // next layer is conv2 of the same block: it starts from the block input
 #pragma unroll
-        for (int j = 0; j < RTW; j++) {
+        for (int j = 0; j < RTW; j++) {  // no per-tile branches: idle slots have their own cell
             f32x4 x0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (rowid[j] != 0xFFFF) {
-                if (conv1) x0 = lds4[cell4[j]];
-                lds4[cell4[j]] = acc[j];
-            }
+            if (conv1) x0 = lds4[cell4[j]];
+            lds4[cell4[j]] = acc[j];
             acc[j] = x0;
         }
         TG_STAMP(layer, 4);
@@ -1087,9 +1088,9 @@ static hipError_t launch_tower_t(hipStream_t st, const float* in, const TowerPar
 // ---- halo image (k_tower_halo): geometry and the square → tile-slot table -------------------------
 bool tower_halo_geometry(int n, int F, int* pw, int* ps) {
     // position strides found by simulating the ds_read_b128 bank groups over all tiles / taps (conflict factor ≤ 1.11)
-    if (n == 5 && F == 64) { *pw = 16; *ps = 36; return true; }   // 158 576 B of LDS
-    if (n == 5 && F == 128) { *pw = 8; *ps = 37; return true; }   // 159 984 B
-    if (n == 6 && F == 128) { *pw = 4; *ps = 51; return true; }   // 111 936 B
+    if (n == 5 && F == 64) { *pw = 16; *ps = 36; return true; }   // 158 848 B of LDS (with the spare cell)
+    if (n == 5 && F == 128) { *pw = 8; *ps = 37; return true; }   // 160 512 B
+    if (n == 6 && F == 128) { *pw = 4; *ps = 51; return true; }   // 112 464 B
     return false;
 }
 
@@ -1134,7 +1135,7 @@ template <int RTW, int NWAVES, int CH0, int CH, int NB, bool FROM_STATES>
 static hipError_t launch_tower_halo_t(hipStream_t st, const float* in, const TowerParams& T, float* out, int B, int CTW) {
     const int PW = T.halo_pw;
     const size_t plain = (size_t)(PW * NB * NB + 1) * (T.cin_pad + LDS_PAD16) * sizeof(float);
-    const size_t halo = (size_t)(NB + 2 + PW * T.halo_ps) * (16 * CH + 4) * sizeof(float);
+    const size_t halo = (size_t)(NB + 2 + PW * T.halo_ps + 1) * (16 * CH + 4) * sizeof(float);  // + the spare cell
     const size_t lds = plain > halo ? plain : halo;
     static size_t configured = 0;
     if (lds > configured) {

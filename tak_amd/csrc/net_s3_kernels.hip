@@ -36,6 +36,19 @@
 
 namespace tg {
 
+// Diagnostic build only (scripts/probes/tower_s3_stamps.hip, -DTG_S3_STAMPS): s_memtime stamps of one workgroup's waves at the
+// phase boundaries of every layer of k_tower_s3_halo.  The product build compiles none of it.
+#ifdef TG_S3_STAMPS
+__device__ unsigned long long* g_s3_stamps = nullptr;  // [layer][wave][8]
+#define TG_S3_STAMP(layer, slot)                                                                                    \
+    do {                                                                                                            \
+        if (blockIdx.x == 8 && g_s3_stamps && (threadIdx.x & 63) == 0)                                              \
+            g_s3_stamps[((size_t)(layer) * 16 + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memtime();  \
+    } while (0)
+#else
+#define TG_S3_STAMP(layer, slot) do { } while (0)
+#endif
+
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
@@ -451,6 +464,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
     const int r16 = lane & 15, q = lane >> 4;
     const int ch0 = cg * 32;
 
+    TG_S3_STAMP(0, 6);
     // ---- stage the input: plain image, CP0 = 32·KC0 channels per row, hi/lo split, pitch + 16 B, one zero row ----
     constexpr int CP0 = 32 * KC0;
     constexpr int LS4 = (CP0 >> 2) + 1;
@@ -495,6 +509,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
     for (int idx = tid; idx < LS4; idx += NW * 64) lds4[rows * LS4 + idx] = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
 
+    TG_S3_STAMP(0, 0);
     // row tiles dealt to the row groups as evenly as they go (k_tower_halo)
     const int NRG = NW / NCG;
     const int ntiles = (PW * nsq + 15) >> 4;
@@ -524,6 +539,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
         } else {
             s3_mainloop<RTW, KC0>(lds4, wp, t1, wstride, LS4, rows, 0, n, rho0, q, vmask, acc);
         }
+        TG_S3_STAMP(0, 1);
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             const f32x4 bv = *(const f32x4*)&T.b[0][ch0 + 16 * t + 4 * q];
@@ -534,11 +550,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
                 acc[j][t] = v;
             }
         }
+        TG_S3_STAMP(0, 2);
         __syncthreads();  // every wave has finished reading the input image
-        const int cells = LEAD + PW * PS;
+        TG_S3_STAMP(0, 3);
+        const int cells = LEAD + PW * PS + 1;  // + the spare cell of the idle slots
         for (int idx = tid; idx < cells * P4; idx += NW * 64) {
             const int c = idx / P4 - LEAD;
-            const int o = c < 0 ? n * RS : c % PS;
+            const int o = c < 0 || c >= PW * PS ? n * RS : c % PS;
             if (o >= n * RS || o % RS == n) lds4[idx] = u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
@@ -558,29 +576,37 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
             }
             acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        TG_S3_STAMP(0, 4);
         __syncthreads();
+        TG_S3_STAMP(0, 5);
     }
     if (T.nlayers == 1) return;  // (never: a tower has at least one block)
 
     // ---- layers 1 … : slot (tile, lane) → square through the slot table ----
     const uint32_t wlane = (uint32_t)(((ch0 >> 4) * 128 + q * 16 + r16) * 16);  // this lane's 16 B inside a step of a layer's weights
-    int cell[RTW], rowid[RTW], addr4[RTW];
+    // idle slots (no square left for them) read the zero cell of position 0 and write a spare cell behind the image, so that
+    // the epilogue needs no per-tile branches (each would wait out its own LDS round trip)
+    int rowid[RTW], addr4[RTW], wb[RTW];  // wb: byte address of this lane's hi half-slot of channel tile 0 in its cell
 #pragma unroll
     for (int j = 0; j < RTW; j++) {
         const uint32_t e = j < my_tiles ? T.slotmap[(tile0 + j) * 16 + r16] : 0xFFFF0000u;
         rowid[j] = (int)(e >> 16);
-        cell[j] = rowid[j] == 0xFFFF ? LEAD + n * RS : (int)(e & 0xFFFFu);
-        addr4[j] = (cell[j] - LEAD) * P4 + q;
+        const bool idle = rowid[j] == 0xFFFF;
+        addr4[j] = ((idle ? LEAD + n * RS : (int)(e & 0xFFFFu)) - LEAD) * P4 + q;
+        wb[j] = ((idle ? LEAD + PW * PS : (int)(e & 0xFFFFu)) * P4 + cg * 8 + (q >> 1)) * 16 + (q & 1) * 8;
     }
+    char* const ldsb = (char*)lds;
     for (int layer = 1; layer < T.nlayers; layer++) {
+        TG_S3_STAMP(layer, 0);
 #pragma unroll
-        for (int j = 0; j < RTW; j++) asm volatile("" : "+v"(addr4[j]));  // keep the compiler from hoisting address sums out of the layer loop
+        for (int j = 0; j < RTW; j++) asm volatile("" : "+v"(addr4[j]), "+v"(wb[j]));  // keep the compiler from hoisting address sums out of the layer loop
         if (RTW > 1 && short_group) {
             f32x4 (&acs)[RTW - 1][2] = *reinterpret_cast<f32x4 (*)[RTW - 1][2]>(&acc[0][0]);
             s3_mainloop_halo<RTW - 1, KC, NB>(lds4, T.w[layer], wlane, wstride * 16, addr4, acs);
         } else {
             s3_mainloop_halo<RTW, KC, NB>(lds4, T.w[layer], wlane, wstride * 16, addr4, acc);
         }
+        TG_S3_STAMP(layer, 1);
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             const f32x4 bv = *(const f32x4*)&T.b[layer][ch0 + 16 * t + 4 * q];
@@ -601,33 +627,42 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
                 }
             break;
         }
+        TG_S3_STAMP(layer, 2);
         __syncthreads();  // every wave has finished reading the previous image
-        const bool conv1 = (layer & 1) == 1;
+        TG_S3_STAMP(layer, 3);
+        const bool conv1 = (layer & 1) == 1;  // next layer is conv2 of the same block: it starts from the block input
+        // half-slots of (cell, channel c = ch0 + 16t + 4q): tile t at + 32 B, lo at + 64 B
         f32x4 nxt[RTW][2];
+#pragma unroll
+        for (int j = 0; j < RTW; j++) nxt[j][0] = nxt[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (conv1) {
+            u32x2 sh[RTW][2], sl[RTW][2];
+#pragma unroll
+            for (int j = 0; j < RTW; j++)
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    sh[j][t] = *(const u32x2*)(ldsb + wb[j] + 32 * t);
+                    sl[j][t] = *(const u32x2*)(ldsb + wb[j] + 32 * t + 64);
+                }
+#pragma unroll
+            for (int j = 0; j < RTW; j++)
+#pragma unroll
+                for (int t = 0; t < 2; t++) nxt[j][t] = join4(sh[j][t], sl[j][t]);
+        }
 #pragma unroll
         for (int j = 0; j < RTW; j++)
 #pragma unroll
             for (int t = 0; t < 2; t++) {
-                nxt[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (conv1 && rowid[j] != 0xFFFF) {
-                    const u32x2* hp = half_slot(cell[j], ch0 + 16 * t + 4 * q);
-                    nxt[j][t] = join4(hp[0], hp[8]);
-                }
+                u32x2 hi, lo;
+                split4(acc[j][t], hi, lo);
+                *(u32x2*)(ldsb + wb[j] + 32 * t) = hi;
+                *(u32x2*)(ldsb + wb[j] + 32 * t + 64) = lo;
             }
 #pragma unroll
-        for (int j = 0; j < RTW; j++)
-#pragma unroll
-            for (int t = 0; t < 2; t++)
-                if (rowid[j] != 0xFFFF) {
-                    u32x2 hi, lo;
-                    split4(acc[j][t], hi, lo);
-                    u32x2* hp = half_slot(cell[j], ch0 + 16 * t + 4 * q);
-                    hp[0] = hi;
-                    hp[8] = lo;
-                }
-#pragma unroll
         for (int j = 0; j < RTW; j++) { acc[j][0] = nxt[j][0]; acc[j][1] = nxt[j][1]; }
+        TG_S3_STAMP(layer, 4);
         __syncthreads();
+        TG_S3_STAMP(layer, 5);
         if (OUT_SPLIT && layer + 1 == T.nlayers) {
             // the image holds the final activations in the split cell layout: copy the real cells out row by row, 16 B per lane
             const int spr = F >> 2;
@@ -953,7 +988,7 @@ static hipError_t launch_s3_t(hipStream_t st, const void* in, const TowerS3Param
 template <int RTW, int KC0, int KC, int NB, bool FROM_STATES, bool OUT_SPLIT, int NW>
 static hipError_t launch_s3_halo_t(hipStream_t st, const void* in, const TowerS3Params& T, float* out, int B, int PW, int NCG) {
     const size_t plain = (size_t)(PW * NB * NB + 1) * (32 * KC0 + 4) * sizeof(float);
-    const size_t halo = (size_t)(NB + 2 + PW * T.halo_ps) * (32 * KC + 4) * sizeof(float);
+    const size_t halo = (size_t)(NB + 2 + PW * T.halo_ps + 1) * (32 * KC + 4) * sizeof(float);  // + the spare cell
     const size_t lds = std::max(plain, halo);
     static size_t configured = 0;
     if (lds > configured) {
@@ -967,9 +1002,9 @@ static hipError_t launch_s3_halo_t(hipStream_t st, const void* in, const TowerS3
 
 bool tower_s3_halo_geometry(int n, int F, int* pw, int* ps) {
     // positions per workgroup as in launch_s3; strides as tower_halo_geometry (same pitch of F/4 + 1 slots)
-    if (n == 5 && F == 64) { *pw = 8; *ps = 36; return true; }    // 80 240 B: two workgroups per CU
-    if (n == 5 && F == 128) { *pw = 8; *ps = 37; return true; }   // 159 984 B
-    if (n == 6 && F == 128) { *pw = 4; *ps = 51; return true; }   // 111 936 B
+    if (n == 5 && F == 64) { *pw = 8; *ps = 36; return true; }    // 80 512 B with the spare cell: two workgroups per CU
+    if (n == 5 && F == 128) { *pw = 8; *ps = 37; return true; }   // 160 512 B
+    if (n == 6 && F == 128) { *pw = 4; *ps = 51; return true; }   // 112 464 B
     return false;
 }
 bool tower_s3_supported(int n, int F) { return (n == 5 && (F == 64 || F == 128)) || (n == 6 && F == 128); }

@@ -562,6 +562,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower_halo(const float* __restr
         for (int j = 0; j < RTW; j++) asm volatile("" : "+v"(addr4[j]));
         TG_STAMP(layer, 0);
         const float* wnext = T.w[layer + 1 < T.nlayers ? layer + 1 : layer];
+        const f32x4 bv = *(const f32x4*)&T.b[layer][ch0 + 4 * q];  // requested here: its latency passes under the main loop
         if (RTW > 1 && short_group) {
             f32x4 (&acs)[RTW - 1] = *reinterpret_cast<f32x4 (*)[RTW - 1]>(&acc[0]);
             conv_mainloop_halo<RTW - 1, CH, NB>(lds4, T.w[layer], wnext, wlane, addr4, acs, turn, w0, w1);
@@ -569,7 +570,6 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower_halo(const float* __restr
             conv_mainloop_halo<RTW, CH, NB>(lds4, T.w[layer], wnext, wlane, addr4, acc, turn, w0, w1);
         }
         TG_STAMP(layer, 1);
-        const f32x4 bv = *(const f32x4*)&T.b[layer][ch0 + 4 * q];
 #pragma unroll
         for (int j = 0; j < RTW; j++) {
             f32x4 v = acc[j] + bv;

@@ -165,24 +165,25 @@ __device__ __forceinline__ void s3_mainloop(const u32x4* __restrict__ lds4, cons
 #ifndef TG_S3_PROBE
 #define TG_S3_PROBE 0  // timing probes (wrong results): 1 = no fragment reads in the loop, 2 = no weight loads in the loop
 #endif
+struct S3W { u32x4 h0, l0, h1, l1; };  // one step of weights of a wave: hi / lo halves of its two 16-channel tiles
+// step kk of a layer at byte kk·wstep; inside a step this lane's four 16-byte slots 1 KB apart
+__device__ __forceinline__ S3W s3_load_w(const void* wlayer, int bytes, uint32_t wlane, int so) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)wlayer, 0, bytes, 0x00020000);
+    S3W w;
+    w.h0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, wlane, so, 0));
+    w.l0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, wlane + 1024, so, 0));
+    w.h1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, wlane + 2048, so, 0));
+    w.l1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, wlane + 3072, so, 0));
+    return w;
+}
+// w0 / w1 arrive holding steps 0 and 1 of this layer and leave holding those of `wnext` (same geometry), requested by the
+// last two steps: the epilogue and the barriers between two layers hide that latency (conv_mainloop_halo does the same).
 template <int NT, int KC, int NB, int NM>
-__device__ __forceinline__ void s3_mainloop_halo(const u32x4* __restrict__ lds4, const void* __restrict__ wlayer, uint32_t wlane, int wstep,
-                                                 const int (&addr4)[NM], f32x4 (&acc)[NT][2]) {
+__device__ __forceinline__ void s3_mainloop_halo(const u32x4* __restrict__ lds4, const void* __restrict__ wlayer, const void* __restrict__ wnext,
+                                                 uint32_t wlane, int wstep, const int (&addr4)[NM], f32x4 (&acc)[NT][2], S3W& w0, S3W& w1) {
     static_assert(NM >= NT, "an address for every row tile");
     constexpr int P4 = 8 * KC + 1, RS = NB + 1, ROW = 3 * KC, total = 9 * KC;
     constexpr int H1 = (NT + 1) / 2;
-    // the layer's weights: step kk at byte kk·wstep; inside a step this lane's 16 B of the hi / lo halves of its two 16-channel tiles
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wlayer, 0, total * wstep, 0x00020000);
-    struct W4 { u32x4 h0, l0, h1, l1; };
-    auto load_w = [&](int kk) {
-        W4 w;
-        const int so = kk * wstep;
-        w.h0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, so, 0));
-        w.l0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + 1024, so, 0));
-        w.h1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + 2048, so, 0));
-        w.l1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + 3072, so, 0));
-        return w;
-    };
 #define TG_S3_OFF(step) (((step) / KC) * P4 + ((step) % KC) * 8)
 #define TG_S3_MFMA(J0, J1)                                                                                              \
     _Pragma("unroll") for (int j = J0; j < J1; j++) {                                                                   \
@@ -203,9 +204,7 @@ __device__ __forceinline__ void s3_mainloop_halo(const u32x4* __restrict__ lds4,
     for (int j = 0; j < NT; j++) ad[j] = addr4[j];
 #pragma unroll
     for (int j = 0; j < (TG_S3_PROBE & 1 ? NT : H1); j++) { ah[j] = lds4[ad[j] + TG_S3_OFF(0)]; al[j] = lds4[ad[j] + TG_S3_OFF(0) + 4]; }
-    W4 w0 = load_w(0);
-    W4 w1 = load_w(1);
-    int wnext = 2;
+    int wchunk = 2;  // next step of weights to request
 #pragma unroll 1
     for (int dy = 0; dy < 3; dy++) {
 #pragma unroll
@@ -218,11 +217,17 @@ __device__ __forceinline__ void s3_mainloop_halo(const u32x4* __restrict__ lds4,
             TG_S3_MFMA(0, H1)
             __builtin_amdgcn_sched_barrier(0);
 #if TG_S3_PROBE & 2
-            const W4 w2 = w0;
+            const S3W w2 = w0;
 #else
-            const W4 w2 = load_w(wnext < total ? wnext : total - 1);
+            S3W w2;
+            if (s < ROW - 2) {
+                w2 = s3_load_w(wlayer, total * wstep, wlane, wchunk * wstep);
+            } else {  // the last two steps of a row of taps — of the layer when dy = 2: on to the next layer's first steps
+                const bool on = dy == 2;
+                w2 = s3_load_w(on ? wnext : wlayer, total * wstep, wlane, (on ? s - (ROW - 2) : wchunk) * wstep);
+            }
 #endif
-            wnext++;
+            wchunk++;
 #if TG_S3_PROBE & 1
             if (false) {
             } else if (s + 1 < ROW) {
@@ -523,6 +528,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
     for (int j = 0; j < RTW; j++) acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int t1 = 128, wstride = (F >> 4) * 128;
 
+    const uint32_t wlane = (uint32_t)(((ch0 >> 4) * 128 + q * 16 + r16) * 16);  // this lane's 16 B inside a step of a layer's weights
+    S3W w0, w1;  // the weight stream's two steps in flight between layers
+    w0.h0 = w0.l0 = w0.h1 = w0.l1 = u32x4{0u, 0u, 0u, 0u};
+    w1 = w0;
     // 8-byte half-slot of channel c inside a cell / row of the F-channel image: chunk c>>5, slot (c&31)>>3 (hi) / +4 (lo), half (c&7)>>2
     auto half_slot = [&](int cell, int c) { return (u32x2*)(lds4 + (size_t)cell * P4 + (c >> 5) * 8 + ((c & 31) >> 3)) + ((c & 7) >> 2); };
 
@@ -540,6 +549,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
             s3_mainloop<RTW, KC0>(lds4, wp, t1, wstride, LS4, rows, 0, n, rho0, q, vmask, acc);
         }
         TG_S3_STAMP(0, 1);
+        if (T.nlayers > 1) {  // in flight during the change of images
+            w0 = s3_load_w(T.w[1], 9 * KC * wstride * 16, wlane, 0);
+            w1 = s3_load_w(T.w[1], 9 * KC * wstride * 16, wlane, wstride * 16);
+        }
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             const f32x4 bv = *(const f32x4*)&T.b[0][ch0 + 16 * t + 4 * q];
@@ -583,7 +596,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
     if (T.nlayers == 1) return;  // (never: a tower has at least one block)
 
     // ---- layers 1 … : slot (tile, lane) → square through the slot table ----
-    const uint32_t wlane = (uint32_t)(((ch0 >> 4) * 128 + q * 16 + r16) * 16);  // this lane's 16 B inside a step of a layer's weights
     // idle slots (no square left for them) read the zero cell of position 0 and write a spare cell behind the image, so that
     // the epilogue needs no per-tile branches (each would wait out its own LDS round trip)
     int rowid[RTW], addr4[RTW], wb[RTW];  // wb: byte address of this lane's hi half-slot of channel tile 0 in its cell
@@ -600,19 +612,22 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
         TG_S3_STAMP(layer, 0);
 #pragma unroll
         for (int j = 0; j < RTW; j++) asm volatile("" : "+v"(addr4[j]), "+v"(wb[j]));  // keep the compiler from hoisting address sums out of the layer loop
+        const void* wnext = T.w[layer + 1 < T.nlayers ? layer + 1 : layer];
+        f32x4 bv[2];  // requested here: the latency passes under the main loop
+#pragma unroll
+        for (int t = 0; t < 2; t++) bv[t] = *(const f32x4*)&T.b[layer][ch0 + 16 * t + 4 * q];
         if (RTW > 1 && short_group) {
             f32x4 (&acs)[RTW - 1][2] = *reinterpret_cast<f32x4 (*)[RTW - 1][2]>(&acc[0][0]);
-            s3_mainloop_halo<RTW - 1, KC, NB>(lds4, T.w[layer], wlane, wstride * 16, addr4, acs);
+            s3_mainloop_halo<RTW - 1, KC, NB>(lds4, T.w[layer], wnext, wlane, wstride * 16, addr4, acs, w0, w1);
         } else {
-            s3_mainloop_halo<RTW, KC, NB>(lds4, T.w[layer], wlane, wstride * 16, addr4, acc);
+            s3_mainloop_halo<RTW, KC, NB>(lds4, T.w[layer], wnext, wlane, wstride * 16, addr4, acc, w0, w1);
         }
         TG_S3_STAMP(layer, 1);
 #pragma unroll
         for (int t = 0; t < 2; t++) {
-            const f32x4 bv = *(const f32x4*)&T.b[layer][ch0 + 16 * t + 4 * q];
 #pragma unroll
             for (int j = 0; j < RTW; j++) {
-                f32x4 v = acc[j][t] + bv;
+                f32x4 v = acc[j][t] + bv[t];
                 v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f);
                 acc[j][t] = v;
             }
@@ -680,11 +695,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
                     const uint32_t hlane = (uint32_t)(((hc0 >> 4) * 128 + q * 16 + r16) * 16);
 #pragma unroll
                     for (int j = 0; j < RTW; j++) asm volatile("" : "+v"(addr4[j]));
+                    w0 = s3_load_w(T.head_w, 9 * KC * hstride * 16, hlane, 0);
+                    w1 = s3_load_w(T.head_w, 9 * KC * hstride * 16, hlane, hstride * 16);
                     if (RTW > 1 && short_group) {
                         f32x4 (&acs)[RTW - 1][2] = *reinterpret_cast<f32x4 (*)[RTW - 1][2]>(&acc[0][0]);
-                        s3_mainloop_halo<RTW - 1, KC, NB>(lds4, T.head_w, hlane, hstride * 16, addr4, acs);
+                        s3_mainloop_halo<RTW - 1, KC, NB>(lds4, T.head_w, T.head_w, hlane, hstride * 16, addr4, acs, w0, w1);
                     } else {
-                        s3_mainloop_halo<RTW, KC, NB>(lds4, T.head_w, hlane, hstride * 16, addr4, acc);
+                        s3_mainloop_halo<RTW, KC, NB>(lds4, T.head_w, T.head_w, hlane, hstride * 16, addr4, acc, w0, w1);
                     }
 #pragma unroll
                     for (int t = 0; t < 2; t++) {

@@ -1,4 +1,5 @@
-// Where a K-step of the policy FC (k_fc_lds, C2 shape: 4096 × 1600 → 1664) spends its cycles: s_memtime stamps of workgroup 0.
+// Where a K-step of the barrier version of the policy FC (k_fc_lds, C2 shape: 4096 × 1600 → 1664; run with TG_FC_BARRIER=1)
+// spends its cycles: s_memtime stamps of workgroup 0.
 // hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DTG_TOWER_STAMPS -I../../tak_amd/csrc fc_stamps.hip -o _bin/fc_stamps
 #include <cstdio>
 #include <vector>

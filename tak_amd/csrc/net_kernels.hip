@@ -789,6 +789,167 @@ __global__ __launch_bounds__(512) void k_fc_lds(const float* __restrict__ A, int
 }
 
 
+// k_fc_lds without workgroup barriers in the loop (the default for full batches; TG_FC_BARRIER=1 selects k_fc_lds for A/B).
+// Three weight buffers of one K-step form a ring filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, no
+// ds_write phase, 16 cache lines per instruction); the eight waves synchronise through two sets of monotonic counters
+// in LDS instead of s_barrier:
+//   ready[b] += 1 by every wave once its share of the K-step now in buffer b has landed (s_waitcnt vmcnt),
+//   done[b]  += 1 by every wave once it has read the last fragment of the K-step in buffer b.
+// A wave reads step s after ready[s % 3] = 8·(s/3 + 1) and refills buffer (s + 2) % 3 — in the MIDDLE of step s, half a
+// step after it finished reading it itself — after done[(s + 2) % 3] = 8·⌊(s + 2)/3⌋.  Both flags are read half a chunk
+// before they are needed and normally hold by then, so no wave waits out a round trip and the waves may drift half a step
+// apart instead of draining the MFMA pipe at a barrier every 17 k cycles.  Same products in the same order as k_fc_lds →
+// identical bits.  Measured (C2, 4096 rows): 173 – 175 µs against 178 – 180 µs; with neither refills nor flags the loop
+// takes 159 µs (of which ≈ 10 µs are the first fill and the 27 MB output burst), the flags alone cost 10 µs (waves held
+// back for a slower one run their SIMD alone), the refills alone 12 µs.  Fair-priority and operand-order variants: no change.
+constexpr int FC_RING = 3;
+constexpr int FC_RING_SLOTS = 4 * FC_PLANE;                                        // f32x4 slots per buffer (3328)
+constexpr size_t FC_RING_LDS = (size_t)FC_RING * FC_RING_SLOTS * 16 + 2 * FC_RING * sizeof(uint32_t);
+// flags are read and bumped with explicit LDS instructions: a volatile access through a generic pointer becomes a flat load
+// with s_waitcnt vmcnt(0), which would drain the LDS-DMA loads in flight at every poll
+__device__ __forceinline__ void fc_ring_wait(uint32_t flag_addr, uint32_t target) {
+    for (;;) {
+        uint32_t v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(flag_addr) : "memory");
+        if (__builtin_amdgcn_readfirstlane((int)v) >= (int)target) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+__device__ __forceinline__ void fc_ring_signal(uint32_t flag_addr) {
+    if ((threadIdx.x & 63) == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(flag_addr), "v"(1u) : "memory");
+}
+__global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, int lda, const float* __restrict__ Wp,
+                                                 const float* __restrict__ bias, float* __restrict__ out, int M, int K, int NP,
+                                                 int out_stride, int n_valid, int a_frag) {
+    extern __shared__ __attribute__((aligned(16))) float fc_ring_lds[];
+    f32x4* wl = (f32x4*)fc_ring_lds;                                // [FC_RING][chunk][output tile][q][r16]
+    uint32_t* flags = (uint32_t*)(wl + FC_RING * FC_RING_SLOTS);    // ready[FC_RING], done[FC_RING]
+    const uint32_t ready0 = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)flags;  // LDS byte addresses
+    const uint32_t done0 = ready0 + FC_RING * 4;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int row = blockIdx.x * 128 + wave * 16 + r16;
+    const bool row_ok = row < M;
+    const int n0 = blockIdx.y * FC_COLS;
+    const int last_tile = (M - 1) >> 4;
+    const int my_tile = min(blockIdx.x * 8 + wave, last_tile);
+    const f32x4* ap = a_frag ? (const f32x4*)A + (size_t)my_tile * (K >> 4) * 64 + r16 * 4 + q
+                             : (const f32x4*)(A + (size_t)(row_ok ? row : M - 1) * lda) + q;
+    const size_t achunk = a_frag ? 64 : 4;
+    const f32x4* wg = (const f32x4*)Wp;  // slot (chunk, col, q) at (chunk*NP + col)*4 + q
+    const int nsteps = K / FC_KSTEP;
+    const int nchunks = nsteps * 4;
+
+    // LDS-DMA: one wave-instruction fills 64 consecutive slots of a buffer (1 KB) = one (chunk, output tile) block, slot
+    // q·16 + r16 inside it — the lane number of its reader, so the fragment reads are contiguous and conflict free — from
+    // the block's 1 KB of the weight matrix (slot r16·4 + q: the permutation is on the source side, 16 cache lines per
+    // instruction).  52 blocks per K-step, block i = wave + 8u by this wave (7 for waves 0-3, 6 for waves 4-7).
+    uint32_t src0[7];
+#pragma unroll
+    for (int u = 0; u < 7; u++) {
+        int blk = wave + 8 * u;
+        blk = blk < FC_RING_SLOTS / 64 ? blk : FC_RING_SLOTS / 64 - 1;
+        const int c = blk / FC_CT, j = blk - c * FC_CT;
+        src0[u] = (uint32_t)(((size_t)c * NP + n0 + j * 16 + r16) * 4 + q);
+    }
+    const uint32_t step_slots = (uint32_t)(4 * NP * 4);  // f32x4 slots of the weights per K-step
+    auto fill = [&](int step, int buf) {
+#pragma unroll
+        for (int u = 0; u < 7; u++)
+            if (wave + 8 * u < FC_RING_SLOTS / 64)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wg + (size_t)step * step_slots + src0[u]),
+                                                 (__attribute__((address_space(3))) void*)(wl + buf * FC_RING_SLOTS + (wave + 8 * u) * 64), 16, 0, 0);
+    };
+#ifndef TG_RING_PROBE
+#define TG_RING_PROBE 0  // timing probes (wrong results): 1 = no refills and no flags, 2 = no activation stream, 8 = MFMA operands swapped, 16 = flags only, 32 = refills only
+#endif
+    auto aload = [&](int kc) { return ap[(size_t)((TG_RING_PROBE & 2) ? 0 : (kc < nchunks ? kc : nchunks - 1)) * achunk]; };
+    if (tid < 2 * FC_RING) flags[tid] = 0u;
+    __syncthreads();
+    fill(0, 0);
+    if (nsteps > 1) fill(1, 1);
+    f32x4 acc[FC_CT];
+#pragma unroll
+    for (int j = 0; j < FC_CT; j++) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // Activations: hipcc waits vmcnt(0) wherever the result of an ordinary load is consumed while an LDS-DMA load may be in
+    // flight, and loads return in order.  So the four chunks up to the middle of the next step are requested at the top of
+    // a step and forced to complete right before the refill is issued (two chunks later): no activation load is ever queued
+    // behind a young refill, whose data comes from the MALL or HBM and takes its time.
+    f32x4 a0 = aload(0), a1 = aload(1), a2, a3, b0, b1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    fc_ring_signal(ready0);
+    if (nsteps > 1) fc_ring_signal(ready0 + 4);
+    // One chunk: the 13 weight fragments in two halves (7 + 6 output tiles); each half is requested while the other half's
+    // MFMAs run, across chunk boundaries inside a step (the tower's half-tile pipeline, conv_mainloop.cuh).
+    constexpr int FC_H1 = 7;
+    f32x4 w[FC_CT];
+#define TG_FC_LOAD(C, J0, J1) _Pragma("unroll") for (int j = J0; j < J1; j++) w[j] = wb[((C) * FC_CT + j) * 64 + lane];
+#define TG_FC_MFMA(AV, J0, J1)                                                                                       \
+    _Pragma("unroll") for (int t = 0; t < 4; t++)                                                                    \
+        _Pragma("unroll") for (int j = J0; j < J1; j++)                                                              \
+            acc[j] = (TG_RING_PROBE & 8) ? __builtin_amdgcn_mfma_f32_16x16x4f32((AV)[t], w[j][t], acc[j], 0, 0, 0)        \
+                                         : __builtin_amdgcn_mfma_f32_16x16x4f32(w[j][t], (AV)[t], acc[j], 0, 0, 0);
+#define TG_FC_CHUNK(C, AV, NEXT, EARLY)                                                                              \
+    TG_FC_LOAD(C, FC_H1, FC_CT)                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    TG_FC_MFMA(AV, 0, FC_H1)                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    if (NEXT) { TG_FC_LOAD((C) + 1, 0, FC_H1) }                                                                      \
+    EARLY;                                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    TG_FC_MFMA(AV, FC_H1, FC_CT)                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);
+    const volatile __attribute__((address_space(3))) uint32_t* flag_lds = (const volatile __attribute__((address_space(3))) uint32_t*)flags;
+    uint32_t early_ready = 0u, early_done = 0u;
+    for (int step = 0; step < nsteps; step++) {
+        const int buf = step % FC_RING;
+        const f32x4* wb = wl + buf * FC_RING_SLOTS;
+        // (the flags were read half a chunk ago, under the MFMAs: they normally hold already and nobody waits out a round trip)
+        if (!(TG_RING_PROBE & (1 | 32)) && (int)__builtin_amdgcn_readfirstlane((int)early_ready) < 8 * (step / FC_RING + 1))
+            fc_ring_wait(ready0 + 4 * buf, 8u * (uint32_t)(step / FC_RING + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        TG_FC_LOAD(0, 0, FC_H1)
+        a2 = aload(step * 4 + 2);
+        a3 = aload(step * 4 + 3);
+        b0 = aload(step * 4 + 4);
+        b1 = aload(step * 4 + 5);
+        __builtin_amdgcn_sched_barrier(0);
+        TG_FC_CHUNK(0, a0, true, (void)0)
+        TG_FC_CHUNK(1, a1, true, early_done = flag_lds[FC_RING + (step + 2) % FC_RING])
+        // the middle of the step: signal the step after this one, refill the buffer of the step before it
+        asm volatile("" : "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1));  // the compiler's own wait for the four loads above …
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // … which, loads returning in order, covers last step's refill too
+        if (!(TG_RING_PROBE & (1 | 32)) && step >= 1 && step + 1 < nsteps) fc_ring_signal(ready0 + 4 * ((step + 1) % FC_RING));
+        if (!(TG_RING_PROBE & 1) && step + 2 < nsteps) {
+            if (!(TG_RING_PROBE & 32) && (int)__builtin_amdgcn_readfirstlane((int)early_done) < 8 * ((step + 2) / FC_RING))
+                fc_ring_wait(done0 + 4 * ((step + 2) % FC_RING), 8u * (uint32_t)((step + 2) / FC_RING));
+            if (!(TG_RING_PROBE & 16)) fill(step + 2, (step + 2) % FC_RING);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        TG_FC_CHUNK(2, a2, true, (void)0)
+        TG_FC_CHUNK(3, a3, false, early_ready = flag_lds[(step + 1) % FC_RING])
+        if (!(TG_RING_PROBE & (1 | 32))) fc_ring_signal(done0 + 4 * buf);
+        a0 = b0;
+        a1 = b1;
+    }
+#undef TG_FC_LOAD
+#undef TG_FC_MFMA
+#undef TG_FC_CHUNK
+    if (row_ok) {
+#pragma unroll
+        for (int j = 0; j < FC_CT; j++) {
+            const int nn = n0 + j * 16 + 4 * q;
+            if (nn < n_valid) {
+                f32x4 v = acc[j] + *(const f32x4*)&bias[nn];
+                float* o = out + (size_t)row * out_stride + nn;
+                if (nn + 3 < n_valid) *(f32x4*)o = v;
+                else for (int t = 0; t < 4; t++) if (nn + t < n_valid) o[t] = v[t];
+            }
+        }
+    }
+}
+
 // The same FC for SMALL batches (host-driven MCTS evaluates 16–32 leaves per call; Player, pit): k_fc_lds gives a row block
 // of 128 positions to one workgroup and needs ≥ 4096 rows to fill the chip, so a 32-row call took as long as a 4096-row
 // one.  Here a wave owns one 16-row tile × 2 output tiles and streams both operands straight from global (no LDS, no
@@ -1239,6 +1400,17 @@ hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp,
     }
     if (NP % FC_COLS == 0 && K % FC_KSTEP == 0) {
         dim3 grid((M + 127) / 128, NP / FC_COLS);
+        static const bool ring = getenv("TG_FC_BARRIER") == nullptr;  // A/B switch: the version with a workgroup barrier per K-step
+        if (ring) {
+            static bool configured = false;
+            if (!configured) {
+                hipError_t e = hipFuncSetAttribute((const void*)k_fc_ring, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FC_RING_LDS);
+                if (e != hipSuccess) return e;
+                configured = true;
+            }
+            hipLaunchKernelGGL(k_fc_ring, grid, dim3(512), FC_RING_LDS, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid, a_frag ? 1 : 0);
+            return hipGetLastError();
+        }
         hipLaunchKernelGGL(k_fc_lds, grid, dim3(512), 0, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid, a_frag ? 1 : 0);
         return hipGetLastError();
     }

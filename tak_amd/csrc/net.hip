@@ -193,8 +193,11 @@ hipError_t upload_conv_s3(const Folded& f, int O, int I, int KC, DevBuf& buf, in
                         float v = f.w[((size_t)o * I + c) * 9 + tap];
                         uint16_t hi = f32_to_bf16(v);
                         uint16_t lo = f32_to_bf16(v - bf16_to_f32(hi));
-                        // [chunk][tile of 16 couts][hi|lo][q][cout in tile][8 bf16]
-                        size_t slot = (((((size_t)tap * KC + kc) * (OP / 16) + o / 16) * 2) * 4 + q) * 16 + o % 16;
+                        // [chunk][tile of 16 couts][hi|lo][q][cout in tile][8 bf16].  A wave computes two tiles = 32 output channels;
+                        // the MFMA leaves rows 4q' … 4q' + 3 of a tile in lane group q', so channel 8q' + 4t + i of the 32 goes to
+                        // row 4q' + i of tile t: lane group q' then holds channels 8q' … 8q' + 7 — one 16-byte slot of the split image
+                        const int o32 = o & 31, tile = (o >> 5) * 2 + ((o32 >> 2) & 1), row = (o32 >> 3) * 4 + (o32 & 3);
+                        size_t slot = (((((size_t)tap * KC + kc) * (OP / 16) + tile) * 2) * 4 + q) * 16 + row;
                         w[slot * 8 + j] = hi;
                         w[(slot + 64) * 8 + j] = lo;
                     }

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3(const voi
         // ---- epilogue: lane holds out[row rho0 + 16j][ch0 + 16t + 4q .. +3] ----
 #pragma unroll
         for (int t = 0; t < 2; t++) {
-            const f32x4 bv = *(const f32x4*)&T.b[layer][ch0 + 16 * t + 4 * q];
+            const f32x4 bv = *(const f32x4*)&T.b[layer][ch0 + 8 * q + 4 * t];
 #pragma unroll
             for (int j = 0; j < RTW; j++) {
                 f32x4 v = acc[j][t] + bv;
@@ -377,7 +377,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3(const voi
         __syncthreads();  // every wave has finished reading the previous image
         const int LS4n = (F >> 2) + 2;
         const bool conv1 = (layer & 1) == 1;  // next layer is conv2 of the same block: it starts from the block input
-        // 8-byte half-slot of (row, channel c = ch0 + 16t + 4q): chunk c>>5, slot (c&31)>>3 (hi) / 4 + that (lo), half (c&7)>>2
+        // 8-byte half-slot of (row, channel c = ch0 + 8q + 4t — see upload_conv_s3 for the order of a wave's 32 output channels):
+        // chunk c>>5, slot (c&31)>>3 = q (hi) / 4 + q (lo), half (c&7)>>2 = t
         f32x4 nxt[RTW][2];
 #pragma unroll
         for (int j = 0; j < RTW; j++)
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3(const voi
             for (int t = 0; t < 2; t++) {
                 nxt[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (S3_PROBE != 1 && conv1 && rho0 + j * 16 < rows) {
-                    const int c = ch0 + 16 * t + 4 * q;
+                    const int c = ch0 + 8 * q + 4 * t;
                     const u32x2* p = (const u32x2*)(lds4 + (size_t)(rho0 + j * 16) * LS4n + (c >> 5) * 8 + ((c & 31) >> 3)) + ((c & 7) >> 2);
                     nxt[j][t] = join4(p[0], p[8]);  // hi slot, lo slot (+4 slots = 64 B)
                 }
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3(const voi
 #pragma unroll
             for (int t = 0; t < 2; t++)
                 if (S3_PROBE != 1 && rho0 + j * 16 < rows) {
-                    const int c = ch0 + 16 * t + 4 * q;
+                    const int c = ch0 + 8 * q + 4 * t;
                     u32x2 hi, lo;
                     split4(acc[j][t], hi, lo);
                     u32x2* p = (u32x2*)(lds4 + (size_t)(rho0 + j * 16) * LS4 + (c >> 5) * 8 + ((c & 31) >> 3)) + ((c & 7) >> 2);
@@ -434,11 +435,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3(const voi
                     }
 #pragma unroll
                     for (int t = 0; t < 2; t++) {
-                        const f32x4 bv = *(const f32x4*)&T.head_b[hc0 + 16 * t + 4 * q];
+                        const f32x4 bv = *(const f32x4*)&T.head_b[hc0 + 8 * q + 4 * t];
 #pragma unroll
                         for (int j = 0; j < RTW; j++)
                             if (rho0 + j * 16 < rows)
-                                *(f32x4*)&T.head_out[((size_t)pos0 * nsq + rho0 + j * 16) * T.head_cout + hc0 + 16 * t + 4 * q] = acc[j][t] + bv;
+                                *(f32x4*)&T.head_out[((size_t)pos0 * nsq + rho0 + j * 16) * T.head_cout + hc0 + 8 * q + 4 * t] = acc[j][t] + bv;
                     }
                 }
             }
@@ -532,8 +533,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
     S3W w0, w1;  // the weight stream's two steps in flight between layers
     w0.h0 = w0.l0 = w0.h1 = w0.l1 = u32x4{0u, 0u, 0u, 0u};
     w1 = w0;
-    // 8-byte half-slot of channel c inside a cell / row of the F-channel image: chunk c>>5, slot (c&31)>>3 (hi) / +4 (lo), half (c&7)>>2
-    auto half_slot = [&](int cell, int c) { return (u32x2*)(lds4 + (size_t)cell * P4 + (c >> 5) * 8 + ((c & 31) >> 3)) + ((c & 7) >> 2); };
 
     // ---- layer 0 on the plain image: tile t = rows 16t … 16t + 15 ----
     {
@@ -555,7 +554,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
         }
 #pragma unroll
         for (int t = 0; t < 2; t++) {
-            const f32x4 bv = *(const f32x4*)&T.b[0][ch0 + 16 * t + 4 * q];
+            const f32x4 bv = *(const f32x4*)&T.b[0][ch0 + 8 * q + 4 * t];
 #pragma unroll
             for (int j = 0; j < RTW; j++) {
                 f32x4 v = acc[j][t] + bv;
@@ -578,14 +577,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
             if (j < my_tiles && rho < PW * nsq) {
                 const int p = rho / nsq, sq = rho - p * nsq, y = sq / n, x = sq - y * n;
                 const int cell = LEAD + p * PS + y * RS + x;
-#pragma unroll
-                for (int t = 0; t < 2; t++) {
-                    u32x2 hi, lo;
-                    split4(acc[j][t], hi, lo);
-                    u32x2* hp = half_slot(cell, ch0 + 16 * t + 4 * q);
-                    hp[0] = hi;
-                    hp[8] = lo;
-                }
+                u32x2 h0, l0, h1, l1;
+                split4(acc[j][0], h0, l0);
+                split4(acc[j][1], h1, l1);
+                u32x4* sp = lds4 + (size_t)cell * P4 + cg * 8 + q;
+                sp[0] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+                sp[4] = u32x4{l0[0], l0[1], l1[0], l1[1]};
             }
             acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -598,14 +595,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
     // ---- layers 1 … : slot (tile, lane) → square through the slot table ----
     // idle slots (no square left for them) read the zero cell of position 0 and write a spare cell behind the image, so that
     // the epilogue needs no per-tile branches (each would wait out its own LDS round trip)
-    int rowid[RTW], addr4[RTW], wb[RTW];  // wb: byte address of this lane's hi half-slot of channel tile 0 in its cell
+    int rowid[RTW], addr4[RTW], wb[RTW];  // wb: byte address of this lane's hi slot (its 8 output channels) in its cell
 #pragma unroll
     for (int j = 0; j < RTW; j++) {
         const uint32_t e = j < my_tiles ? T.slotmap[(tile0 + j) * 16 + r16] : 0xFFFF0000u;
         rowid[j] = (int)(e >> 16);
         const bool idle = rowid[j] == 0xFFFF;
         addr4[j] = ((idle ? LEAD + n * RS : (int)(e & 0xFFFFu)) - LEAD) * P4 + q;
-        wb[j] = ((idle ? LEAD + PW * PS : (int)(e & 0xFFFFu)) * P4 + cg * 8 + (q >> 1)) * 16 + (q & 1) * 8;
+        wb[j] = ((idle ? LEAD + PW * PS : (int)(e & 0xFFFFu)) * P4 + cg * 8 + q) * 16;
     }
     char* const ldsb = (char*)lds;
     for (int layer = 1; layer < T.nlayers; layer++) {
@@ -615,7 +612,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
         const void* wnext = T.w[layer + 1 < T.nlayers ? layer + 1 : layer];
         f32x4 bv[2];  // requested here: the latency passes under the main loop
 #pragma unroll
-        for (int t = 0; t < 2; t++) bv[t] = *(const f32x4*)&T.b[layer][ch0 + 16 * t + 4 * q];
+        for (int t = 0; t < 2; t++) bv[t] = *(const f32x4*)&T.b[layer][ch0 + 8 * q + 4 * t];
         if (RTW > 1 && short_group) {
             f32x4 (&acs)[RTW - 1][2] = *reinterpret_cast<f32x4 (*)[RTW - 1][2]>(&acc[0][0]);
             s3_mainloop_halo<RTW - 1, KC, NB>(lds4, T.w[layer], wnext, wlane, wstride * 16, addr4, acs, w0, w1);
@@ -636,9 +633,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
 #pragma unroll
             for (int j = 0; j < RTW; j++)
                 if (rowid[j] < rows) {
-                    float* o = out + ((size_t)pos0 * nsq + rowid[j]) * F + ch0 + 4 * q;
+                    float* o = out + ((size_t)pos0 * nsq + rowid[j]) * F + ch0 + 8 * q;
                     *(f32x4*)o = acc[j][0];
-                    *(f32x4*)(o + 16) = acc[j][1];
+                    *(f32x4*)(o + 4) = acc[j][1];
                 }
             break;
         }
@@ -646,33 +643,32 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
         __syncthreads();  // every wave has finished reading the previous image
         TG_S3_STAMP(layer, 3);
         const bool conv1 = (layer & 1) == 1;  // next layer is conv2 of the same block: it starts from the block input
-        // half-slots of (cell, channel c = ch0 + 16t + 4q): tile t at + 32 B, lo at + 64 B
+        // the lane's 8 channels ch0 + 8q … + 7 (tile 0: the first four, tile 1: the others) are one hi slot and one lo slot of
+        // its cell — the slots the main loop reads with the same lanes, so these accesses are conflict free as well
         f32x4 nxt[RTW][2];
 #pragma unroll
         for (int j = 0; j < RTW; j++) nxt[j][0] = nxt[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (conv1) {
-            u32x2 sh[RTW][2], sl[RTW][2];
+            u32x4 sh[RTW], sl[RTW];
 #pragma unroll
-            for (int j = 0; j < RTW; j++)
+            for (int j = 0; j < RTW; j++) {
+                sh[j] = *(const u32x4*)(ldsb + wb[j]);
+                sl[j] = *(const u32x4*)(ldsb + wb[j] + 64);
+            }
 #pragma unroll
-                for (int t = 0; t < 2; t++) {
-                    sh[j][t] = *(const u32x2*)(ldsb + wb[j] + 32 * t);
-                    sl[j][t] = *(const u32x2*)(ldsb + wb[j] + 32 * t + 64);
-                }
-#pragma unroll
-            for (int j = 0; j < RTW; j++)
-#pragma unroll
-                for (int t = 0; t < 2; t++) nxt[j][t] = join4(sh[j][t], sl[j][t]);
+            for (int j = 0; j < RTW; j++) {
+                nxt[j][0] = join4(u32x2{sh[j][0], sh[j][1]}, u32x2{sl[j][0], sl[j][1]});
+                nxt[j][1] = join4(u32x2{sh[j][2], sh[j][3]}, u32x2{sl[j][2], sl[j][3]});
+            }
         }
 #pragma unroll
-        for (int j = 0; j < RTW; j++)
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                u32x2 hi, lo;
-                split4(acc[j][t], hi, lo);
-                *(u32x2*)(ldsb + wb[j] + 32 * t) = hi;
-                *(u32x2*)(ldsb + wb[j] + 32 * t + 64) = lo;
-            }
+        for (int j = 0; j < RTW; j++) {
+            u32x2 h0, l0, h1, l1;
+            split4(acc[j][0], h0, l0);
+            split4(acc[j][1], h1, l1);
+            *(u32x4*)(ldsb + wb[j]) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+            *(u32x4*)(ldsb + wb[j] + 64) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+        }
 #pragma unroll
         for (int j = 0; j < RTW; j++) { acc[j][0] = nxt[j][0]; acc[j][1] = nxt[j][1]; }
         TG_S3_STAMP(layer, 4);
@@ -705,11 +701,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
                     }
 #pragma unroll
                     for (int t = 0; t < 2; t++) {
-                        const f32x4 bv = *(const f32x4*)&T.head_b[hc0 + 16 * t + 4 * q];
+                        const f32x4 bv = *(const f32x4*)&T.head_b[hc0 + 8 * q + 4 * t];
 #pragma unroll
                         for (int j = 0; j < RTW; j++)
                             if (rowid[j] < rows)
-                                *(f32x4*)&T.head_out[((size_t)pos0 * nsq + rowid[j]) * T.head_cout + hc0 + 16 * t + 4 * q] = acc[j][t] + bv;
+                                *(f32x4*)&T.head_out[((size_t)pos0 * nsq + rowid[j]) * T.head_cout + hc0 + 8 * q + 4 * t] = acc[j][t] + bv;
                     }
                 }
             }

@@ -3,17 +3,25 @@
 // Replaces the libtorch ops behind reference alpha-tak/src/model/{net5,net6,res_block}.rs
 // (conv2d 3×3 pad 1 + batch_norm(eval) + relu + residual add, linear, softmax, tanh).
 //
-// Layout: activations are NHWC — row m = (position b, square sq), F contiguous channels — so a
-// 3×3 convolution is an implicit GEMM  out[m][o] = Σ_{tap,c} X[nbr(m,tap)][c] · W[tap,c][o]  with
-// M = B·N² rows, K = 9·C.  Halos never cross positions, so a workgroup stages the whole positions
-// its row tile touches into LDS once (plus one all-zero row that out-of-board taps point at) and
-// every tap is just a different LDS row offset: im2col lives in address arithmetic only.
-// MFMA: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate — bit-exact fmaf chains, the parity path;
-// 157 TF peak).  Each lane feeds 4 consecutive k of its row/column from one 16-byte load, so the
-// K order inside a group of 8 is (k, k+4) pairs; weights are pre-permuted to [K/8][Cout][8] on
-// the host so the B fragment is one coalesced 16-byte global load per lane (L2-resident: a whole
-// layer is ≤ 590 KB).  BatchNorm (eval) is folded into weights/bias at load time; bias, residual
-// and ReLU are fused into the accumulator epilogue.
+// Layout: activations are NHWC — row m = (position b, square sq), F contiguous channels — so a 3×3 convolution is an
+// implicit GEMM  out[m][o] = Σ_{tap,c} X[nbr(m,tap)][c] · W[tap,c][o]  with M = B·N² rows, K = 9·C.  Halos never cross
+// positions, so a workgroup keeps whole positions in LDS and a tap is an LDS offset: im2col lives in address arithmetic.
+// Arithmetic: v_mfma_f32_16x16x4_f32 in the fused towers and the policy FC, v_mfma_f32_32x32x2_f32 in the generic per-layer
+// kernels — f32 in, f32 accumulate, bit-exact fmaf chains (the parity path; 157.3 TFLOP/s peak).  BatchNorm (eval) is
+// folded into weights / bias at load time; bias, residual and ReLU are fused into the accumulator epilogue.
+//
+// Kernels, in the order of the file:
+//   k_conv3x3, k_conv_pos   one 3×3 layer (shapes the fused towers do not cover; the conv policy head of Net6)
+//   k_tower                 conv0 + the whole residual tower in ONE launch on the plain LDS image (one zero row for
+//                           off-board taps, per-tap masks): batches below 2048 / 1024 / 512 positions
+//   k_tower_halo            the same tower on the HALO image (zero cells between board rows and positions, taps as
+//                           ds_read immediates, conflict-free slot table): full batches, 89 – 94 % of the MFMA peak
+//   k_gemm, k_fc_lds        generic GEMM; policy FC with a workgroup barrier per K-step (A/B reference)
+//   k_fc_ring               policy FC for full batches: LDS-DMA ring of three K-steps, flag counters instead of barriers
+//   k_fc_small              policy FC for ≤ 512 rows (no LDS, no barrier)
+//   k_softmax(_conv), k_value_head
+// Every variant of a layer type performs the same products in the same order: a position's outputs are the same bits
+// whatever batch (and therefore kernel) evaluates it (tests/test_gpu_net.py, tests/test_gpu_variants.py).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

@@ -8,15 +8,18 @@
 // well inside the 1e-4 of BASELINE.json's north_star; plain bf16 (one pass) would miss it by 10×.
 // This is the throughput variant of SURVEY.md §7 step 5; the exact-f32 tower (net_kernels.hip) stays the default.
 //
-// Structure = k_tower: a workgroup keeps PW whole positions in LDS for all 1+2R layers, one launch.  LDS row of a
-// board square: per chunk of 32 channels eight 16-byte slots — hi of the channel groups q = 0..3, then lo of q = 0..3 —
-// and 32 B of padding per row (the f32 row size + 32 B).  An MFMA B operand (32 k × 16 rows) is two ds_read_b128 per
-// lane (its row, slots q and 4+q of the chunk): ds_read_b128 is served in lane groups that pair 8 rows of one q with 8
-// rows of the next (MI355X_MICROARCH.md §LDS); with this pitch the rows of a group fall on the even 16-byte bank groups
-// and neighbouring q on the odd ones, so the reads are conflict free (hi|lo interleaved per q at pitch +16 B was 2-way on
-// every read and LDS-bound).  The A operand (16 output channels × 32 k) is two 16-B global loads of the pre-split
-// weights [chunk][cout][q][hi|lo].
-// A wave owns CTW = 2 channel tiles × RTW row tiles, so every activation fragment feeds 6 MFMAs.
+// Structure = the f32 towers: a workgroup keeps PW whole positions in LDS for all 1+2R layers, one launch.
+//   k_tower_s3        plain LDS image (batches below 256 positions).  Row of a board square: per chunk of 32 channels eight
+//                     16-byte slots — hi of the channel groups q = 0..3, then lo of q = 0..3 — and 32 B of padding; a zero
+//                     REGION for off-board taps.  An MFMA B operand (32 k × 16 rows) is two ds_read_b128 per lane (slots q
+//                     and 4 + q of the chunk); ds_read_b128 is served in lane groups that pair 8 rows of one q with 8 rows
+//                     of the next (MI355X_MICROARCH.md §LDS), and this pitch keeps a group on 16 distinct bank quads.
+//   k_tower_s3_halo   the halo image of k_tower_halo (net_kernels.hip): cell pitch F/4 + 1 slots, the same slot table,
+//                     taps as ds_read immediates, pinned half-tile pipeline, weight stream across layers.  Full batches.
+// The A operand (16 output channels × 32 k) is two 16-B loads of the pre-split weights [chunk][tile][hi|lo][q][cout]; a wave
+// owns 2 channel tiles × RTW row tiles (every activation fragment feeds 6 MFMAs) and its 32 output channels are ordered so
+// that lane group q ends up with channels 8q … 8q + 7 — one hi and one lo slot of the image (net.hip upload_conv_s3).
+//   k_fc_s3b / k_fc_s3, k_value_head_s3   policy FC and value head on the split activations.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

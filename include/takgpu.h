@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 2
+#define TG_ABI_VERSION 3
 
 /* ---------------------------------------------------------------------------------------
  * Status codes.  TG_PLAY_* mirror reference tak/src/error.rs:4-15 (PlayError) and
@@ -450,8 +450,10 @@ int tg_train_grad_buffer(TgEngine* e, float** d_grads, size_t* count);
  * iterations of `batch` virtual rollouts + one evaluation (reference: ROLLOUTS 50 × Player::rollout with BATCH_SIZE 16),
  * the waiting side `idle_rollouts` iterations (the batch a `Player` keeps in flight, player.rs:65-66), moves are
  * pick_move(exploit = true).  Openings: a1, a random far corner, `random_plies` random Flat/Cap placements
- * (pit.rs:33-63), drawn from Philox(seed).  Not reproduced: the early exit of pit.rs:20-23 (all games run at once) and
- * the exact interleaving of the waiting player's stale batch with the moves.  The caller applies the gate
+ * (pit.rs:33-63), drawn from Philox(seed).  All games run at once, so the early exit of pit.rs:20-23 cannot save any
+ * work; its effect on the counts is reproduced in the ref_* fields (the tallies of the openings the reference's loop would
+ * have played before breaking, in its order).  Not reproduced: the exact interleaving of the waiting player's stale batch
+ * with the moves.  The caller applies the gate
  * (main.rs:102: win_rate > 0.55).  Both engines' search / self-play state is replaced (tg_search_create is called on
  * each); 2·pairs·batch ≤ max_batch of both engines.
  * ------------------------------------------------------------------------------------- */
@@ -472,6 +474,11 @@ typedef struct TgPitResult {
     uint32_t plies;               /* lock-step plies played */
     uint32_t reserved;
     double win_rate;              /* wins / (wins + losses), pit.rs:105-110 */
+    /* The same with pit.rs:20-23 applied: openings are counted in order (White game, then Black game of each) until
+     * wins > pairs + pairs/10 or losses > pairs - pairs/10 holds before an opening — what `pit` returns. */
+    uint32_t ref_wins, ref_losses, ref_draws;
+    uint32_t ref_pairs;           /* openings counted (= pairs when the loop never breaks) */
+    double ref_win_rate;
 } TgPitResult;
 int tg_pit(TgEngine* e_new, TgEngine* e_old, const TgPitConfig* cfg, TgPitResult* out);
 

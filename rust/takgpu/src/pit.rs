@@ -17,7 +17,8 @@ impl PitResult {
 }
 
 /// Drop-in for `pit(&new_network, &network)` at train/src/main.rs:100.  PIT_GAMES 128, ROLLOUTS 50, BATCH_SIZE 16,
-/// RANDOM_PLIES 2, komi 2 (pit.rs:5-9,27).  Not reproduced: the early exit of pit.rs:20-23 (all games run concurrently).
+/// RANDOM_PLIES 2, komi 2 (pit.rs:5-9,27).  All games run concurrently; the counts returned are the ones `pit` would return,
+/// early exit of pit.rs:20-23 included (the library tallies the openings in the reference's order: `ref_*`).
 pub fn pit_gpu<const N: usize>(new: &GpuNet<N>, old: &GpuNet<N>) -> PitResult {
     let cfg = sys::TgPitConfig {
         pairs: 128,
@@ -33,5 +34,5 @@ pub fn pit_gpu<const N: usize>(new: &GpuNet<N>, old: &GpuNet<N>) -> PitResult {
     let mut out = std::mem::MaybeUninit::<sys::TgPitResult>::zeroed();
     check(unsafe { sys::tg_pit(new.e, old.e, &cfg, out.as_mut_ptr()) }).expect("tg_pit");
     let r = unsafe { out.assume_init() };
-    PitResult { wins: r.wins, draws: r.draws, losses: r.losses, unfinished: r.unfinished }
+    PitResult { wins: r.ref_wins, draws: r.ref_draws, losses: r.ref_losses, unfinished: r.unfinished }
 }

@@ -93,7 +93,7 @@ extern "C" int tg_pit(TgEngine* e_new, TgEngine* e_old, const TgPitConfig* cfg, 
         rc = tg_search_reset(e, states.data());
         if (rc) return rc;
     }
-    std::vector<uint8_t> results(G), alive(G, 1), act[2], idle[2];
+    std::vector<uint8_t> results(G), alive(G, 1), final_res(G, TG_ONGOING), act[2], idle[2];
     for (int k = 0; k < 2; k++) { act[k].resize(G); idle[k].resize(G); }
     std::vector<TgMove> moves[2], chosen(G);
     std::vector<uint32_t> visits[2];
@@ -106,6 +106,7 @@ extern "C" int tg_pit(TgEngine* e_new, TgEngine* e_old, const TgPitConfig* cfg, 
         for (int g = 0; g < G; g++) {
             if (alive[g] && results[g] != TG_ONGOING) {  // PitResult::update, pit.rs:113-126
                 alive[g] = 0;
+                final_res[g] = results[g];
                 const bool new_is_white = (g & 1) == 0;
                 if (results[g] == TG_DRAW || results[g] == TG_DRAW_REVERSIBLE) out->draws++;
                 else {
@@ -152,5 +153,19 @@ extern "C" int tg_pit(TgEngine* e_new, TgEngine* e_old, const TgPitConfig* cfg, 
         out->plies++;
     }
     out->win_rate = (out->wins + out->losses) ? (double)out->wins / (double)(out->wins + out->losses) : 0.0;  // pit.rs:105-110
+    // the reference plays the openings one after the other and stops once the verdict cannot change (pit.rs:20-23)
+    const uint32_t P = (uint32_t)cfg->pairs;
+    for (uint32_t i = 0; i < P; i++) {
+        if (out->ref_wins > P + P / 10 || out->ref_losses > P - P / 10) break;
+        out->ref_pairs++;
+        for (int c = 0; c < 2; c++) {  // Color::White, then Color::Black (pit.rs:27)
+            const uint8_t r = final_res[2 * i + c];
+            if (r == TG_ONGOING) continue;  // cut by max_plies
+            if (r == TG_DRAW || r == TG_DRAW_REVERSIBLE) out->ref_draws++;
+            else if ((r == TG_WHITE_ROAD || r == TG_WHITE_FLAT) == (c == 0)) out->ref_wins++;
+            else out->ref_losses++;
+        }
+    }
+    out->ref_win_rate = (out->ref_wins + out->ref_losses) ? (double)out->ref_wins / (double)(out->ref_wins + out->ref_losses) : 0.0;
     return TG_OK;
 }

@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TAKGPU_LIB") or os.path.join(_HERE, "libtakgpu.so")  # TAKGPU_LIB: probe builds (scripts/probes)
 
-TG_ABI_VERSION = 2
+TG_ABI_VERSION = 3
 TG_MAX_MOVES = 512
 HEAD_FC5, HEAD_CONV = 0, 1
 EVAL_RESNET, EVAL_DUMMY, EVAL_HASH = 0, 1, 2
@@ -73,7 +73,9 @@ class TgPitConfig(C.Structure):
 
 class TgPitResult(C.Structure):
     _fields_ = [("wins", C.c_uint32), ("losses", C.c_uint32), ("draws", C.c_uint32), ("unfinished", C.c_uint32),
-                ("plies", C.c_uint32), ("reserved", C.c_uint32), ("win_rate", C.c_double)]
+                ("plies", C.c_uint32), ("reserved", C.c_uint32), ("win_rate", C.c_double),
+                ("ref_wins", C.c_uint32), ("ref_losses", C.c_uint32), ("ref_draws", C.c_uint32), ("ref_pairs", C.c_uint32),
+                ("ref_win_rate", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -246,7 +248,8 @@ def comm_unique_id():
 
 
 def pit(new, old, pairs=128, rollouts=50, batch=16, idle_rollouts=1, random_plies=2, komi=2, max_plies=0, arena_nodes=0, seed=0):
-    """`pit(new, old)` of train/src/pit.rs on two engines (one per weight set) → dict(wins, losses, draws, win_rate, …);
+    """`pit(new, old)` of train/src/pit.rs on two engines (one per weight set) → dict(wins, losses, draws, win_rate, …; the
+    ref_* entries are the counts with the reference's early exit, pit.rs:20-23, applied);
     `rollouts` iterations of `batch` virtual rollouts per move (ROLLOUTS × BATCH_SIZE); 2·pairs·batch ≤ max_batch"""
     cfg = TgPitConfig(pairs, rollouts, idle_rollouts, random_plies, komi, max_plies, arena_nodes, batch, seed)
     res = TgPitResult()

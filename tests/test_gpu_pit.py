@@ -33,6 +33,7 @@ def _oracle_pit(orc, n, evals, pairs, rollouts, idle, random_plies, komi, seed, 
     for t in trees:
         t.reset(states)
     alive = np.ones(G, bool)
+    final = np.zeros(G, np.int64)
     wins = losses = draws = plies = 0
     sb = states.shape[1]
     while True:
@@ -40,6 +41,7 @@ def _oracle_pit(orc, n, evals, pairs, rollouts, idle, random_plies, komi, seed, 
         for g in range(G):
             if alive[g] and res[g] != 0:
                 alive[g] = False
+                final[g] = res[g]
                 if res[g] in (5, 6):
                     draws += 1
                 elif (res[g] in (1, 2)) == (g % 2 == 0):
@@ -67,10 +69,31 @@ def _oracle_pit(orc, n, evals, pairs, rollouts, idle, random_plies, komi, seed, 
             t.play(chosen, alive.astype(np.uint8))
         states = trees[0].states()
         plies += 1
-    return dict(wins=wins, losses=losses, draws=draws, plies=plies, unfinished=int(alive.sum()))
+    return dict(wins=wins, losses=losses, draws=draws, plies=plies, unfinished=int(alive.sum()), **_reference_tally(final, pairs))
 
 
-@pytest.mark.parametrize("n,pairs,rollouts,batch", [(4, 6, 40, 1), (5, 5, 30, 1), (5, 4, 6, 8)])
+def _reference_tally(final, pairs):
+    """`pit` plays the openings one after the other, White game then Black game, and breaks once the verdict is known
+    (pit.rs:20-23): the counts it returns, from the per-game results of all games."""
+    w = l = d = played = 0
+    for i in range(pairs):
+        if w > pairs + pairs // 10 or l > pairs - pairs // 10:
+            break
+        played += 1
+        for c in range(2):
+            r = final[2 * i + c]
+            if r == 0:
+                continue
+            if r in (5, 6):
+                d += 1
+            elif (r in (1, 2)) == (c == 0):
+                w += 1
+            else:
+                l += 1
+    return dict(ref_wins=w, ref_losses=l, ref_draws=d, ref_pairs=played)
+
+
+@pytest.mark.parametrize("n,pairs,rollouts,batch", [(4, 6, 40, 1), (5, 5, 30, 1), (5, 4, 6, 8), (4, 24, 8, 1)])
 def test_pit_matches_oracle_replay(orc, n, pairs, rollouts, batch):
     import tak_amd
 
@@ -81,7 +104,7 @@ def test_pit_matches_oracle_replay(orc, n, pairs, rollouts, batch):
     got = tak_amd.pit(new, old, arena_nodes=1 << 16, **kw)
     want = _oracle_pit(orc, n, (orc.EVAL_HASH, orc.EVAL_DUMMY), kw["pairs"], kw["rollouts"], kw["idle_rollouts"], 2, 2, 11, max_plies=60,
                        batch=batch)
-    for k in ("wins", "losses", "draws", "plies", "unfinished"):
+    for k in ("wins", "losses", "draws", "plies", "unfinished", "ref_wins", "ref_losses", "ref_draws", "ref_pairs"):
         assert got[k] == want[k], (got, want)
     assert got["wins"] + got["losses"] + got["draws"] + got["unfinished"] == 2 * pairs
     if got["wins"] + got["losses"]:
@@ -102,3 +125,14 @@ def test_identical_networks_split_every_pair(orc):
         tak_amd.pit(a, a)
     a.close()
     b.close()
+
+
+def test_early_exit_tally_of_the_reference():
+    """pit.rs:20-23 on hand-made results: with 10 openings the loop breaks before an opening once wins > 11 or losses > 9."""
+    white_wins, black_wins = 1, 3  # result codes: road wins
+    final = np.array([white_wins, black_wins] * 10)  # the new network wins both games of every opening
+    assert _reference_tally(final, 10) == dict(ref_wins=12, ref_losses=0, ref_draws=0, ref_pairs=6)
+    final = np.array([black_wins, white_wins] * 10)  # … loses both
+    assert _reference_tally(final, 10) == dict(ref_wins=0, ref_losses=10, ref_draws=0, ref_pairs=5)
+    final = np.array([white_wins, white_wins] * 10)  # one each: never breaks
+    assert _reference_tally(final, 10) == dict(ref_wins=10, ref_losses=10, ref_draws=0, ref_pairs=10)

@@ -21,6 +21,21 @@ __device__ inline int game_of_wave() { return (int)(blockIdx.x * WPB + (threadId
 __device__ inline void flag(const SearchDev& S, uint32_t bit) { atomicOr(S.err, bit); }
 __device__ inline void wave_sync_mem() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 
+// Diagnostic build only (-DTG_TREE_STAMPS, scripts/probes/tree_stamps.py): s_memtime stamps of the waves of the first 64 games
+// at the phase boundaries of k_backup_select; tg_debug_tree_stamps copies them out.  The product build compiles none of it.
+#ifdef TG_TREE_STAMPS
+__device__ unsigned long long g_tree_stamps[64][32];
+#define TG_TSTAMP(g, slot)                                                                                    \
+    do {                                                                                                      \
+        if ((g) < 64 && (slot) < 32 && (threadIdx.x & 63) == 0) {                                             \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                        \
+            g_tree_stamps[(g)][(slot)] = __builtin_amdgcn_s_memtime();                                        \
+        }                                                                                                     \
+    } while (0)
+#else
+#define TG_TSTAMP(g, slot) do { } while (0)
+#endif
+
 // ---- node pool (search.cuh): chunks of 2^chunk_shift nodes handed out from a ring of free chunk ids ----
 // Take one chunk for the calling wave (wave-uniform result, 0 = pool exhausted).  Only chunks whose return was
 // published before this kernel started are handed out, so a taker never reads a ring slot that a concurrent
@@ -112,14 +127,18 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
         NodeCold nc = cold[root];
         vis = uni(nh.visits); vv = uni(nh.virt); nres = uni((uint32_t)nc.nres); cbase = uni(nc.child);
     }
+    TG_TSTAMP(g, 4);  // root state + root record loaded
     for (;;) {
         if (vis == 0 && vv == 0) {
             // uninitialised node: initialise it and stop (mcts.rs:41-53)
+            TG_TSTAMP(g, 24);  // descent done
             res = ws_result(s, geo);
+            TG_TSTAMP(g, 25);
             uint32_t count = 0, cb = 0;
             if (res == TG_ONGOING) {
                 // the legal moves are staged in LDS so that the children block can be placed once its size is known
                 count = (uint32_t)ws_movegen(s, geo, EX_MOVES, [&](int idx, uint32_t code) { mvl[idx] = (uint16_t)code; });
+                TG_TSTAMP(g, 26);
                 if (count > (uint32_t)EX_MOVES) {
                     flag(S, ERRF_MOVES);
                     if (lane == 0) S.leaf_kind[slot] = 0;
@@ -159,6 +178,7 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
                 cold[node].nres = (uint16_t)(count | (res << 12));
             }
             terminal = res != TG_ONGOING;
+            TG_TSTAMP(g, 27);  // children created
             break;
         }
         res = nres >> 12;
@@ -209,7 +229,9 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
         vv = uni((uint32_t)__shfl((int)bh.virt, src));
         nres = uni((uint32_t)__shfl((int)(uint32_t)bc.nres, src));
         cbase = uni((uint32_t)__shfl((int)bc.child, src));
+        TG_TSTAMP(g, 5 + 2 * (depth < 9 ? depth : 9));  // children scanned, best child known
         ws_play(s, mv, geo);
+        TG_TSTAMP(g, 6 + 2 * (depth < 9 ? depth : 9));  // move played
         if (depth >= MAX_DEPTH) {
             flag(S, ERRF_DEPTH);
             if (lane == 0) S.leaf_kind[slot] = 0;
@@ -237,6 +259,7 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
         }
         hot[nd] = h;
     }
+    TG_TSTAMP(g, 28);  // virtual visits marked
     uint32_t* gpath = S.path + slot * MAX_DEPTH;
     for (int d = lane; d < depth; d += 64) gpath[d] = path[d];
     if (!terminal) {
@@ -249,6 +272,7 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
             if (lane == 0) S.leaf_hash[slot] = h;
         }
     }
+    TG_TSTAMP(g, 29);  // leaf state stored
     if (lane == 0) {
         S.path_len[slot] = depth;
         S.leaf_kind[slot] = terminal ? 2 : 1;
@@ -304,6 +328,7 @@ __device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, con
     else e = 0.0f;
     const float* pol = S.policy + slot * S.P;
     bool bad = false;
+    TG_TSTAMP(g, 1);  // leaf record + softmax statistics done
     for (uint32_t i = lane; i < nchild; i += 64) {
         uint32_t mv = cold[cb + i].mv;
         int idx = move_index_dev(mv, S.n, S.legacy5 != 0, S.lut5);
@@ -315,6 +340,7 @@ __device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, con
         hot[cb + i].prior = p;
     }
     if (__ballot(bad)) flag(S, ERRF_MOVE);
+    TG_TSTAMP(g, 2);  // priors written
     for (int d = lane; d <= L; d += 64) {
         uint32_t nd = d == 0 ? root : path[d - 1];
         NodeHot h = hot[nd];
@@ -348,9 +374,12 @@ __global__ __launch_bounds__(256) void k_backup_select(SearchDev S) {
     __shared__ uint16_t mv_lds[WPB][EX_MOVES];
     const int g = game_of_wave();
     if (g >= S.G) return;
+    TG_TSTAMP(g, 0);
     backup_pass(S, g, 0);
     wave_sync_mem();
+    TG_TSTAMP(g, 3);  // path updated
     select_pass(S, nullptr, g, 0, path_lds[threadIdx.x >> 6], mv_lds[threadIdx.x >> 6]);
+    TG_TSTAMP(g, 31);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -841,5 +870,11 @@ void launch_sp_pick(hipStream_t st, const SearchDev& S, const SelfPlayDev& P, in
     hipLaunchKernelGGL(k_sp_pick, wgrid(S.G), dim3(256), 0, st, S, P, op);
 }
 void launch_sp_count_ply(hipStream_t st, const SelfPlayDev& P) { hipLaunchKernelGGL(k_sp_count_ply, dim3(1), dim3(1), 0, st, P); }
+
+#ifdef TG_TREE_STAMPS
+extern "C" int tg_debug_tree_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tree_stamps), sizeof(g_tree_stamps));
+}
+#endif
 
 }  // namespace tg

@@ -1,6 +1,6 @@
 """Kernel variants selected by the launchers' A/B switches must return the same BITS: the halo-image towers against the
-plain-image ones (TG_NO_HALO_TOWER), the barrier-free policy FC against the barrier version (TG_FC_BARRIER), in exact f32
-and on the split-bf16 path.  The switches are read once per process, so every variant runs scripts/ab_bits.py (sha256 of
+plain-image ones (TG_NO_HALO_TOWER), the barrier-free policy FC against the barrier version (TG_FC_BARRIER), fragment-major
+against row-major FC input (TG_NO_FRAG_OUT), in exact f32 and on the split-bf16 path.  The switches are read once per process, so every variant runs scripts/ab_bits.py (sha256 of
 policy + eval of 4093 positions of one BASELINE topology, a ragged last workgroup included) in its own process."""
 import os
 import subprocess
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _digest(cfg, batch, **env):
     e = dict(os.environ)
-    for k in ("TG_NO_HALO_TOWER", "TG_FC_BARRIER", "TG_PRECISION"):
+    for k in ("TG_NO_HALO_TOWER", "TG_FC_BARRIER", "TG_NO_FRAG_OUT", "TG_PRECISION"):
         e.pop(k, None)
     e.update(env)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "ab_bits.py"), cfg, str(batch)], env=e, check=True,
@@ -29,6 +29,8 @@ def test_launcher_variants_return_identical_bits(cfg, batch):
     assert _digest(cfg, batch, TG_NO_HALO_TOWER="1") == base
     if cfg != "c3":  # FC policy head
         assert _digest(cfg, batch, TG_FC_BARRIER="1") == base
+        assert _digest(cfg, batch, TG_NO_FRAG_OUT="1") == base  # row-major tower output into the ring FC
+        assert _digest(cfg, batch, TG_NO_FRAG_OUT="1", TG_FC_BARRIER="1") == base
     s3 = _digest(cfg, batch, TG_PRECISION="bf16x3")
     assert s3 != base
     assert _digest(cfg, batch, TG_PRECISION="bf16x3", TG_NO_HALO_TOWER="1") == s3

@@ -14,7 +14,7 @@ int main(int argc, char** argv) {
     for (int b = 0; b < B; b++) { uint8_t* h = &hs[(size_t)b * 256 + 240]; h[0] = 5; h[4] = 21; h[5] = 1; h[6] = 21; h[7] = 1; h[8] = 4; }
     hipMemcpy(states, hs.data(), hs.size(), hipMemcpyHostToDevice);
     TowerParams T{};
-    T.nlayers = nl; T.cin_pad = cin_pad; T.F = F;
+    T.nlayers = nl; T.cin_pad = cin_pad; T.cin_last_t = 2; T.F = F;
     for (int l = 0; l < nl; l++) {
         size_t wf = (size_t)9 * (l ? F : cin_pad) * F;
         float* w; hipMalloc(&w, wf * 4);

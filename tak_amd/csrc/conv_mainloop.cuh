@@ -42,6 +42,29 @@ __device__ __forceinline__ void conv_tap_masks(int rows, int n, int nsq, int rho
     }
 }
 
+// Layer 0 of the fused towers: C_in = 72 / 92 real channels in 80 / 96 padded ones.  Position p = 4q + t of a 16-channel
+// chunk is element t of lane group q's 16 bytes, i.e. MFMA t of the chunk — so the r = 8 / 12 real channels of the LAST
+// chunk are stored at q = i / LT, t = i % LT (LT = ⌈r/4⌉ = 2 / 3) and MFMAs t ≥ LT see nothing but padding.  The same
+// permutation is applied to the layer's weights (net.hip upload_conv).  src = the chunk's four quads in channel order.
+template <int LT>
+__device__ __forceinline__ void conv_last_chunk_perm(const f32x4 (&src)[4], f32x4 (&dst)[4]) {
+#pragma unroll
+    for (int qq = 0; qq < 4; qq++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int i = qq * LT + t;  // compile-time after unrolling
+            dst[qq][t] = t < LT ? src[i >> 2][i & 3] : 0.0f;
+        }
+}
+__device__ __forceinline__ void conv_last_chunk_store(f32x4* row_last, const f32x4 (&src)[4], int last_t) {
+    f32x4 d[4];
+    if (last_t == 2) conv_last_chunk_perm<2>(src, d);
+    else if (last_t == 3) conv_last_chunk_perm<3>(src, d);
+    else { d[0] = src[0]; d[1] = src[1]; d[2] = src[2]; d[3] = src[3]; }
+#pragma unroll
+    for (int qq = 0; qq < 4; qq++) row_last[qq] = d[qq];
+}
+
 // Implicit-GEMM main loop of k_tower: RTW row tiles × one 16-channel tile, K = 9·16·CH.  Explicit half-tile
 // software pipeline that also runs across tap boundaries:
 //     load H2(s) | MFMA H1(s) | load H1(s+1), w(s+2) | MFMA H2(s)
@@ -50,7 +73,10 @@ __device__ __forceinline__ void conv_tap_masks(int rows, int n, int nsq, int rho
 template <int RTW, int CH, int NM>
 __device__ __forceinline__ void conv_mainloop(const f32x4* __restrict__ lds4, const f32x4* __restrict__ wp, size_t wstride4,
                                                  int LS4, int rows, int n, int rho0, int q, const int (&vmask)[NM],
-                                                 f32x4 (&acc)[RTW]) {
+                                                 f32x4 (&acc)[RTW], const int last_t = 4) {
+    // last_t < 4 (layer 0 of the fused towers): the real input channels of a tap's LAST 16-channel chunk were permuted so
+    // that they fill MFMAs t = 0 … last_t − 1 of the chunk completely (conv_last_chunk_perm); the others would multiply
+    // the zero padding and are skipped.
     static_assert(NM >= RTW, "tap masks for every row tile");
     // TG_PROBE (scripts/probes/tower_stamps.hip only): bit 0 = every tap reads its shifted row (no zero-row reads),
     // bit 1 = no weight stream (w0 reused), bit 2 = no tap switch (offsets of tap 0 throughout).  Wrong results, same shape.
@@ -94,8 +120,10 @@ __device__ __forceinline__ void conv_mainloop(const f32x4* __restrict__ lds4, co
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 4; t++)
+                if (kc + 1 < CH || t < last_t) {
 #pragma unroll
-                for (int j = 0; j < H1; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t], a[j][t], acc[j], 0, 0, 0);
+                    for (int j = 0; j < H1; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t], a[j][t], acc[j], 0, 0, 0);
+                }
             __builtin_amdgcn_sched_barrier(0);
             const int k2 = kk + 2 < total ? kk + 2 : total - 1;
             const f32x4 w2 = (TG_PROBE & 2) ? w0 : wp[(size_t)k2 * wstride4];
@@ -113,8 +141,10 @@ __device__ __forceinline__ void conv_mainloop(const f32x4* __restrict__ lds4, co
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 4; t++)
+                if (kc + 1 < CH || t < last_t) {
 #pragma unroll
-                for (int j = H1; j < RTW; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t], a[j][t], acc[j], 0, 0, 0);
+                    for (int j = H1; j < RTW; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t], a[j][t], acc[j], 0, 0, 0);
+                }
             __builtin_amdgcn_sched_barrier(0);
             w0 = w1;
             w1 = w2;

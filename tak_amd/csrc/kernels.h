@@ -29,6 +29,7 @@ struct TowerParams {
     const float* b[48];   // per layer: bias[CoutP]
     int nlayers;          // 1 + 2·R
     int cin_pad;          // channels of the input planes (layer 0)
+    int cin_last_t;       // 2 / 3: w[0] and the LDS image of the planes carry the last 16-channel chunk permuted (conv_mainloop.cuh); 4: plain
     int F;                // channels of every later layer (= CoutP of every layer)
     // halo image of the large-batch kernel (k_tower_halo): tile slot → cell | row << 16, position stride in cells
     const uint32_t* slotmap;

@@ -34,6 +34,7 @@ struct Net {
     DevBuf x, y, logits, planes_nhwc, planes_nchw;
     bool fused = false;  // whole tower in one launch (k_tower)
     TowerParams tower;
+    ConvLayer conv0_tower;             // conv0 with the last input chunk permuted (layer 0 of the fused towers)
     DevBuf halo_map;                   // tile slot → square table of the halo tower (k_tower_halo)
     DevBuf s3_halo_map;                // the same for the split tower's workgroup (k_tower_s3_halo)
     size_t logit_row = 0;              // floats per position in `logits`
@@ -143,7 +144,9 @@ bool fold_conv_bn(Net* n, const std::string& conv, const std::string& bn, int O,
 }
 
 // OIHW → Wp[(tap*Ipad + c)/16][CoutP][(tap*Ipad + c)%16], tap = ky*3 + kx, zero padded
-hipError_t upload_conv(const Folded& f, int O, int I, int Ipad, ConvLayer& L) {
+// last_t = 2 / 3: the real channels of the last 16-channel chunk go to positions 4·(i / last_t) + i % last_t
+// (conv_mainloop.cuh conv_last_chunk_perm: layer 0 of the fused towers); 4 = channel order
+hipError_t upload_conv(const Folded& f, int O, int I, int Ipad, ConvLayer& L, int last_t = 4) {
     int OP = round_up(O, 64);
     size_t K = (size_t)9 * Ipad;
     std::vector<float> wp(K * OP, 0.0f), bp(OP, 0.0f);
@@ -151,7 +154,9 @@ hipError_t upload_conv(const Folded& f, int O, int I, int Ipad, ConvLayer& L) {
         bp[o] = f.b[o];
         for (int c = 0; c < I; c++)
             for (int tap = 0; tap < 9; tap++) {
-                size_t k = (size_t)tap * Ipad + c;
+                int pos = c & 15;
+                if (last_t < 4 && c >= Ipad - 16) { const int i = c - (Ipad - 16); pos = 4 * (i / last_t) + i % last_t; }
+                size_t k = (size_t)tap * Ipad + (c & ~15) + pos;
                 wp[((k >> 4) * OP + o) * 16 + (k & 15)] = f.w[((size_t)o * I + c) * 9 + tap];
             }
     }
@@ -288,7 +293,17 @@ int net_finalize(TgEngine* e) {
     if (n->fused) {
         TowerParams& T = n->tower;
         T.nlayers = 1 + 2 * R; T.cin_pad = n->cin_pad; T.F = F;
-        T.w[0] = n->conv0.w.as<float>(); T.b[0] = n->conv0.b.as<float>();
+        // layer 0: 72 of 80 (5×5) / 92 of 96 (6×6) input channels are real; with the last chunk permuted 2 of 20 / 1 of 24
+        // MFMAs per tile and tap multiply padding only and are skipped — the towers get their own copy of the weights
+        const int tail = n->cin - (n->cin_pad - 16);
+        T.cin_last_t = (tail > 0 && tail <= 12 && !getenv("TG_NO_CIN_PERM")) ? (tail + 3) / 4 : 4;
+        if (T.cin_last_t < 2) T.cin_last_t = 4;
+        {
+            Folded f0;
+            if (!fold_conv_bn(n, "conv0", "bn0", F, n->cin, f0, err)) return fail(TG_ERR_WEIGHTS, err);
+            TG_HIP(upload_conv(f0, F, n->cin, n->cin_pad, n->conv0_tower, T.cin_last_t));
+        }
+        T.w[0] = n->conv0_tower.w.as<float>(); T.b[0] = n->conv0.b.as<float>();
         for (int i = 0; i < R; i++) {
             T.w[1 + 2 * i] = n->res1[i].w.as<float>(); T.b[1 + 2 * i] = n->res1[i].b.as<float>();
             T.w[2 + 2 * i] = n->res2[i].w.as<float>(); T.b[2 + 2 * i] = n->res2[i].b.as<float>();

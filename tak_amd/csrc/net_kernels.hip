@@ -335,10 +335,18 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
             const RowMask m = ws_row_mask(ws, geo);
             if (lane < nsq) {
                 f32x4* row = lds4 + (size_t)(p * nsq + lane) * LS4;
-                for (int k = 0; k < (Cpad >> 2); k++) {
+                const int kl = (Cpad >> 2) - 4;  // first quad of the last 16-channel chunk
+                for (int k = 0; k < kl; k++) {
                     float4 v = row_mask_value(m, k, C, fcd);
                     row[k] = f32x4{v.x, v.y, v.z, v.w};
                 }
+                f32x4 lc[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float4 v = row_mask_value(m, kl + k, C, fcd);
+                    lc[k] = f32x4{v.x, v.y, v.z, v.w};
+                }
+                conv_last_chunk_store(row + kl, lc, T.cin_last_t);
             }
         }
         for (int idx = tid; idx < LS4; idx += NWAVES * 64) lds4[rows * LS4 + idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -348,7 +356,13 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
         const int total = rows * vpr;
         for (int idx = tid; idx < total; idx += NWAVES * 64) {
             int r = idx / vpr, v = idx - r * vpr;
-            lds4[r * LS4 + v] = src[idx];
+            if (v < vpr - 4) lds4[r * LS4 + v] = src[idx];
+        }
+        for (int r = tid; r < rows; r += NWAVES * 64) {  // the last chunk of every row, permuted like the weights
+            f32x4 lc[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) lc[k] = src[(size_t)r * vpr + vpr - 4 + k];
+            conv_last_chunk_store(lds4 + (size_t)r * LS4 + vpr - 4, lc, T.cin_last_t);
         }
         for (int idx = tid; idx < LS4; idx += NWAVES * 64) lds4[rows * LS4 + idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
@@ -380,10 +394,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
         TG_STAMP(layer, 0);
         if (RTW > 1 && short_group) {
             f32x4 (&acs)[RTW - 1] = *reinterpret_cast<f32x4 (*)[RTW - 1]>(&acc[0]);
-            if (layer == 0) conv_mainloop<RTW - 1, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acs);
+            if (layer == 0) conv_mainloop<RTW - 1, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acs, T.cin_last_t);
             else conv_mainloop<RTW - 1, CH>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acs);
         } else {
-            if (layer == 0) conv_mainloop<RTW, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acc);
+            if (layer == 0) conv_mainloop<RTW, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acc, T.cin_last_t);
             else conv_mainloop<RTW, CH>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acc);
         }
         TG_STAMP(layer, 1);
@@ -473,10 +487,18 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower_halo(const float* __restr
             const RowMask m = ws_row_mask(ws, geo);
             if (lane < nsq) {
                 f32x4* row = lds4 + (size_t)(p * nsq + lane) * LS4;
-                for (int k = 0; k < (Cpad >> 2); k++) {
+                const int kl = (Cpad >> 2) - 4;  // first quad of the last 16-channel chunk
+                for (int k = 0; k < kl; k++) {
                     float4 v = row_mask_value(m, k, C, fcd);
                     row[k] = f32x4{v.x, v.y, v.z, v.w};
                 }
+                f32x4 lc[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float4 v = row_mask_value(m, kl + k, C, fcd);
+                    lc[k] = f32x4{v.x, v.y, v.z, v.w};
+                }
+                conv_last_chunk_store(row + kl, lc, T.cin_last_t);
             }
         }
     } else {
@@ -485,7 +507,13 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower_halo(const float* __restr
         const int total = rows * vpr;
         for (int idx = tid; idx < total; idx += NWAVES * 64) {
             int r = idx / vpr, v = idx - r * vpr;
-            lds4[r * LS4 + v] = src[idx];
+            if (v < vpr - 4) lds4[r * LS4 + v] = src[idx];
+        }
+        for (int r = tid; r < rows; r += NWAVES * 64) {  // the last chunk of every row, permuted like the weights
+            f32x4 lc[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) lc[k] = src[(size_t)r * vpr + vpr - 4 + k];
+            conv_last_chunk_store(lds4 + (size_t)r * LS4 + vpr - 4, lc, T.cin_last_t);
         }
     }
     for (int idx = tid; idx < LS4; idx += NWAVES * 64) lds4[rows * LS4 + idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -515,9 +543,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower_halo(const float* __restr
         TG_STAMP(0, 0);
         if (RTW > 1 && short_group) {
             f32x4 (&acs)[RTW - 1] = *reinterpret_cast<f32x4 (*)[RTW - 1]>(&acc[0]);
-            conv_mainloop<RTW - 1, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acs);
+            conv_mainloop<RTW - 1, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acs, T.cin_last_t);
         } else {
-            conv_mainloop<RTW, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acc);
+            conv_mainloop<RTW, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acc, T.cin_last_t);
         }
         TG_STAMP(0, 1);
         if (T.nlayers > 1) conv_halo_first_weights<CH>(T.w[1], wlane, w0, w1);  // in flight during the change of images

@@ -212,6 +212,24 @@ def test_result_does_not_depend_on_the_batch_size(orc, n, blocks, filters, head,
     e.close()
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("n,blocks,filters,head,batch", [(5, 2, 64, "fc5", 2500), (6, 1, 128, "conv", 700)])
+def test_planes_entry_equals_states_entry_at_full_batch(orc, n, blocks, filters, head, batch, precision):
+    """tg_forward_mcts (caller-encoded planes, net5.rs:121-131) runs the halo towers' other staging path: same bits as
+    tg_policy_eval on the packed states (whose planes the tower encodes itself)."""
+    net = torch_ref.make_net(n, blocks, filters, head, seed=4)
+    sts = orc.random_positions(n, 64, seed=2, max_plies=70, half_komi=4)
+    sts = np.concatenate([sts] * ((batch + 63) // 64))[:batch]
+    e = _engine(n, blocks, filters, head, max_batch=batch)
+    if precision != "f32":
+        e.set_precision(precision)
+    e.load_state_dict(torch_ref.abi_tensors(net))
+    p, v = e.policy_eval(sts)
+    p2, v2 = e.forward_mcts(orc.encode(n, sts))
+    assert np.array_equal(p, p2) and np.array_equal(v, v2)
+    e.close()
+
+
 @pytest.mark.parametrize("n,blocks,filters,head", [(5, 2, 32, "fc5"), (6, 2, 32, "conv")])
 def test_checkpoint_archive_loads_into_the_engine(orc, tmp_path, n, blocks, filters, head):
     """N4: a tch VarStore archive (Network::save, net5.rs:95-104) written by tak_amd.checkpoint → read back → tg_net_set_tensor →

@@ -8,18 +8,25 @@ every game on the GPU: opening / instant-win scan / root evaluation + Dirichlet 
 rollouts (virtual_rollout → one batched network forward → devirtualize_path) / move choice, example
 emission, tree reuse and game recycling.  Everything runs on the GPU with states resident in HBM.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts the N ranks itself, see launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] --train                     (config C5 alone: the data-parallel training step)
 
 Self-play shards by game with no data-path collective: rank r owns games
 [r·4096, (r+1)·4096) with their own RNG streams; RCCL is used only for the barrier / max-over-ranks
-timing.  Rank 0 prints ONE JSON line.
+timing.  Config C5 (`extra.train_c5`, every N): the 10-block x 128-filter network plays, then trains on its own
+examples with the reference's chunking (500 examples x 8 symmetries, 20 chunks per optimiser step,
+alpha-tak/src/model/network.rs:89-96); with N > 1 every step all-reduces the 32.3 MB flat gradient buffer over RCCL
+inside libtakgpu — the only collective of the build.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -133,6 +140,189 @@ def tak_amd_supports_bf16x3(args):
     return (args.board == 5 and args.filters in (64, 128)) or (args.board == 6 and args.filters == 128)
 
 
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (one per GPU), exactly as
+    `torch.distributed.run --nproc-per-node N` would.  This parent never initialises HIP — it imports neither torch nor the
+    engine — so nothing that has touched the GPU forks or execs.  Rank 0's JSON line is relayed to stdout, every
+    other stream goes to stderr; the exit code is non-zero if any rank fails, and the first failure ends the others (by
+    their exact PIDs)."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+
+    def relay(pipe):  # the JSON line to stdout; whatever libraries print on rank 0's stdout (gloo's connection notes) to stderr
+        for line in iter(pipe.readline, b""):
+            dst = sys.stdout.buffer if line.lstrip().startswith(b"{") else sys.stderr.buffer
+            dst.write(line)
+            dst.flush()
+
+    t = threading.Thread(target=relay, args=(procs[0].stdout,), daemon=True)
+    t.start()
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                for o in live:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    t.join(timeout=5)
+    return rc
+
+
+class Watchdog:
+    """Bounds a phase that contains collectives which have never run at this world size: if it does not finish in time,
+    `on_timeout` runs (rank 0 prints the line it already has) and the process leaves without waiting for the GPU."""
+
+    def __init__(self, seconds, on_timeout, exit_code=3):
+        self.t = threading.Timer(seconds, self._fire)
+        self.t.daemon = True
+        self.on_timeout = on_timeout
+        self.exit_code = exit_code
+
+    def _fire(self):
+        try:
+            self.on_timeout()
+        finally:
+            os._exit(self.exit_code)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
+
+
+C5_FLOPS_FWD = 161_689_600  # SURVEY.md §8(d): 5x5, 10 blocks x 128 filters, FC-1575 head, 2·MAC per position (forward)
+
+
+def train_c5(args, rank, world, local_rank, dist, backend, barrier_fn):
+    """BASELINE config C5 on this rank's GPU: the 10-block x 128-filter network plays 5x5 self-play (games sharded by rank, no
+    collective), then trains data-parallel on the examples it just produced: tg_train = Network::train (shuffle, chunks of 500
+    examples x 8 symmetries, an Adam step every 20 chunks).  With world > 1 every optimiser step all-reduces the flat
+    gradient buffer (8.08 M f32 = 32.3 MB) over RCCL inside libtakgpu (tg_train_comm_init; the 128-byte unique id travels
+    over torch.distributed); under TAK_BENCH_BACKEND=gloo (several ranks on one card) the same reduction goes through the
+    host hook.  Returns the dict rank 0 reports (identical timing discipline: barrier, sync, max over ranks)."""
+    import torch
+
+    import tak_amd
+    from tak_amd import dist as tdist
+
+    n, blocks, filters = 5, args.train_blocks, args.train_filters
+    games = args.train_games
+    net, weights = make_weights(n, blocks, filters, "fc5", seed=args.seed)  # the same weights on every rank
+    eng = tak_amd.Engine(n, res_blocks=blocks, filters=filters, policy_head=tak_amd.HEAD_FC5, evaluator=tak_amd.EVAL_RESNET,
+                         max_batch=games, device=local_rank)
+    eng.load_state_dict(weights)
+    eng.train_create(chunk_size=args.train_chunk, chunks_in_step=args.train_chunks_in_step)
+    transport = "single rank"
+    if world > 1:
+        if backend == "nccl":
+            uid = tdist.broadcast_unique_id(dist, tak_amd.comm_unique_id, device="cuda")
+            eng.train_comm_init(rank, world, uid)
+            transport = "RCCL ncclAllReduce(sum, f32) inside libtakgpu"
+        else:
+            eng.train_set_allreduce(tdist.host_allreduce_hook(dist), world)
+            transport = f"host all-reduce through torch.distributed/{backend} (ranks share a card)"
+
+    # 1. self-play on the C5 network at the headline search settings (2 plies timed after 1 warm-up ply)
+    eng.selfplay_create(games, arena_nodes=args.arena, seed=args.seed, rollouts=args.rollouts, max_examples=1 << 14,
+                        slot_base=tdist.slot_base(rank, games))
+    eng.selfplay_step(1)
+    barrier_fn(eng)
+    s0 = eng.selfplay_stats()
+    t0 = time.perf_counter()
+    eng.selfplay_step(2)
+    eng.sync()
+    dt_sp_local = time.perf_counter() - t0
+    barrier_fn(eng)
+    sp_exp = eng.selfplay_stats()["expansions"] - s0["expansions"]
+    dt_sp, sp_total = tdist.reduce_time_and_count(dist, dt_sp_local, sp_exp, device="cuda" if backend == "nccl" else "cpu")
+
+    # 2. examples for the training step: the same network at a few rollouts per move until every rank holds enough
+    need = args.train_steps * args.train_chunk * args.train_chunks_in_step
+    eng.selfplay_create(games, arena_nodes=1 << 12, seed=args.seed + 1, rollouts=args.train_example_rollouts,
+                        max_examples=max(1 << 16, 4 * need), slot_base=tdist.slot_base(rank, games))
+    got = None
+    t_gen = time.perf_counter()
+    while got is None or len(got[0]) < need:
+        eng.selfplay_step(8)
+        new = eng.selfplay_drain(2 * need)
+        got = new if got is None else [np.concatenate([a, b]) for a, b in zip(got, new)]
+        if time.perf_counter() - t_gen > 120:
+            raise RuntimeError(f"example generation: {len(got[0])} of {need} examples after 120 s")
+    t_gen = time.perf_counter() - t_gen
+    hdr, states, moves, visits = [a[:need] for a in got]
+
+    # 3. the training step(s), timed
+    barrier_fn(eng)
+    t0 = time.perf_counter()
+    lp, lz, steps = eng.train(states, hdr["n_moves"], moves, visits, hdr["result"], seed=args.seed + rank)
+    eng.sync()
+    dt_local = time.perf_counter() - t0
+    barrier_fn(eng)
+    dt, positions = tdist.reduce_time_and_count(dist, dt_local, need * 8, device="cuda" if backend == "nccl" else "cpu")
+    ar_ms, ar_n = eng.train_comm_stats()
+    # identical parameters on every rank after the all-reduced steps
+    w = eng.train_get_tensor("value.weight", (1, filters * n * n))
+    same = True
+    if dist is not None:
+        dev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.from_numpy(w).to(dev)
+        lo, hi = t.clone(), t.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        same = bool(torch.equal(lo, hi))
+    eng.train_commit()
+    eng.close()
+    flops = 3 * C5_FLOPS_FWD if (blocks, filters) == (10, 128) else None  # forward + data gradient + weight gradient
+    per_gpu = positions / dt / world
+    return {
+        "metric": "training positions/s (forward + backward + Adam; 8-fold augmented examples)", "value": positions / dt, "unit": "positions/s",
+        "n_gpus": world, "seconds": dt, "optimizer_steps": steps, "ms_per_optimizer_step": 1000.0 * dt / max(steps, 1),
+        "positions_per_rank": need * 8, "loss_p": lp, "loss_z": lz,
+        "frac_of_f32_mfma_peak": (per_gpu * flops / 1e12 / F32_MFMA_PEAK_TFLOPS) if flops else None,
+        "gradient_allreduce": {"transport": transport, "bytes": None if world == 1 else int(eng_param_bytes(blocks, filters, n)),
+                               "count": ar_n, "ms_per_step_rank0": (ar_ms / ar_n) if ar_n else 0.0},
+        "parameters_identical_on_all_ranks": same,
+        "selfplay_c5net": {"value": sp_total / dt_sp, "unit": "node-expansions/s", "ms_per_step": 1000.0 * dt_sp / 2,
+                           "games_per_gpu": games, "sims_per_move": args.rollouts},
+        "example_generation_s": t_gen,
+        "workload": f"BASELINE config C5: 5x5 Tak, {blocks}-block x {filters}-filter resnet (fc5 head): self-play, then Network::train on its own examples — "
+                    f"{need} examples/rank, chunks of {args.train_chunk} x 8 symmetries, an Adam step every {args.train_chunks_in_step} chunks, "
+                    f"gradients all-reduced once per step ({transport}); host buffers in, so the chunk uploads (1.6 MB each) are inside the time",
+    }
+
+
+def eng_param_bytes(blocks, filters, n):
+    """bytes of the flat gradient buffer (trainable parameters, f32) of a 5x5 fc5-head network"""
+    cin = (n + 2 + 6) * 2 + 2 + 2 * {3: 10, 4: 15, 5: 21, 6: 30}[n] + 2 * (1 if n >= 5 else 0)
+    conv = lambda o, i: o * i * 9 + o + 2 * o  # weight + bias + BN gamma/beta
+    p = conv(filters, cin) + 2 * blocks * conv(filters, filters)
+    p += (filters * n * n) * 1575 + 1575 + filters * n * n + 1
+    return 4 * p
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,15 +346,46 @@ def main():
                     help="tower arithmetic: exact f32 MFMA (default, the parity path) or split-bf16 (3 bf16 MFMAs per product)")
     ap.add_argument("--no-alt-precision", action="store_true", help="skip the second run on the bf16x3 path")
     ap.add_argument("--profile-every", type=int, default=8, help="time the tower convs of every k-th forward (0 = off)")
+    ap.add_argument("--train", action="store_true",
+                    help="report config C5 alone (data-parallel training step on the 10x128 network) as the JSON line")
+    ap.add_argument("--no-train", action="store_true", help="skip extra.train_c5")
+    ap.add_argument("--train-steps", type=int, default=2, help="optimiser steps timed (each = chunks-in-step chunks)")
+    ap.add_argument("--train-chunk", type=int, default=500, help="examples per chunk (CHUNK_SIZE, network.rs:17)")
+    ap.add_argument("--train-chunks-in-step", type=int, default=20, help="chunks per optimiser step (CHUNKS_IN_STEP, network.rs:18)")
+    ap.add_argument("--train-blocks", type=int, default=10)
+    ap.add_argument("--train-filters", type=int, default=128)
+    ap.add_argument("--train-games", type=int, default=4096, help="concurrent games per GPU that produce the training examples")
+    ap.add_argument("--train-example-rollouts", type=int, default=16, help="sims per move while producing the training examples")
+    ap.add_argument("--train-timeout", type=float, default=420.0,
+                    help="N > 1: seconds the C5 phase (first RCCL all-reduce inside libtakgpu) may take before the headline line is printed without it")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="launcher plumbing only, for machines without a GPU: rendezvous, barrier and the max / sum reductions "
+                         "of the N ranks, no engine, no measurement ('value' is null)")
     args = ap.parse_args()
 
     from tak_amd import dist as tdist
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # invoked directly: become the launcher (before anything in this process touches the GPU)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank, world, local_rank = tdist.env_rank()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}", file=sys.stderr)
-            sys.exit(2)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+
+    backend = os.environ.get("TAK_BENCH_BACKEND", "nccl")
+    if args.rehearse_launch:
+        # no engine, no GPU: what is exercised is launch_ranks / the torchrun environment, the rendezvous and the reductions
+        dist = tdist.init("gloo", rank, world)
+        if dist is not None:
+            dist.barrier()
+        dt, total = tdist.reduce_time_and_count(dist, 1.0 + rank, 1 + rank)
+        if rank == 0:
+            print(json.dumps({"metric": "launcher rehearsal (no measurement)", "value": None, "unit": "node-expansions/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "rehearsal": True, "max_over_ranks": dt, "sum_over_ranks": total}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     import torch
 
@@ -172,7 +393,6 @@ def main():
         print("bench.py: no GPU visible — the engine has no CPU fallback", file=sys.stderr)
         sys.exit(2)
     # TAK_BENCH_BACKEND=gloo rehearses the N>1 path with several ranks on ONE card (RCCL refuses two ranks per device)
-    backend = os.environ.get("TAK_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -230,91 +450,125 @@ def main():
         run.last = {"games_finished": s1["games_finished"], "examples": s1["examples"], "drained": drained, "dropped_examples": s1["dropped_examples"]}
         return dt_local, s1["expansions"] - s0["expansions"], s1["evals"] - s0["evals"], prof
 
-    dt_local, expansions, evals, prof = run(args.precision, args.profile_every)
-    dt, total_exp = tdist.reduce_time_and_count(dist, dt_local, expansions, device="cuda" if backend == "nccl" else "cpu")
+    out = None
+    if not args.train:
+        dt_local, expansions, evals, prof = run(args.precision, args.profile_every)
+        dt, total_exp = tdist.reduce_time_and_count(dist, dt_local, expansions, device="cuda" if backend == "nccl" else "cpu")
 
-    if rank == 0:
-        out = {
-            "metric": f"MCTS node-expansions/sec ({args.board}x{args.board} Tak, {args.rollouts} sims/move, {args.games} games/GPU)",
-            "value": total_exp / dt,
-            "unit": "node-expansions/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1000.0 * dt / max(args.steps, 1),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "bf16x3 (split f32: 3 bf16 MFMAs per product, f32 accumulate)",
-            "data": "synthetic",
-            "config": {
-                "workload": f"{args.board}x{args.board} Tak self-play, {args.games} concurrent games/GPU, {args.rollouts} sims/move, "
-                            f"{args.blocks}-block x {args.filters}-filter resnet ({args.head} policy head), random-init weights, 1 step = 1 ply of all games",
-                "games_per_gpu": args.games, "sims_per_move": args.rollouts, "board": args.board,
-                "parallelism": f"games sharded x{world}, no data-path collective",
-                "expansions_timed": total_exp, "network_evals_rank0": evals,
-            },
-        }
-        if prof and prof["conv_launches"]:
-            avg_ms = prof["conv_ms"] / prof["conv_launches"]
-            achieved = prof["conv_flops"] / (avg_ms * 1e-3) / 1e12
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "pmc_conv.json")
-            if os.path.exists(pmc):
-                try:
-                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            if args.precision == "f32":
-                kernel, peak = "k_tower_halo (fused conv0 + residual tower on a halo LDS image, f32 MFMA 16x16x4; one launch = 1+2R 3x3 convs)", F32_MFMA_PEAK_TFLOPS
-            else:  # three bf16 MFMA passes per algorithmic product: the ceiling for algorithmic FLOPs is a third of the bf16 peak
-                kernel, peak = "k_tower_s3 (fused tower, 3 x bf16 MFMA 16x16x32 per product; peak = 2500 TFLOP/s dense bf16 / 3)", 2500.0 / 3
-            out["roofline"] = {
-                "bound": "mfma", "kernel": kernel,
-                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": traffic, "avg_launch_ms": avg_ms, "launches_timed": prof["conv_launches"],
-                "flops_per_launch": prof["conv_flops"], "rows_per_launch": prof["conv_rows"],
-                "forward_ms": prof["forward_ms"] / max(prof["forwards"], 1),
+        if rank == 0:
+            out = {
+                "metric": f"MCTS node-expansions/sec ({args.board}x{args.board} Tak, {args.rollouts} sims/move, {args.games} games/GPU)",
+                "value": total_exp / dt,
+                "unit": "node-expansions/s",
+                "n_gpus": world,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "ms_per_step": 1000.0 * dt / max(args.steps, 1),
+                "higher_is_better": True,
+                "scaling": "weak",
+                "vs_baseline": None,
+                "dtype": "f32" if args.precision == "f32" else "bf16x3 (split f32: 3 bf16 MFMAs per product, f32 accumulate)",
+                "data": "synthetic",
+                "config": {
+                    "workload": f"{args.board}x{args.board} Tak self-play, {args.games} concurrent games/GPU, {args.rollouts} sims/move, "
+                                f"{args.blocks}-block x {args.filters}-filter resnet ({args.head} policy head), random-init weights, 1 step = 1 ply of all games",
+                    "games_per_gpu": args.games, "sims_per_move": args.rollouts, "board": args.board,
+                    "parallelism": f"games sharded x{world}, no data-path collective",
+                    "expansions_timed": total_exp, "network_evals_rank0": evals,
+                },
             }
-        if world == 1 and args.precision == "f32" and not args.no_alt_precision and tak_amd_supports_bf16x3(args):
-            # the same workload on the split-bf16 tower / policy FC (3 bf16 MFMAs per product, f32 accumulate): measured
-            # deviation from the f32 forward ≤ 1.1e-5 relative on the policy, ≤ 5e-6 on the eval (tests/test_gpu_net.py),
-            # inside the 1e-4 of the reference comparison; trees differ from the f32 run only through those last bits
-            try:
-                dt2, exp2, _, prof2 = run("bf16x3", args.profile_every)
-                alt = {"precision": "bf16x3", "value": exp2 / dt2, "unit": "node-expansions/s", "ms_per_step": 1000.0 * dt2 / max(args.steps, 1),
-                       "max_deviation_vs_f32_forward": measured_deviation(args, tensors, local_rank)}
-                if prof2 and prof2["conv_launches"]:
-                    avg2 = prof2["conv_ms"] / prof2["conv_launches"]
-                    alt["tower_avg_launch_ms"] = avg2
-                    alt["tower_f32_equivalent_tflops"] = prof2["conv_flops"] / (avg2 * 1e-3) / 1e12
-                    alt["tower_bf16_mfma_frac_of_peak"] = 3 * prof2["conv_flops"] / (avg2 * 1e-3) / 1e12 / 2500.0
-                out["alt_precision"] = alt
-            except Exception as ex:
-                out["alt_precision"] = {"error": repr(ex)}
-        if world == 1 and args.precision == "f32" and not args.no_extras:
-            # more lines than the headline, same engine, same timing discipline (fresh engine, warm-up ply, sync on both sides):
-            # the other single-GPU BASELINE config, the north star's "≥ 10 k concurrent games", and a long run with drains
-            extras = {}
-            try:
-                dt3, exp3, _, _ = run("f32", 0, steps=120, warmup=0, drain_every=10)
-                extras["sustained_120_plies"] = {"value": exp3 / dt3, "unit": "node-expansions/s", "plies": 120, "seconds": dt3,
-                                                 "what": "the headline config from ply 0 for 120 plies, finished examples drained every 10 plies", **run.last}
-                dt4, exp4, _, _ = run("f32", 0, cfg=(args.board, args.blocks, args.filters, args.head, 4 * args.games, tensors), steps=2, warmup=1)
-                extras["games_x4"] = {"value": exp4 / dt4, "unit": "node-expansions/s", "games": 4 * args.games, "ms_per_step": 1000.0 * dt4 / 2}
-                if (args.board, args.blocks, args.filters) == (5, 6, 64):
-                    net3, w3 = make_weights(6, 10, 128, "conv", seed=args.seed)
-                    dt5, exp5, _, p5 = run("f32", 1, cfg=(6, 10, 128, "conv", args.games, w3), steps=2, warmup=1)
-                    c3 = {"value": exp5 / dt5, "unit": "node-expansions/s", "ms_per_step": 1000.0 * dt5 / 2,
-                          "workload": f"BASELINE config C3: 6x6 Tak, {args.games} games, {args.rollouts} sims/move, 10-block x 128-filter resnet, conv policy head",
-                          "fp32_ceiling": F32_MFMA_PEAK_TFLOPS * 1e12 / 240_795_648}
-                    if p5 and p5["conv_launches"]:
-                        c3["tower_frac_of_f32_mfma_peak"] = p5["conv_flops"] / (p5["conv_ms"] / p5["conv_launches"] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS
-                    extras["config_c3"] = c3
-            except Exception as ex:
-                extras["error"] = repr(ex)
-            out["extra"] = extras
-        if not args.no_cpu_baseline and world == 1:
+            if prof and prof["conv_launches"]:
+                avg_ms = prof["conv_ms"] / prof["conv_launches"]
+                achieved = prof["conv_flops"] / (avg_ms * 1e-3) / 1e12
+                traffic = None
+                pmc = os.path.join(ROOT, "profiles", "pmc_conv.json")
+                if os.path.exists(pmc):
+                    try:
+                        traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                    except Exception:
+                        traffic = None
+                if args.precision == "f32":
+                    kernel, peak = "k_tower_halo (fused conv0 + residual tower on a halo LDS image, f32 MFMA 16x16x4; one launch = 1+2R 3x3 convs)", F32_MFMA_PEAK_TFLOPS
+                else:  # three bf16 MFMA passes per algorithmic product: the ceiling for algorithmic FLOPs is a third of the bf16 peak
+                    kernel, peak = "k_tower_s3 (fused tower, 3 x bf16 MFMA 16x16x32 per product; peak = 2500 TFLOP/s dense bf16 / 3)", 2500.0 / 3
+                out["roofline"] = {
+                    "bound": "mfma", "kernel": kernel,
+                    "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                    "traffic": traffic, "avg_launch_ms": avg_ms, "launches_timed": prof["conv_launches"],
+                    "flops_per_launch": prof["conv_flops"], "rows_per_launch": prof["conv_rows"],
+                    "forward_ms": prof["forward_ms"] / max(prof["forwards"], 1),
+                }
+            if world == 1 and args.precision == "f32" and not args.no_alt_precision and tak_amd_supports_bf16x3(args):
+                # the same workload on the split-bf16 tower / policy FC (3 bf16 MFMAs per product, f32 accumulate): measured
+                # deviation from the f32 forward ≤ 1.1e-5 relative on the policy, ≤ 5e-6 on the eval (tests/test_gpu_net.py),
+                # inside the 1e-4 of the reference comparison; trees differ from the f32 run only through those last bits
+                try:
+                    dt2, exp2, _, prof2 = run("bf16x3", args.profile_every)
+                    alt = {"precision": "bf16x3", "value": exp2 / dt2, "unit": "node-expansions/s", "ms_per_step": 1000.0 * dt2 / max(args.steps, 1),
+                           "max_deviation_vs_f32_forward": measured_deviation(args, tensors, local_rank)}
+                    if prof2 and prof2["conv_launches"]:
+                        avg2 = prof2["conv_ms"] / prof2["conv_launches"]
+                        alt["tower_avg_launch_ms"] = avg2
+                        alt["tower_f32_equivalent_tflops"] = prof2["conv_flops"] / (avg2 * 1e-3) / 1e12
+                        alt["tower_bf16_mfma_frac_of_peak"] = 3 * prof2["conv_flops"] / (avg2 * 1e-3) / 1e12 / 2500.0
+                    out["alt_precision"] = alt
+                except Exception as ex:
+                    out["alt_precision"] = {"error": repr(ex)}
+            if world == 1 and args.precision == "f32" and not args.no_extras:
+                # more lines than the headline, same engine, same timing discipline (fresh engine, warm-up ply, sync on both sides):
+                # the other single-GPU BASELINE config, the north star's "≥ 10 k concurrent games", and a long run with drains
+                extras = {}
+                try:
+                    dt3, exp3, _, _ = run("f32", 0, steps=120, warmup=0, drain_every=10)
+                    extras["sustained_120_plies"] = {"value": exp3 / dt3, "unit": "node-expansions/s", "plies": 120, "seconds": dt3,
+                                                     "what": "the headline config from ply 0 for 120 plies, finished examples drained every 10 plies", **run.last}
+                    dt4, exp4, _, _ = run("f32", 0, cfg=(args.board, args.blocks, args.filters, args.head, 4 * args.games, tensors), steps=2, warmup=1)
+                    extras["games_x4"] = {"value": exp4 / dt4, "unit": "node-expansions/s", "games": 4 * args.games, "ms_per_step": 1000.0 * dt4 / 2}
+                    if (args.board, args.blocks, args.filters) == (5, 6, 64):
+                        net3, w3 = make_weights(6, 10, 128, "conv", seed=args.seed)
+                        dt5, exp5, _, p5 = run("f32", 1, cfg=(6, 10, 128, "conv", args.games, w3), steps=2, warmup=1)
+                        c3 = {"value": exp5 / dt5, "unit": "node-expansions/s", "ms_per_step": 1000.0 * dt5 / 2,
+                              "workload": f"BASELINE config C3: 6x6 Tak, {args.games} games, {args.rollouts} sims/move, 10-block x 128-filter resnet, conv policy head",
+                              "fp32_ceiling": F32_MFMA_PEAK_TFLOPS * 1e12 / 240_795_648}
+                        if p5 and p5["conv_launches"]:
+                            c3["tower_frac_of_f32_mfma_peak"] = p5["conv_flops"] / (p5["conv_ms"] / p5["conv_launches"] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS
+                        extras["config_c3"] = c3
+                except Exception as ex:
+                    extras["error"] = repr(ex)
+                out["extra"] = extras
+    # config C5 on every rank (the only part of the bench with a data-path collective)
+    if args.train or not (args.no_train or args.no_extras or args.precision != "f32"):
+        def give_up():
+            print(f"bench.py: rank {rank}: the C5 phase did not finish within {args.train_timeout:.0f} s", file=sys.stderr, flush=True)
+            if rank == 0 and out is not None:
+                out.setdefault("extra", {})["train_c5"] = {"error": f"timed out after {args.train_timeout:.0f} s (world {world})"}
+                print(json.dumps(out), flush=True)
+
+        try:
+            if world > 1:
+                with Watchdog(args.train_timeout, give_up, 0 if out is not None or rank != 0 else 3):
+                    c5 = train_c5(args, rank, world, local_rank, dist, backend, barrier)
+            else:
+                c5 = train_c5(args, rank, world, local_rank, dist, backend, barrier)
+        except Exception as ex:
+            if args.train:
+                raise
+            c5 = {"error": repr(ex)}
+        if rank == 0 and args.train:
+            out = {
+                "metric": c5["metric"], "value": c5["value"], "unit": c5["unit"], "n_gpus": world, "steps": c5["optimizer_steps"], "warmup": 0,
+                "ms_per_step": c5["ms_per_optimizer_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic (examples from the network's own self-play)",
+                "config": {"workload": c5["workload"], "parallelism": f"data parallel x{world}, one gradient all-reduce per optimiser step"},
+                "roofline": {"bound": "mfma", "kernel": "whole training step (forward + data gradients + weight gradients + BatchNorm + Adam)",
+                             "achieved": None if c5["frac_of_f32_mfma_peak"] is None else c5["frac_of_f32_mfma_peak"] * F32_MFMA_PEAK_TFLOPS,
+                             "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": c5["frac_of_f32_mfma_peak"], "traffic": None},
+                "train_c5": c5,
+            }
+        elif rank == 0:
+            out.setdefault("extra", {})["train_c5"] = c5
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1 and not args.train:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, net)
             except Exception as ex:  # the checker failing must not hide the GPU number

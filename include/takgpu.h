@@ -410,9 +410,12 @@ int tg_train_chunk(TgEngine* e, int n, const void* states, const int32_t* n_move
                    const float* results, float* loss_p, float* loss_z, int32_t* stepped);
 /* Network::train (network.rs:37-56): fresh Adam state and zeroed gradients, shuffle (Philox keyed by seed; the reference
  * uses thread_rng), chunks_exact(chunk_size) → tg_train_chunk each.  mean losses over the chunks are returned.  Every
- * example is validated before the first chunk, so that with several ranks an argument error cannot strand the others in a
- * collective; tg_train_chunk validates only its own chunk — a data-parallel caller of tg_train_chunk must agree on errors
- * across ranks itself before the chunk that completes an optimiser step. */
+ * example is validated (state, move count, visit sum — the checks of tg_train_chunk) before the first chunk, and with a
+ * communicator or a reduction hook attached the ranks exchange their verdicts through it (one 16-byte all-reduce): if any
+ * rank refuses its examples EVERY rank returns TG_ERR_INVALID_ARG and none trains, so an argument error cannot strand the
+ * others in a collective.  All ranks must therefore call tg_train together.  tg_train_chunk validates only its own chunk — a
+ * data-parallel caller of tg_train_chunk must agree on errors across ranks itself before the chunk that completes an
+ * optimiser step. */
 int tg_train(TgEngine* e, int n, const void* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
              const float* results, uint64_t seed, float* mean_loss_p, float* mean_loss_z, int32_t* steps);
 /* opt.step(); opt.zero_grad() now (network.rs:92-96), whatever the chunk counter says */
@@ -442,6 +445,10 @@ int tg_train_set_allreduce(TgEngine* e, TgAllReduceFn fn, void* ctx, int world_s
 /* device address and length (floats) of the flat gradient buffer the reduction operates on: parameters in the creation
  * order of tg_net_set_tensor's names, BatchNorm buffers excluded */
 int tg_train_grad_buffer(TgEngine* e, float** d_grads, size_t* count);
+/* Measurement: every gradient all-reduce an optimiser step issues (RCCL or the hook) is bracketed
+ * with HIP events on the engine stream; this call synchronises the stream and returns their total duration in
+ * milliseconds and their number since tg_train_create.  Zero reductions on a single-rank trainer. */
+int tg_train_comm_stats(TgEngine* e, double* ms_total, int64_t* reductions);
 
 /* ---------------------------------------------------------------------------------------
  * Pit (replaces `pit`, train/src/pit.rs:15-96): the new network against the old one,

@@ -105,7 +105,13 @@ struct Trainer {
     int world = 1, rank = 0;
     TgAllReduceFn hook = nullptr;
     void* hook_ctx = nullptr;
+    // gradient all-reduces timed with HIP events on the engine stream (tg_train_comm_stats): pairs not yet read back
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ar_events;
+    double ar_ms = 0.0;
+    int64_t ar_count = 0;
+    DevBuf err_flag;  // one float: the ranks agree on an argument error before the first chunk of tg_train
     ~Trainer() {
+        for (auto& p : ar_events) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
         if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
     }
 };
@@ -282,7 +288,18 @@ int optimizer_step(TgEngine* e) {
     float gscale = 1.0f;
     {
         bool reduced;
+        const bool timed = t->hook || t->comm;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (timed) {
+            TG_HIP(hipEventCreate(&ev0));
+            TG_HIP(hipEventCreate(&ev1));
+            TG_HIP(hipEventRecord(ev0, st));
+        }
         int rc = all_reduce_sum(e, t->grads.as<float>(), t->n_params, "gradients", &reduced);
+        if (timed) {
+            hipEventRecord(ev1, st);
+            t->ar_events.emplace_back(ev0, ev1);
+        }
         if (rc) return rc;
         if (reduced) gscale = 1.0f / (float)t->world;
     }
@@ -338,20 +355,32 @@ int train_chunk_dev(TgEngine* e, int n, float* loss_p, float* loss_z, int32_t* s
     return TG_OK;
 }
 
+// The complete host-side check of ONE example (index s of the caller's arrays), used by tg_train_chunk's upload and by
+// tg_train's pass over all examples: a reachable state, 1 ≤ n_moves ≤ TG_MAX_MOVES, at least one visit.
+int validate_example(const TgEngine* e, int s, const uint8_t* states, const int32_t* n_moves, const uint32_t* visits) {
+    int vrc = validate_states(e, 1, states + (size_t)s * e->g.bytes, "training example");
+    if (vrc) return vrc;
+    if (n_moves[s] <= 0 || n_moves[s] > TG_MAX_MOVES)
+        return fail(TG_ERR_INVALID_ARG, "training example " + std::to_string(s) + ": n_moves out of range");
+    uint64_t total = 0;
+    for (int k = 0; k < n_moves[s]; k++) total += visits[(size_t)s * TG_MAX_MOVES + k];
+    if (total == 0) return fail(TG_ERR_INVALID_ARG, "training example " + std::to_string(s) + " without visits (the policy target would be 0/0)");
+    return TG_OK;
+}
+
+// validated = the caller (tg_train) has already checked every example
 int upload_chunk(TgEngine* e, int n, const uint8_t* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
-                 const float* results, const int* order) {
+                 const float* results, const int* order, bool validated = false) {
     Trainer* t = e->trainer;
     hipStream_t st = e->stream;
     const size_t sb = e->g.bytes;
     std::vector<float> z8((size_t)n * 8);
     for (int i = 0; i < n; i++) {
         const int s = order ? order[i] : i;
-        int vrc = validate_states(e, 1, states + (size_t)s * sb, "training example");
-        if (vrc) return vrc;
-        if (n_moves[s] <= 0 || n_moves[s] > TG_MAX_MOVES) return fail(TG_ERR_INVALID_ARG, "training example: n_moves out of range");
-        uint64_t total = 0;
-        for (int k = 0; k < n_moves[s]; k++) total += visits[(size_t)s * TG_MAX_MOVES + k];
-        if (total == 0) return fail(TG_ERR_INVALID_ARG, "training example without visits (the policy target would be 0/0)");
+        if (!validated) {
+            int vrc = validate_example(e, s, states, n_moves, visits);
+            if (vrc) return vrc;
+        }
         for (int k = 0; k < 8; k++) z8[(size_t)i * 8 + k] = results[s];
     }
     // shuffled chunks are gathered on the host first: five copies per chunk, whatever the order
@@ -541,13 +570,25 @@ int tg_train(TgEngine* e, int n, const void* states, const int32_t* n_moves, con
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!states || !n_moves || !moves || !visits || !results))) return fail(TG_ERR_INVALID_ARG, "tg_train: bad arguments");
     Trainer* t = e->trainer;
-    // every example is checked before the first chunk: with several ranks a validation error in the middle of the loop
-    // would leave the other ranks waiting in the optimiser step's all-reduce
-    for (int i = 0; i < n; i++) {
-        rc = validate_states(e, 1, (const uint8_t*)states + (size_t)i * e->g.bytes, "training example");
+    // Every example is checked — completely, once — before the first chunk.  With several ranks the verdicts are then summed
+    // through the reduction (RCCL or the hook): a rank whose examples are fine returns TG_ERR_INVALID_ARG together with the
+    // rank that found the bad one, instead of waiting for it in the first optimiser step's all-reduce.
+    int bad = TG_OK;
+    for (int i = 0; i < n && bad == TG_OK; i++) bad = validate_example(e, i, (const uint8_t*)states, n_moves, visits);
+    if (t->hook || t->comm) {
+        const std::string local_msg = bad ? tg_last_error() : "";
+        TG_HIP(t->err_flag.ensure(16));
+        const float mine[4] = {bad ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f};
+        TG_HIP(hipMemcpyAsync(t->err_flag.p, mine, 16, hipMemcpyHostToDevice, e->stream));
+        bool reduced;
+        rc = all_reduce_sum(e, t->err_flag.as<float>(), 4, "argument check", &reduced);
         if (rc) return rc;
-        if (n_moves[i] < 1 || n_moves[i] > TG_MAX_MOVES) return fail(TG_ERR_INVALID_ARG, "tg_train: example " + std::to_string(i) + " has no moves / too many");
-    }
+        float all[4];
+        TG_HIP(hipMemcpyAsync(all, t->err_flag.p, 16, hipMemcpyDeviceToHost, e->stream));
+        TG_HIP(hipStreamSynchronize(e->stream));
+        if (bad) return fail(TG_ERR_INVALID_ARG, local_msg);
+        if (all[0] != 0.0f) return fail(TG_ERR_INVALID_ARG, "tg_train: " + std::to_string((int)all[0]) + " other rank(s) refused their examples; no rank trains");
+    } else if (bad) return bad;
     // a fresh optimiser per call (network.rs:40-45) on fresh gradients: the reference trains a fresh copy of the network
     // each round (train/src/main.rs `copy`: save + load into a new VarStore), so the gradients an incomplete last step
     // left behind (n / chunk_size not a multiple of chunks_in_step) never reach the next call's first step
@@ -569,7 +610,7 @@ int tg_train(TgEngine* e, int n, const void* states, const int32_t* n_moves, con
     double sp = 0.0, sz = 0.0;
     int chunks = 0, nsteps = 0;
     for (int off = 0; off + cs <= n; off += cs) {  // chunks_exact: the remainder is dropped
-        rc = upload_chunk(e, cs, (const uint8_t*)states, n_moves, moves, visits, results, order.data() + off);
+        rc = upload_chunk(e, cs, (const uint8_t*)states, n_moves, moves, visits, results, order.data() + off, true);
         if (rc) return rc;
         float lp, lz;
         int32_t did;
@@ -670,6 +711,23 @@ int tg_train_grad_buffer(TgEngine* e, float** d_grads, size_t* count) {
     if (!d_grads || !count) return fail(TG_ERR_INVALID_ARG, "null argument");
     *d_grads = e->trainer->grads.as<float>();
     *count = e->trainer->n_params;
+    return TG_OK;
+}
+
+int tg_train_comm_stats(TgEngine* e, double* ms_total, int64_t* reductions) {
+    int rc = need_trainer(e);
+    if (rc) return rc;
+    Trainer* t = e->trainer;
+    TG_HIP(hipStreamSynchronize(e->stream));
+    for (auto& p : t->ar_events) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { t->ar_ms += ms; t->ar_count++; }
+        hipEventDestroy(p.first);
+        hipEventDestroy(p.second);
+    }
+    t->ar_events.clear();
+    if (ms_total) *ms_total = t->ar_ms;
+    if (reductions) *reductions = t->ar_count;
     return TG_OK;
 }
 

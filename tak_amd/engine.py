@@ -93,7 +93,7 @@ ABI_SYMBOLS = [
     "tg_augment_examples",
     "tg_train_create", "tg_train_chunk", "tg_train", "tg_train_step", "tg_train_forward", "tg_train_get_tensor",
     "tg_train_get_grad", "tg_train_commit", "tg_comm_unique_id", "tg_train_comm_init", "tg_train_set_allreduce",
-    "tg_train_grad_buffer", "tg_pit",
+    "tg_train_grad_buffer", "tg_train_comm_stats", "tg_pit",
     "tg_format_move", "tg_parse_move", "tg_format_tps", "tg_parse_tps", "tg_format_example", "tg_parse_example",
 ]
 
@@ -462,6 +462,12 @@ class Engine:
         ptr, cnt = C.c_void_p(0), C.c_size_t(0)
         self._check(self.lib.tg_train_grad_buffer(self.h, C.byref(ptr), C.byref(cnt)))
         return ptr.value, cnt.value
+
+    def train_comm_stats(self):
+        """(total milliseconds, count) of the gradient all-reduces issued by optimiser steps so far (HIP events on the engine stream)"""
+        ms, cnt = C.c_double(0), C.c_int64(0)
+        self._check(self.lib.tg_train_comm_stats(self.h, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
 
     def train_comm_init(self, rank, world, unique_id):
         uid = np.frombuffer(bytes(unique_id), np.uint8).copy()

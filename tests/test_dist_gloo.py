@@ -39,7 +39,9 @@ def test_two_rank_sharding_equals_single_process(orc):
     with tempfile.TemporaryDirectory() as tmp:
         script = os.path.join(tmp, "worker.py")
         open(script, "w").write(WORKER.format(root=ROOT, out=tmp))
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", OMP_NUM_THREADS="1")
+        from bench import free_port
+
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), OMP_NUM_THREADS="1")
         procs = []
         for r in range(2):
             e = dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r))
@@ -85,7 +87,7 @@ def test_data_parallel_host_plumbing():
     with tempfile.TemporaryDirectory() as tmp:
         script = os.path.join(tmp, "dp_worker.py")
         open(script, "w").write(DP_WORKER.format(root=ROOT, out=tmp))
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", OMP_NUM_THREADS="1")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(__import__("bench").free_port()), OMP_NUM_THREADS="1")
         procs = [subprocess.Popen([sys.executable, script], env=dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r))) for r in range(2)]
         for p in procs:
             assert p.wait(timeout=300) == 0

@@ -103,7 +103,10 @@ def test_two_ranks_on_one_gpu_selfplay_and_training(orc):
     with tempfile.TemporaryDirectory() as tmp:
         script = os.path.join(tmp, "worker.py")
         open(script, "w").write(WORKER.format(root=ROOT, out=tmp, cfg=(N, BLOCKS, FILTERS, G, PLIES), kw=KW))
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        from bench import free_port
+
+        # a free port per run: a fixed one collides with a concurrent pytest or with the leftovers of a killed run
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs = [subprocess.Popen([sys.executable, script], env=dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0")) for r in range(2)]
         for p in procs:
             assert p.wait(timeout=600) == 0
@@ -130,3 +133,28 @@ def test_two_ranks_on_one_gpu_selfplay_and_training(orc):
     assert float(shards[0]["lp"]) != float(shards[1]["lp"])  # … although they trained on different examples
     changed = max(np.abs(shards[0]["p_" + torch_ref.abi_name(k)] - v.detach().numpy()).max() for k, v in net.named_parameters())
     assert 0 < changed <= 1e-3 * int(shards[0]["steps"]) * 1.001
+
+
+def test_bench_gpus_2_runs_unaided_on_one_card():
+    """`python bench.py --gpus 2` with no launcher around it: the parent spawns both ranks before touching the GPU, the ranks
+    shard the games, and config C5's data-parallel training step runs with a gradient all-reduce per optimiser step (through
+    the host hook: RCCL refuses two ranks on one device — on a multi-GPU node the same code calls tg_train_comm_init)."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(TAK_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--games", "256", "--rollouts", "24",
+           "--blocks", "2", "--filters", "64", "--train-games", "256", "--train-blocks", "2", "--train-filters", "64", "--train-steps", "2",
+           "--train-chunk", "40", "--train-chunks-in-step", "2", "--train-example-rollouts", "8", "--profile-every", "0"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["expansions_timed"] == 2 * 256 * 25  # both shards: (1 root evaluation + 24 rollouts) per game and ply
+    c5 = out["extra"]["train_c5"]
+    assert "error" not in c5, c5
+    assert c5["n_gpus"] == 2 and c5["optimizer_steps"] == 2 and c5["parameters_identical_on_all_ranks"] is True
+    assert c5["gradient_allreduce"]["count"] == 2 and c5["gradient_allreduce"]["ms_per_step_rank0"] > 0
+    assert c5["value"] > 0 and c5["selfplay_c5net"]["value"] > 0

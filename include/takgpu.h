@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 3
+#define TG_ABI_VERSION 4
 
 /* ---------------------------------------------------------------------------------------
  * Status codes.  TG_PLAY_* mirror reference tak/src/error.rs:4-15 (PlayError) and
@@ -47,9 +47,12 @@ typedef enum TgStatus {
     TG_ERR_LIMIT = -9          /* one of the fixed capacities below (TG_LIMIT_*) was exceeded      */
 } TgStatus;
 
-/* Fixed capacities of the search / self-play engine (the reference's heap structures have none).  Exceeding one
- * sets a sticky error on the engine (TG_ERR_LIMIT from the next polling call) until tg_search_reset /
- * tg_search_create / tg_selfplay_create. */
+/* Fixed capacities of the search / self-play engine (the reference's heap structures have none).
+ * Self-play (tg_selfplay_*): a game that exceeds one is RETIRED — its staged examples are discarded, its slot restarts a
+ * fresh game (next generation, as after a finished game), TgSelfPlayStats.aborted_games counts it — and every other game
+ * keeps running: one runaway game does not stop the other 4095.
+ * Caller-driven search (tg_search_run: Player, pit): exceeding one sets a sticky error on the engine (TG_ERR_LIMIT from
+ * the next polling call) until tg_search_reset / tg_search_create / tg_selfplay_create. */
 #define TG_LIMIT_DEPTH 256          /* longest selection path (plies below the root)                     */
 #define TG_LIMIT_VISITS (1 << 22)   /* visits + virtual visits of one node (exploration-rate table)      */
 #define TG_LIMIT_GAME_PLIES 512     /* examples staged per self-play game = plies of one game            */
@@ -283,6 +286,9 @@ typedef struct TgSearchConfig {
     uint32_t batch;           /* virtual rollouts per tree and iteration before the one network call — the batching of
                                  `Player` (player.rs:77-93; pit.rs BATCH_SIZE 16).  0 = 1 (self_play_parallel: one leaf per game).
                                  games × batch ≤ TgConfig.max_batch */
+    int32_t visit_limit;      /* entries of the exploration-rate table = largest visits + virtual visits of one node;
+                                 0 = TG_LIMIT_VISITS (16 MB).  Smaller values serve tests of the limit handling */
+    int32_t reserved;
 } TgSearchConfig;
 
 int tg_search_create(TgEngine* e, const TgSearchConfig* cfg);
@@ -342,6 +348,9 @@ typedef struct TgSelfPlayConfig {
     int32_t total_games;     /* SELF_PLAY_GAMES: finished games are replaced until
                                 completed + games ≥ total_games (self_play.rs:151,237); 0 = endless */
     int32_t max_examples;    /* capacity of the device example ring drained by tg_selfplay_drain */
+    int32_t max_game_plies;  /* a game is retired (see TG_LIMIT_*) when it would stage more examples than this;
+                                0 = TG_LIMIT_GAME_PLIES, the size of the per-game staging area (the largest value allowed) */
+    int32_t reserved;
 } TgSelfPlayConfig;
 
 /* One training example, fixed-size record (reference alpha-tak/src/example.rs:29-33):
@@ -369,6 +378,9 @@ typedef struct TgSelfPlayStats {
     uint64_t instant_wins;
     uint64_t dropped_examples; /* finished examples overwritten in the output ring before tg_selfplay_drain fetched them
                                   (max_examples too small for the drain interval); 0 in a loss-free run */
+    uint64_t aborted_games;    /* games retired because they exceeded a TG_LIMIT_* capacity (not in games_finished, no examples) */
+    uint64_t alive_games;      /* slots still playing: 0 once every slot has retired (completed + games ≥ total_games) —
+                                  the end of self_play_parallel's `while` loop (self_play.rs:107) */
 } TgSelfPlayStats;
 int tg_selfplay_stats(TgEngine* e, TgSelfPlayStats* out);
 /* copy out up to `cap` finished examples (headers + states + moves + visits) and remove them

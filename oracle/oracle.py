@@ -37,12 +37,13 @@ class SelfPlayConfig(C.Structure):
 
 class SelfPlayStats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in (
-        "games_finished", "examples", "expansions", "evals", "plies", "white_wins", "black_wins", "draws", "instant_wins")]
+        "games_finished", "examples", "expansions", "evals", "plies", "white_wins", "black_wins", "draws", "instant_wins",
+        "dropped_examples", "aborted_games", "alive_games")]  # = TgSelfPlayStats (include/takgpu.h)
 
     def as_dict(self):
-        d = {k: int(getattr(self, k)) for k, _ in self._fields_}
-        d["dropped_examples"] = 0  # the restatement keeps every example (a Vec, as the reference does)
-        return d
+        # dropped_examples / aborted_games are always 0 here: the restatement keeps every example in a Vec and has no
+        # capacities a game could exceed, as the reference
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
 EVAL_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)

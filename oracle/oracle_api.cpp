@@ -357,6 +357,10 @@ void orc_selfplay_stats(void* hh, TgSelfPlayStats* out) {
     out->expansions = sp.s.expansions; out->evals = sp.s.evals; out->plies = sp.plies;
     out->white_wins = sp.white_wins; out->black_wins = sp.black_wins; out->draws = sp.draws;
     out->instant_wins = sp.instant_wins;
+    out->dropped_examples = 0;
+    out->aborted_games = 0;  // the reference's heap structures have no capacities to exceed
+    out->alive_games = 0;
+    for (auto a : sp.s.alive) out->alive_games += a ? 1u : 0u;
 }
 
 // examples in emission order; removes what it returns.  header.game_id = slot | generation << 20

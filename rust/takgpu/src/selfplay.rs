@@ -57,6 +57,8 @@ pub fn self_play_with<const N: usize>(network: &GpuNet<N>, s: SelfPlaySettings) 
         seed: s.seed,
         slot_base: s.slot_base,
         batch: 1, // one leaf per game and iteration (self_play.rs:181-210)
+        visit_limit: 0, // TG_LIMIT_VISITS
+        reserved: 0,
     };
     let drain_cap = (s.games as usize) * 64;
     let cfg = sys::TgSelfPlayConfig {
@@ -67,7 +69,9 @@ pub fn self_play_with<const N: usize>(network: &GpuNet<N>, s: SelfPlaySettings) 
         noise_ratio: s.noise_ratio,
         komi: s.komi,
         total_games: s.self_play_games,
-        max_examples: (drain_cap * 4) as i32, // the ring holds four drain intervals: nothing is dropped
+        max_examples: (drain_cap * 4) as i32, // four drain intervals; an overrun is reported below, never waited for
+        max_game_plies: 0, // TG_LIMIT_GAME_PLIES: a longer game is retired alone (TgSelfPlayStats.aborted_games)
+        reserved: 0,
     };
     check(unsafe { sys::tg_selfplay_create(network.e, &scfg, &cfg) })?;
     let mut file = s.example_dir.map(|d| File::create(format!("{d}/{}.data", sys_time())).unwrap()); // self_play.rs:98
@@ -96,11 +100,19 @@ pub fn self_play_with<const N: usize>(network: &GpuNet<N>, s: SelfPlaySettings) 
         let mut st = std::mem::MaybeUninit::<sys::TgSelfPlayStats>::zeroed();
         check(unsafe { sys::tg_selfplay_stats(network.e, st.as_mut_ptr()) })?;
         let st = unsafe { st.assume_init() };
-        debug_assert_eq!(st.dropped_examples, 0);
-        // every slot retires once completed + games ≥ SELF_PLAY_GAMES (self_play.rs:151,237): done when all examples are out
-        if n_out == 0 && st.examples == examples.len() as u64 && st.games_finished + (s.games as u64) >= s.self_play_games as u64 {
-            let mut roots = vec![0u8; s.games as usize * sb];
-            check(unsafe { sys::tg_search_states(network.e, roots.as_mut_ptr() as *mut _) })?;
+        // Examples the ring overwrote before this loop fetched them can never arrive: say so instead of waiting for them
+        // (st.examples counts what was emitted, examples.len() what was received).
+        if st.dropped_examples > 0 {
+            return Err(crate::TgError {
+                code: sys::TG_ERR_LIMIT,
+                message: format!("self-play: {} examples were overwritten in the device ring before they were drained (max_examples too small)",
+                                 st.dropped_examples),
+            });
+        }
+        // The reference's loop runs `while games.iter().any(Option::is_some)` (self_play.rs:107): a slot retires when its game
+        // ends with completed + WORKERS ≥ SELF_PLAY_GAMES (:151,237), and up to `games` games are still in flight when the first
+        // slot retires.  So: until NO slot is alive, and every emitted example has been received.
+        if st.alive_games == 0 && n_out == 0 && st.examples == examples.len() as u64 {
             break;
         }
     }

@@ -72,6 +72,7 @@ struct SearchDev {
     // games
     uint8_t* root_state; // [G][state bytes]
     uint8_t* alive;      // [G]
+    uint8_t* abort;      // [G] self-play: ERRF_* bits of the capacity this game has exceeded (retired at the end of the ply)
     uint32_t* generation;// [G]
     // per-iteration leaf hand-off
     int32_t* path_len;   // [G·batch]  (every per-leaf array below has G·batch entries, slot = g·batch + pass)
@@ -93,6 +94,7 @@ struct SearchDev {
                                    // serialise 2·G same-address atomics per iteration, ≈ 11 ns each)
     int G, n, cin_pad, P, ctab_size, legacy5, evaluator;
     int batch, pass;     // virtual rollouts per tree and iteration; the one this launch performs (leaf slot = g·batch + pass)
+    int retire;          // 1 = a game past a capacity is retired on its own (self-play); 0 = sticky engine error (caller-driven search)
     uint32_t slot_base;
     uint64_t seed;
 };
@@ -117,10 +119,12 @@ struct SelfPlayDev {
     uint8_t* mask;        // [G] scratch mask (noise phase)
     unsigned long long* stats;  // games_finished, examples, plies, white, black, draws, instant_wins
     int ex_per_game, max_examples;
+    int max_game_plies;   // ≤ ex_per_game: a game that would stage more examples is retired
     int rollouts, noise_plies, exploit_plies, komi, total_games;
     float noise_alpha, noise_ratio;
 };
 
-enum { ST_FINISHED = 0, ST_EXAMPLES = 1, ST_PLIES = 2, ST_WHITE = 3, ST_BLACK = 4, ST_DRAWS = 5, ST_INSTANT = 6, ST_COUNT = 8 };
+enum { ST_FINISHED = 0, ST_EXAMPLES = 1, ST_PLIES = 2, ST_WHITE = 3, ST_BLACK = 4, ST_DRAWS = 5, ST_INSTANT = 6, ST_ABORTED = 7, ST_COUNT = 8 };
+constexpr uint8_t FIN_ABORTED = 0x80;  // SelfPlayDev.fin: not a TgResult — the game exceeded a capacity and is retired without examples
 
 }  // namespace tg

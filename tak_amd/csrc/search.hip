@@ -17,7 +17,7 @@ struct Search {
     TgSearchConfig cfg;
     SearchDev d;
     DevBuf hot, cold, root, alloc, chunk_head, chunk_link, chunk_fwd, chunk_used, free_ring, pool_ctl, root_state, alive, generation, path_len, path, leaf_kind, leaf_hash, planes, leaf_state, policy, eval,
-        ctab, err, counters, op, active, noise;
+        ctab, err, counters, op, active, noise, abort;
     DevBuf r_moves, r_visits, r_prior, r_q, r_counts, r_rv, r_rq, s_moves;
     // self-play
     bool selfplay = false;
@@ -37,7 +37,7 @@ static int describe_errors(uint32_t bits) {
         if (bits & b) { if (!msg.empty()) msg += "; "; msg += m; code = c; }
     };
     add(ERRF_DEPTH, "selection path deeper than 256 plies (TG_LIMIT_DEPTH)", TG_ERR_LIMIT);
-    add(ERRF_CTAB, "a node was visited more than 2^22 times (TG_LIMIT_VISITS)", TG_ERR_LIMIT);
+    add(ERRF_CTAB, "a node was visited more often than the exploration-rate table is long (TG_LIMIT_VISITS / TgSearchConfig.visit_limit)", TG_ERR_LIMIT);
     add(ERRF_EXAMPLES, "a game lasted more than 512 plies (TG_LIMIT_GAME_PLIES)", TG_ERR_LIMIT);
     add(ERRF_MOVES, "a position has more than TG_MAX_MOVES legal moves", TG_ERR_LIMIT);
     add(ERRF_PICK, "pick_move on a root without visits", TG_ERR_STATE);
@@ -102,6 +102,8 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     if (B > 4096 || (e->cfg.evaluator == TG_EVAL_RESNET && (size_t)cfg->games * B > (size_t)e->cfg.max_batch))
         return fail(TG_ERR_INVALID_ARG, "games x batch leaves per iteration exceed max_batch");
     if (cfg->arena_nodes != 0 && cfg->arena_nodes < 1024) return fail(TG_ERR_INVALID_ARG, "arena_nodes must be 0 (auto) or at least 1024");
+    if (cfg->visit_limit < 0 || (cfg->visit_limit != 0 && cfg->visit_limit < 16) || cfg->visit_limit > TG_LIMIT_VISITS)
+        return fail(TG_ERR_INVALID_ARG, "visit_limit must be 0 (= TG_LIMIT_VISITS) or in 16..TG_LIMIT_VISITS");
     if (e->cfg.evaluator == TG_EVAL_RESNET && !net_ready(e)) return fail(TG_ERR_STATE, "network weights not finalized (tg_net_finalize)");
     TG_HIP(hipSetDevice(e->cfg.device));
     if (e->search) {
@@ -151,6 +153,7 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     TG_HIP(s->pool_ctl.ensure(4 * 8));
     TG_HIP(s->root_state.ensure(G * e->g.bytes));
     TG_HIP(s->alive.ensure(G));
+    TG_HIP(s->abort.ensure(G));
     TG_HIP(s->generation.ensure(G * 4));
     TG_HIP(s->path_len.ensure(G * B * 4));
     TG_HIP(s->path.ensure(G * B * MAX_DEPTH * 4));
@@ -181,7 +184,7 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     }
     // exploration_rate(n) = ln((1 + n + base) / base) + init for integer visit counts (mcts.rs:10-12),
     // evaluated once on the host in f32 so that every GPU and the CPU agree on the last bit
-    const int ctab_size = 1 << 22;  // TG_LIMIT_VISITS
+    const int ctab_size = cfg->visit_limit ? cfg->visit_limit : TG_LIMIT_VISITS;
     std::vector<float> ctab(ctab_size);
     for (int i = 0; i < ctab_size; i++) {
         float nf = (float)i;
@@ -193,12 +196,13 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     TG_HIP(hipMemsetAsync(s->counters.p, 0, G * 16, e->stream));
     TG_HIP(hipMemsetAsync(s->generation.p, 0, G * 4, e->stream));
     TG_HIP(hipMemsetAsync(s->alive.p, 0, G, e->stream));
+    TG_HIP(hipMemsetAsync(s->abort.p, 0, G, e->stream));
     SearchDev& d = s->d;
     d.hot = s->hot.as<NodeHot>(); d.cold = s->cold.as<NodeCold>(); d.root = s->root.as<uint32_t>(); d.alloc = s->alloc.as<uint32_t>();
     d.chunk_head = s->chunk_head.as<uint32_t>(); d.chunk_link = s->chunk_link.as<uint32_t>(); d.chunk_fwd = s->chunk_fwd.as<uint32_t>();
     d.chunk_used = s->chunk_used.as<uint32_t>(); d.free_ring = s->free_ring.as<uint32_t>();
     d.pool_ctl = s->pool_ctl.as<unsigned long long>(); d.n_chunks = (uint32_t)n_chunks; d.chunk_shift = chunk_shift;
-    d.root_state = s->root_state.as<uint8_t>(); d.alive = s->alive.as<uint8_t>(); d.generation = s->generation.as<uint32_t>();
+    d.root_state = s->root_state.as<uint8_t>(); d.alive = s->alive.as<uint8_t>(); d.abort = s->abort.as<uint8_t>(); d.generation = s->generation.as<uint32_t>();
     d.path_len = s->path_len.as<int32_t>(); d.path = s->path.as<uint32_t>(); d.leaf_kind = s->leaf_kind.as<uint8_t>();
     d.leaf_hash = s->leaf_hash.as<uint64_t>(); d.planes = s->planes.as<float>(); d.leaf_state = s->leaf_state.as<uint8_t>();
     d.policy = s->policy.as<float>();
@@ -211,6 +215,7 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     d.G = cfg->games; d.n = e->g.n; d.cin_pad = cin_pad; d.P = e->policy_size; d.ctab_size = ctab_size;
     d.legacy5 = e->legacy5 ? 1 : 0; d.evaluator = e->cfg.evaluator; d.slot_base = cfg->slot_base; d.seed = cfg->seed;
     d.batch = (int)B; d.pass = 0;
+    d.retire = 0;  // tg_selfplay_create turns it on: only the self-play driver can restart a game on its own
     d.logits = nullptr; d.logit_ld = 0;  // refreshed before every iteration (bind_logits)
     e->search = sp.release();
     return TG_OK;
@@ -613,6 +618,8 @@ int tg_search_pool(TgEngine* e, uint64_t* nodes_total, uint64_t* nodes_in_use, u
 int tg_selfplay_create(TgEngine* e, const TgSearchConfig* scfg, const TgSelfPlayConfig* cfg) {
     if (!cfg || !scfg) return fail(TG_ERR_INVALID_ARG, "null self-play config");
     if (cfg->rollouts < 1 || cfg->max_examples < 1) return fail(TG_ERR_INVALID_ARG, "rollouts and max_examples must be positive");
+    if (cfg->max_game_plies < 0 || cfg->max_game_plies > TG_LIMIT_GAME_PLIES)
+        return fail(TG_ERR_INVALID_ARG, "max_game_plies must be 0 (= TG_LIMIT_GAME_PLIES) or in 1..TG_LIMIT_GAME_PLIES");
     TgSearchConfig sc1 = *scfg;
     sc1.batch = 1;  // self_play_parallel gathers ONE leaf per game and iteration (self_play.rs:181-210)
     int rc = search_alloc(e, &sc1);
@@ -620,8 +627,9 @@ int tg_selfplay_create(TgEngine* e, const TgSearchConfig* scfg, const TgSelfPlay
     Search* s = e->search;
     s->selfplay = true;
     s->spcfg = *cfg;
+    s->d.retire = 1;
     const size_t G = (size_t)s->d.G, sb = (size_t)e->g.bytes;
-    const int epg = 512;
+    const int epg = TG_LIMIT_GAME_PLIES;
     const size_t ME = (size_t)cfg->max_examples;
     TG_HIP(s->st_hdr.ensure(G * epg * sizeof(ExampleRec)));
     TG_HIP(s->st_state.ensure(G * epg * sb));
@@ -649,6 +657,7 @@ int tg_selfplay_create(TgEngine* e, const TgSearchConfig* scfg, const TgSelfPlay
     p.fin = s->fin.as<uint8_t>(); p.recycle = s->recycle.as<uint8_t>(); p.out_off = s->out_off.as<uint32_t>();
     p.chosen = s->chosen.as<int32_t>(); p.mask = s->mask.as<uint8_t>(); p.stats = s->stats.as<unsigned long long>();
     p.ex_per_game = epg; p.max_examples = cfg->max_examples;
+    p.max_game_plies = cfg->max_game_plies ? cfg->max_game_plies : epg;
     p.rollouts = cfg->rollouts; p.noise_plies = cfg->noise_plies; p.exploit_plies = cfg->exploit_plies; p.komi = cfg->komi;
     p.total_games = cfg->total_games; p.noise_alpha = cfg->noise_alpha; p.noise_ratio = cfg->noise_ratio;
     // games[i] = Game::with_komi(komi), nodes[i] = Node::default()  (self_play.rs:102-103)
@@ -712,6 +721,13 @@ int tg_selfplay_stats(TgEngine* e, TgSelfPlayStats* out) {
     out->games_finished = st[ST_FINISHED]; out->examples = st[ST_EXAMPLES]; out->plies = st[ST_PLIES];
     out->white_wins = st[ST_WHITE]; out->black_wins = st[ST_BLACK]; out->draws = st[ST_DRAWS]; out->instant_wins = st[ST_INSTANT];
     out->expansions = c[0]; out->evals = c[1];
+    out->aborted_games = st[ST_ABORTED];
+    {
+        std::vector<uint8_t> alive((size_t)s->d.G);
+        TG_HIP(hipMemcpy(alive.data(), s->alive.p, alive.size(), hipMemcpyDeviceToHost));
+        out->alive_games = 0;
+        for (uint8_t a : alive) out->alive_games += a ? 1u : 0u;
+    }
     {   // examples the ring has overwritten since the last drain count as dropped as soon as they are observable
         const unsigned long long ME = (unsigned long long)s->p.max_examples;
         unsigned long long lost = st[ST_EXAMPLES] - s->drained > ME ? st[ST_EXAMPLES] - s->drained - ME : 0ull;

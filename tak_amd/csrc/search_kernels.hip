@@ -19,6 +19,13 @@ constexpr int WPB = 4;  // waves (games) per 256-thread block
 
 __device__ inline int game_of_wave() { return (int)(blockIdx.x * WPB + (threadIdx.x >> 6)); }
 __device__ inline void flag(const SearchDev& S, uint32_t bit) { atomicOr(S.err, bit); }
+// A game ran into one of the fixed capacities (TG_LIMIT_*, takgpu.h).  Self-play retires that game alone — the bit is kept
+// per game, its wave stops touching the tree, and the end of the ply discards its examples and restarts the slot;
+// a caller-driven search has nobody to restart the game, so the engine-wide sticky error stays.  Called by the whole wave.
+__device__ inline void limit_hit(const SearchDev& S, int g, uint32_t bit) {
+    if (S.retire) { if (lane_id() == 0) S.abort[g] = (uint8_t)(S.abort[g] | bit); }
+    else flag(S, bit);
+}
 __device__ inline void wave_sync_mem() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 
 // Diagnostic build only (-DTG_TREE_STAMPS, scripts/probes/tree_stamps.py): s_memtime stamps of the waves of the first 64 games
@@ -102,7 +109,7 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
     // leaf slot of this pass: `batch` virtual rollouts per tree and iteration (Player's batching, player.rs:77-93), pass p
     // writing slot g·batch + p
     const size_t slot = (size_t)g * (size_t)S.batch + (size_t)pass;
-    if (!S.alive[g] || (active && !active[g])) {
+    if (!S.alive[g] || (active && !active[g]) || (S.retire && S.abort[g])) {
         if (lane == 0) S.leaf_kind[slot] = 0;
         return;
     }
@@ -140,7 +147,7 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
                 count = (uint32_t)ws_movegen(s, geo, EX_MOVES, [&](int idx, uint32_t code) { mvl[idx] = (uint16_t)code; });
                 TG_TSTAMP(g, 26);
                 if (count > (uint32_t)EX_MOVES) {
-                    flag(S, ERRF_MOVES);
+                    limit_hit(S, g, ERRF_MOVES);
                     if (lane == 0) S.leaf_kind[slot] = 0;
                     return;
                 }
@@ -188,7 +195,14 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
         const uint32_t nsum = vis + vv;
         const float visit_count = (float)nsum;
         uint32_t ti = nsum;
-        if ((int)ti >= S.ctab_size) { flag(S, ERRF_CTAB); ti = (uint32_t)S.ctab_size - 1; }
+        if ((int)ti >= S.ctab_size) {
+            limit_hit(S, g, ERRF_CTAB);
+            if (S.retire) {  // nothing of this rollout has touched the tree yet (virtual visits are marked in the unwind)
+                if (lane == 0) S.leaf_kind[slot] = 0;
+                return;
+            }
+            ti = (uint32_t)S.ctab_size - 1;
+        }
         const float c_rate = S.ctab[ti];
         const float root_n = sqrtf(visit_count);
         float best = -INFINITY;
@@ -233,7 +247,7 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
         ws_play(s, mv, geo);
         TG_TSTAMP(g, 6 + 2 * (depth < 9 ? depth : 9));  // move played
         if (depth >= MAX_DEPTH) {
-            flag(S, ERRF_DEPTH);
+            limit_hit(S, g, ERRF_DEPTH);
             if (lane == 0) S.leaf_kind[slot] = 0;
             return;
         }
@@ -608,7 +622,7 @@ __device__ inline void stage_example(const SearchDev& S, const SelfPlayDev& P, i
                                      uint32_t nmoves, int& slot_out) {
     // reserves the next staging slot of game g and writes header + state; returns the slot (or -1)
     int k = P.st_count[g];
-    if (k >= P.ex_per_game) { flag(S, ERRF_EXAMPLES); slot_out = -1; return; }
+    if (k >= P.max_game_plies) { limit_hit(S, g, ERRF_EXAMPLES); slot_out = -1; return; }
     size_t e = (size_t)g * P.ex_per_game + k;
     ws_store(s, P.st_state + e * geo.bytes, geo);
     if (lane_id() == 0) {
@@ -640,7 +654,11 @@ __global__ __launch_bounds__(256) void k_sp_instant_win(SearchDev S, SelfPlayDev
     int count = ws_movegen(s, geo, EX_MOVES, [&](int idx, uint32_t code) { mv[idx] = (uint16_t)code; });
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (count > EX_MOVES) { flag(S, ERRF_EXAMPLES); return; }
+    if (count > EX_MOVES) {  // (no such position exists on boards up to 6×6; kept as a bound on the LDS staging)
+        limit_hit(S, g, ERRF_MOVES);
+        if (lane == 0) P.fin[g] = FIN_ABORTED;
+        return;
+    }
     bool win = false;
     for (int k = 0; k < count; k++) {
         WState t = s;
@@ -655,7 +673,11 @@ __global__ __launch_bounds__(256) void k_sp_instant_win(SearchDev S, SelfPlayDev
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     int slot;
     stage_example(S, P, g, s, geo, (uint32_t)count, slot);
-    if (slot >= 0) {
+    if (slot < 0) {  // the game is past max_game_plies: retired without examples
+        if (lane == 0) P.fin[g] = FIN_ABORTED;
+        return;
+    }
+    {
         size_t e = (size_t)g * P.ex_per_game + slot;
         for (int k = lane; k < count; k += 64) {
             P.st_moves[e * EX_MOVES + k] = mv[k];
@@ -676,8 +698,9 @@ __global__ __launch_bounds__(1024) void k_sp_finish_scan(SearchDev S, SelfPlayDe
     const int per = (S.G + 1023) / 1024;
     const int g0 = tid * per, g1 = min(g0 + per, S.G);
     uint32_t nf = 0, ne = 0;
+    // (a retired game — FIN_ABORTED — is not a completed game and emits nothing; its slot always restarts)
     for (int g = g0; g < g1; g++)
-        if (P.fin[g]) { nf++; ne += (uint32_t)P.st_count[g]; }
+        if (P.fin[g] && P.fin[g] != FIN_ABORTED) { nf++; ne += (uint32_t)P.st_count[g]; }
     s_fin[tid] = nf;
     s_ex[tid] = ne;
     __syncthreads();
@@ -692,6 +715,7 @@ __global__ __launch_bounds__(1024) void k_sp_finish_scan(SearchDev S, SelfPlayDe
     uint32_t rf = s_fin[tid] - nf, re = s_ex[tid] - ne;
     for (int g = g0; g < g1; g++) {
         if (!P.fin[g]) continue;
+        if (P.fin[g] == FIN_ABORTED) { P.recycle[g] = 1; continue; }
         unsigned long long completed = done0 + rf + 1;
         P.recycle[g] = (P.total_games == 0 || completed + (unsigned long long)S.G < (unsigned long long)P.total_games) ? 1 : 0;
         P.out_off[g] = (uint32_t)((ex0 + re) % (unsigned long long)P.max_examples);
@@ -713,8 +737,9 @@ __global__ __launch_bounds__(256) void k_sp_finish_apply(SearchDev S, SelfPlayDe
     const uint32_t r = P.fin[g];
     if (!r) return;
     const Geom geo = make_geom(S.n);
+    const bool aborted = r == FIN_ABORTED;
     const float white_result = (r == TG_WHITE_ROAD || r == TG_WHITE_FLAT) ? 1.0f : (r == TG_BLACK_ROAD || r == TG_BLACK_FLAT) ? -1.0f : 0.0f;
-    const int cnt = P.st_count[g];
+    const int cnt = aborted ? 0 : P.st_count[g];
     const uint32_t off = P.out_off[g];
     for (int k = 0; k < cnt; k++) {
         size_t e = (size_t)g * P.ex_per_game + k;
@@ -738,7 +763,8 @@ __global__ __launch_bounds__(256) void k_sp_finish_apply(SearchDev S, SelfPlayDe
         S.generation[g] += 1;
         if (!P.recycle[g]) S.alive[g] = 0;
         op[g] = -2;  // *node = Node::default()
-        atomicAdd(&P.stats[white_result > 0 ? ST_WHITE : white_result < 0 ? ST_BLACK : ST_DRAWS], 1ull);
+        S.abort[g] = 0;
+        atomicAdd(&P.stats[aborted ? ST_ABORTED : white_result > 0 ? ST_WHITE : white_result < 0 ? ST_BLACK : ST_DRAWS], 1ull);
     }
 }
 
@@ -757,6 +783,10 @@ __global__ __launch_bounds__(256) void k_sp_pick(SearchDev S, SelfPlayDev P, int
     const int lane = lane_id();
     if (lane == 0) { P.fin[g] = 0; op[g] = -1; }
     if (!S.alive[g]) return;
+    if (S.abort[g]) {  // the search of this ply ran into a capacity (depth, visits): retire the game
+        if (lane == 0) P.fin[g] = FIN_ABORTED;
+        return;
+    }
     const Geom geo = make_geom(S.n);
     const NodeHot* hot = S.hot;
     const NodeCold* cold = S.cold;
@@ -810,7 +840,11 @@ __global__ __launch_bounds__(256) void k_sp_pick(SearchDev S, SelfPlayDev P, int
     // example = (game before the move, visit counts of every child)
     int slot;
     stage_example(S, P, g, s, geo, nchild, slot);
-    if (slot >= 0) {
+    if (slot < 0) {  // the game is past max_game_plies
+        if (lane == 0) P.fin[g] = FIN_ABORTED;
+        return;
+    }
+    {
         size_t e = (size_t)g * P.ex_per_game + slot;
         for (uint32_t i = lane; i < nchild && i < EX_MOVES; i += 64) {
             P.st_moves[e * EX_MOVES + i] = cold[cb + i].mv;

@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TAKGPU_LIB") or os.path.join(_HERE, "libtakgpu.so")  # TAKGPU_LIB: probe builds (scripts/probes)
 
-TG_ABI_VERSION = 3
+TG_ABI_VERSION = 4
 TG_MAX_MOVES = 512
 HEAD_FC5, HEAD_CONV = 0, 1
 EVAL_RESNET, EVAL_DUMMY, EVAL_HASH = 0, 1, 2
@@ -33,7 +33,8 @@ class TgConfig(C.Structure):
 
 class TgSearchConfig(C.Structure):
     _fields_ = [("games", C.c_int32), ("arena_nodes", C.c_int32), ("exploration_base", C.c_float),
-                ("exploration_init", C.c_float), ("seed", C.c_uint64), ("slot_base", C.c_uint32), ("batch", C.c_uint32)]
+                ("exploration_init", C.c_float), ("seed", C.c_uint64), ("slot_base", C.c_uint32), ("batch", C.c_uint32),
+                ("visit_limit", C.c_int32), ("reserved", C.c_int32)]
 
 
 class TgProfile(C.Structure):
@@ -47,13 +48,13 @@ class TgProfile(C.Structure):
 class TgSelfPlayConfig(C.Structure):
     _fields_ = [("rollouts", C.c_int32), ("noise_plies", C.c_int32), ("exploit_plies", C.c_int32),
                 ("noise_alpha", C.c_float), ("noise_ratio", C.c_float), ("komi", C.c_int32),
-                ("total_games", C.c_int32), ("max_examples", C.c_int32)]
+                ("total_games", C.c_int32), ("max_examples", C.c_int32), ("max_game_plies", C.c_int32), ("reserved", C.c_int32)]
 
 
 class TgSelfPlayStats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in (
         "games_finished", "examples", "expansions", "evals", "plies", "white_wins", "black_wins", "draws", "instant_wins",
-        "dropped_examples")]
+        "dropped_examples", "aborted_games", "alive_games")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -531,9 +532,9 @@ class Engine:
         self._check(self.lib.tg_policy_eval_dev(self.h, n, C.c_void_p(d_states), C.c_void_p(d_policy), C.c_void_p(d_eval)))
 
     # ---- Node / search ----------------------------------------------------------------------------
-    def search_create(self, games, arena_nodes=1 << 16, base=500.0, init=4.0, seed=0, slot_base=0, batch=1):
+    def search_create(self, games, arena_nodes=1 << 16, base=500.0, init=4.0, seed=0, slot_base=0, batch=1, visit_limit=0):
         """batch: virtual rollouts per tree and iteration (Player's batching); games * batch <= max_batch"""
-        cfg = TgSearchConfig(games, arena_nodes, base, init, seed, slot_base, batch)
+        cfg = TgSearchConfig(games, arena_nodes, base, init, seed, slot_base, batch, visit_limit, 0)
         self._check(self.lib.tg_search_create(self.h, C.byref(cfg)))
         self.games = games
 
@@ -613,9 +614,10 @@ class Engine:
     # ---- self_play_parallel ------------------------------------------------------------------------
     def selfplay_create(self, games, arena_nodes=0, base=500.0, init=4.0, seed=0, rollouts=400, noise_plies=80,
                         exploit_plies=40, noise_alpha=0.2, noise_ratio=0.3, komi=2, total_games=0, max_examples=1 << 16,
-                        slot_base=0):
-        scfg = TgSearchConfig(games, arena_nodes, base, init, seed, slot_base, 0)
-        cfg = TgSelfPlayConfig(rollouts, noise_plies, exploit_plies, noise_alpha, noise_ratio, komi, total_games, max_examples)
+                        slot_base=0, max_game_plies=0, visit_limit=0):
+        scfg = TgSearchConfig(games, arena_nodes, base, init, seed, slot_base, 0, visit_limit, 0)
+        cfg = TgSelfPlayConfig(rollouts, noise_plies, exploit_plies, noise_alpha, noise_ratio, komi, total_games, max_examples,
+                               max_game_plies, 0)
         self._check(self.lib.tg_selfplay_create(self.h, C.byref(scfg), C.byref(cfg)))
         self.games = games
 

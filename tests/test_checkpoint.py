@@ -60,3 +60,35 @@ def test_mismatching_archives_fail_loudly(tmp_path):
     checkpoint.save_tch_varstore(path, shallow, 1)
     with pytest.raises(ValueError):
         checkpoint.load_tch_varstore(path, 2)
+
+
+ARCHIVES = [("tch_net4_conv_1x32", 4, 1, 32, "conv", 11), ("tch_net6_conv_1x32", 6, 1, 32, "conv", 12)]
+
+
+@pytest.mark.parametrize("stem,n,blocks,filters,head,seed", ARCHIVES)
+def test_reads_an_archive_written_the_way_tch_writes_it(stem, n, blocks, filters, head, seed):
+    """tests/golden/tch_*.model were written by libtorch's torch::serialize::OutputArchive — write(name, tensor, false) per
+    variable + save_to, the calls behind tch's VarStore::save (tests/golden/tch_archive_writer.cpp, make_tch_archive.py) —
+    not by torch.jit.script as the round-trip tests above: the container the reference binary produces."""
+    import zipfile
+
+    from tak_amd import checkpoint
+
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    path = os.path.join(golden, stem + ".model")
+    names = zipfile.ZipFile(path).namelist()
+    assert any(nm.endswith("data.pkl") for nm in names) and sum("/data/" in nm for nm in names) == 8 + 14 * blocks
+    back = checkpoint.load_tch_varstore(path, blocks)
+    want = torch_ref.abi_tensors(torch_ref.make_net(n, blocks, filters, head, seed=seed))
+    exp = np.load(os.path.join(golden, stem + ".expected.npz"))
+    assert set(back) == set(want)
+    for k in want:
+        assert back[k].shape == want[k].shape and back[k].dtype == np.float32
+        assert np.isclose(back[k].astype(np.float64).sum(), float(exp["sum_" + k]), rtol=0, atol=1e-9), k
+        assert np.array_equal(back[k], want[k]), k  # same image, same seed: the generator's weights
+    # and the network they describe returns the recorded outputs (PyTorch-CPU fp32)
+    from oracle import oracle as orc
+
+    net = torch_ref.load_abi_tensors(torch_ref.make_net(n, blocks, filters, head, seed=0), back)
+    p, v = torch_ref.forward(net, orc.encode(n, exp["states"]))
+    assert np.array_equal(p, exp["policy"]) and np.array_equal(v, exp["value"])

@@ -39,10 +39,14 @@ def test_policy_eval_full_batch_properties(c2, orc):
         if key in first:
             assert np.array_equal(p[i], p[first[key]]) and v[i] == v[first[key]]
         first.setdefault(key, i)
-    # a slice against PyTorch fp32 (north_star tolerance)
-    idx = np.arange(0, G, 64)
-    p_ref, v_ref = torch_ref.forward(net, orc.encode(5, sts[idx]))
-    assert np.abs(p[idx] - p_ref).max() <= 1e-4 and np.abs(v[idx] - v_ref).max() <= 1e-4
+    # ALL 4096 rows of the full batch — the batch the benchmarked kernels (k_tower_halo, k_fc_ring) run on — against PyTorch
+    # fp32 (north_star tolerance 1e-4), in chunks so the CPU reference stays in cache
+    worst_p = worst_v = 0.0
+    for lo in range(0, G, 512):
+        p_ref, v_ref = torch_ref.forward(net, orc.encode(5, sts[lo : lo + 512]))
+        worst_p = max(worst_p, float(np.abs(p[lo : lo + 512] - p_ref).max()))
+        worst_v = max(worst_v, float(np.abs(v[lo : lo + 512] - v_ref).max()))
+    assert worst_p <= 1e-4 and worst_v <= 1e-4, (worst_p, worst_v)
 
 
 def test_search_full_size_invariants_and_slice_parity(c2, orc):
@@ -172,9 +176,15 @@ def test_config_c3_full_size(orc):
     sts = np.tile(base, (G // len(base) + 1, 1))[:G]
     p, v = e.policy_eval(sts)
     assert p.shape == (G, 9036) and np.abs(p.sum(1) - 1).max() < 2e-5 and (p > 0).all() and (np.abs(v) <= 1).all()
-    idx = np.arange(0, G, 128)
-    p_ref, v_ref = torch_ref.forward(net, orc.encode(n, sts[idx]))
-    assert np.abs(p[idx] - p_ref).max() <= 1e-4 and np.abs(v[idx] - v_ref).max() <= 1e-4
+    # 1024 rows of the full batch against PyTorch fp32 (every 4th row: all workgroup positions and row tiles are hit)
+    idx = np.arange(0, G, 4)
+    worst_p = worst_v = 0.0
+    for lo in range(0, len(idx), 128):
+        sel = idx[lo : lo + 128]
+        p_ref, v_ref = torch_ref.forward(net, orc.encode(n, sts[sel]))
+        worst_p = max(worst_p, float(np.abs(p[sel] - p_ref).max()))
+        worst_v = max(worst_v, float(np.abs(v[sel] - v_ref).max()))
+    assert worst_p <= 1e-4 and worst_v <= 1e-4, (worst_p, worst_v)
     assert np.array_equal(p[0], p[len(base)]) and v[0] == v[len(base)]  # same position, another slot of the batch
     iters = 12
     e.search_create(G, arena_nodes=1 << 13)

@@ -257,3 +257,24 @@ def test_checkpoint_archive_loads_into_the_engine(orc, tmp_path, n, blocks, filt
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     p_ref, v_ref = torch_ref.forward(net, orc.encode(n, sts))
     assert np.abs(outs[1][0] - p_ref).max() <= 1e-4 and np.abs(outs[1][1] - v_ref).max() <= 1e-4
+
+
+@pytest.mark.parametrize("stem,n,blocks,filters", [("tch_net4_conv_1x32", 4, 1, 32), ("tch_net6_conv_1x32", 6, 1, 32)])
+def test_archive_written_by_libtorch_loads_into_the_engine(stem, n, blocks, filters):
+    """N4 against the real container: tests/golden/tch_*.model were written by libtorch's OutputArchive (write + save_to: the
+    calls behind tch's VarStore::save, tests/golden/tch_archive_writer.cpp), with tch-style variable names.  Archive →
+    tak_amd.checkpoint → tg_net_set_tensor → tg_policy_eval must give the outputs recorded with PyTorch-CPU on the same
+    weights (≤ 1e-4).  The variable NAMES remain the recalled tch convention (tch is not vendored in the reference)."""
+    import os
+
+    import tak_amd
+    from tak_amd import checkpoint
+
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    loaded = checkpoint.load_tch_varstore(os.path.join(golden, stem + ".model"), blocks)
+    exp = np.load(os.path.join(golden, stem + ".expected.npz"))
+    e = tak_amd.Engine(n, res_blocks=blocks, filters=filters, policy_head=tak_amd.HEAD_CONV, evaluator=tak_amd.EVAL_RESNET, max_batch=64)
+    e.load_state_dict(loaded)
+    p, v = e.policy_eval(exp["states"])
+    assert np.abs(p - exp["policy"]).max() <= 1e-4 and np.abs(v - exp["value"]).max() <= 1e-4
+    e.close()

@@ -460,3 +460,104 @@ def test_states_no_game_can_reach_are_refused(orc):
     e.search_run(20)
     assert (e.search_root()["root_visits"] == 20).all()
     e.close()
+
+
+def _parse_tree(rec):
+    """pre-order dump → children index lists (an uninitialised child is one record with n_children = 0xFFFF)"""
+    kids = [[] for _ in range(len(rec))]
+    pos = [0]
+
+    def walk():
+        me = pos[0]
+        pos[0] += 1
+        if rec["n_children"][me] == 0xFFFF:
+            return
+        for _ in range(int(rec["n_children"][me])):
+            kids[me].append(pos[0])
+            walk()
+
+    walk()
+    assert pos[0] == len(rec)
+    return kids
+
+
+def _ucb(rec, ch, node, base=500.0, init=4.0):
+    """upper confidence bounds of `node`'s children (mcts.rs:94-118), f32"""
+    f32 = np.float32
+    prior = rec["prior_bits"].view(np.float32)
+    q = rec["q_bits"].view(np.float32)
+    ns = f32(int(rec["visits"][node]) + int(rec["virtual_visits"][node]))
+    c = f32(np.log(f32((f32(1.0) + ns + f32(base)) / f32(base)))) + f32(init)
+    cv, cvirt = rec["visits"][ch].astype(np.float32), rec["virtual_visits"][ch].astype(np.float32)
+    cn = cv + cvirt
+    qv = np.where(cn > 0, (q[ch] * cv - cvirt) / np.maximum(cn, f32(1)), f32(0)).astype(np.float32)
+    return (qv + c * prior[ch] * (np.sqrt(ns) / (f32(1) + cn))).astype(np.float32)
+
+
+def _closest_call(rec, other, kids):
+    """Along the path the NEXT rollout descends in `rec`'s tree: the smallest (top-2 gap of the upper confidence bounds) ÷
+    (largest difference between the two sides' bounds at that node) — how many times wider the decision was than the
+    numerical disagreement of the two networks.  `other` is the same tree (same structure) with the other side's numbers."""
+    node, worst = 0, np.inf
+    while True:
+        vis, virt = int(rec["visits"][node]), int(rec["virtual_visits"][node])
+        if (vis == 0 and virt == 0) or rec["n_children"][node] == 0xFFFF or rec["result"][node] != 0 or not kids[node]:
+            return worst
+        ch = np.array(kids[node])
+        u, v = _ucb(rec, ch, node), _ucb(other, ch, node)
+        if len(ch) > 1:
+            top = np.sort(u)
+            noise = max(float(np.abs(u - v).max()), 1e-7)
+            worst = min(worst, float(top[-1] - top[-2]) / noise)
+        node = int(ch[len(ch) - 1 - int(np.argmax(u[::-1]))])  # max_by keeps the last maximum
+
+
+def test_end_to_end_against_oracle_mcts_with_the_pytorch_network(orc):
+    """No GPU code on the reference side: the oracle's MCTS evaluates its leaves with PyTorch-CPU fp32 (the ATen ops tch-rs
+    calls), the engine runs its own search on its own network kernels.  The two networks agree to ≤ 1e-4, not to the bit, so
+    a selection whose two best upper confidence bounds are closer than the two sides' numbers disagree may legitimately go
+    either way.  Trees must be identical — same nodes, same moves, same visit counts, same results; priors and values within
+    1e-4 — for as long as every selection made so far was at least 4 times wider than that disagreement (measured per node
+    from both trees; with random-init weights priors are nearly flat and a fixed margin such as 1e-3 would exclude almost
+    every selection, so the margin is relative to the observed noise).  A closer call is reported and ends the strict
+    comparison for that game only."""
+    import torch
+
+    import tak_amd
+
+    n, blocks, filters, games, iters = 5, 2, 32, 8, 50
+    net = torch_ref.make_net(n, blocks, filters, "fc5", seed=6)
+    with torch.no_grad():  # a trained network's policy is peaked, a fresh one's is flat: sharpen it so selections are decisions
+        net.policy.weight *= 20
+        net.value.weight *= 4
+    e = _mk(n, tak_amd.EVAL_RESNET, games, res_blocks=blocks, filters=filters)
+    e.load_state_dict(torch_ref.abi_tensors(net))
+    e.search_create(games, arena_nodes=1 << 14)
+    s = orc.Search(n, head=orc.HEAD_FC5, py_eval=lambda st: torch_ref.forward(net, orc.encode(n, st)))
+    sts = _roots(orc, n, games, seed=12, max_plies=24)
+    e.search_reset(sts)
+    s.reset(sts)
+    strict = np.ones(games, bool)
+    close_calls = []
+    compared = 0
+    for it in range(iters):
+        for g in np.nonzero(strict)[0]:
+            a, b = e.search_dump(int(g)), s.dump(int(g))
+            ratio = _closest_call(b, a, _parse_tree(b))
+            if ratio < 4.0:
+                strict[g] = False
+                close_calls.append((int(g), it, round(ratio, 2)))
+        e.search_run(1)
+        s.run(1)
+        for g in np.nonzero(strict)[0]:
+            a, b = e.search_dump(int(g)), s.dump(int(g))
+            assert len(a) == len(b), f"game {g}, iteration {it}: {len(a)} nodes against {len(b)}"
+            for f in ("move", "n_children", "visits", "virtual_visits", "result"):
+                assert np.array_equal(a[f], b[f]), f"game {g}, iteration {it}: {f} differs (first at node {int(np.argmax(a[f] != b[f]))})"
+            pa, pb = a["prior_bits"].view(np.float32), b["prior_bits"].view(np.float32)
+            qa, qb = a["q_bits"].view(np.float32), b["q_bits"].view(np.float32)
+            assert np.abs(pa - pb).max() <= 1e-4 and np.abs(qa - qb).max() <= 1e-4, (g, it)
+            compared += 1
+    print(f"end-to-end: {compared} (game, iteration) trees identical; close calls (game, iteration, margin / noise): {close_calls}")
+    assert strict.sum() >= games // 2 and compared >= games * iters // 2, close_calls
+    e.close()

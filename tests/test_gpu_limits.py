@@ -46,11 +46,18 @@ def test_a_game_past_max_game_plies_is_retired_alone(orc):
     assert st["games_finished"] == len(cut) and st["examples"] == sum(len(v) for v in cut.values())
     assert st["white_wins"] + st["black_wins"] + st["draws"] == st["games_finished"]  # a retired game is no result
     assert max(len(v) for v in cut.values()) <= limit
-    # the same game under the same key, whatever happened to the slot before it
+    # The same game under the same (slot, generation) key, whatever happened to the slot before it.  (One thing does carry
+    # over, in the reference too: a slot recycled by the instant-win scan — phase (b), after the opening phase (a) of that
+    # ply — starts its next game WITHOUT the forced opening.  So a game whose predecessor ended differently in the two runs
+    # — instant win in one, retired at the move choice in the other — may start from another position: then it is a
+    # different game; from the same first position it must be the same game.)
     common = set(cut) & set(full)
-    assert len(common) >= 10
-    for gid in common:
+    same_start = [gid for gid in common if cut[gid][0][0] == full[gid][0][0]]
+    assert len(same_start) >= 10 and len(same_start) >= len(common) // 2
+    for gid in same_start:
         assert cut[gid] == full[gid], f"game {gid:#x} differs from the unlimited run"
+    for gid in common - set(same_start):
+        assert (gid >> 20) > 0 and (gid - (1 << 20)) not in cut  # its predecessor was retired in the limited run
     # games of the unlimited run that fit under the limit and started early enough were all played by the limited run too
     short_first = {gid for gid, v in full.items() if (gid >> 20) == 0 and len(v) <= limit}
     assert short_first and short_first <= set(cut)
@@ -68,13 +75,19 @@ def test_a_game_past_max_game_plies_is_retired_alone(orc):
 def test_a_game_past_the_visit_table_is_retired_alone():
     import tak_amd
 
-    # 20 rollouts + the root evaluation per ply and tree reuse: a root passes 64 visits within a few plies
-    st, games = _run(visit_limit=64)
-    assert st["aborted_games"] > 0 and st["alive_games"] == G
-    assert st["games_finished"] == len(games)
+    # 20 rollouts + the root evaluation per ply, plus the visits the kept subtree brings along (tree reuse): a root whose kept
+    # subtree is well visited passes a table of 24 – 48 entries; find a length at which some games are retired and some finish
+    for limit in (48, 40, 32, 28, 24):
+        st, games = _run(visit_limit=limit)
+        assert st["alive_games"] == G and st["games_finished"] == len(games)
+        if st["aborted_games"] > 0 and len(games) > 0:
+            break
+    else:
+        pytest.fail("no table length retired some games and let others finish")
     full_st, full = _run()
     for gid in set(games) & set(full):
-        assert games[gid] == full[gid]
+        if games[gid][0][0] == full[gid][0][0]:  # (same first position: see the note on the opening in the test above)
+            assert games[gid] == full[gid]
     # a caller-driven search has nobody to restart the game: the capacity stays a sticky engine error there
     e = tak_amd.Engine(N, evaluator=tak_amd.EVAL_HASH, max_batch=64)
     e.search_create(4, arena_nodes=1 << 14, visit_limit=64)

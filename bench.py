@@ -496,6 +496,11 @@ def main():
                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                     "traffic": traffic, "avg_launch_ms": avg_ms, "launches_timed": prof["conv_launches"],
                     "flops_per_launch": prof["conv_flops"], "rows_per_launch": prof["conv_rows"],
+                    # what the MFMA pipe actually issued: the constant input planes (reserves, colour, fcd: 46 of the 72) enter
+                    # layer 0 as a per-position bias, so fewer MFMAs run than the algorithmic count — `frac` can exceed this
+                    "executed_flops_per_launch": prof.get("conv_flops_executed", prof["conv_flops"]),
+                    "achieved_executed": prof.get("conv_flops_executed", prof["conv_flops"]) / (avg_ms * 1e-3) / 1e12,
+                    "frac_executed": prof.get("conv_flops_executed", prof["conv_flops"]) / (avg_ms * 1e-3) / 1e12 / peak,
                     "forward_ms": prof["forward_ms"] / max(prof["forwards"], 1),
                 }
             if world == 1 and args.precision == "f32" and not args.no_alt_precision and tak_amd_supports_bf16x3(args):
@@ -531,7 +536,10 @@ def main():
                               "workload": f"BASELINE config C3: 6x6 Tak, {args.games} games, {args.rollouts} sims/move, 10-block x 128-filter resnet, conv policy head",
                               "fp32_ceiling": F32_MFMA_PEAK_TFLOPS * 1e12 / 240_795_648}
                         if p5 and p5["conv_launches"]:
-                            c3["tower_frac_of_f32_mfma_peak"] = p5["conv_flops"] / (p5["conv_ms"] / p5["conv_launches"] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS
+                            t5 = p5["conv_ms"] / p5["conv_launches"] * 1e-3
+                            c3["tower_frac_of_f32_mfma_peak"] = p5["conv_flops"] / t5 / 1e12 / F32_MFMA_PEAK_TFLOPS
+                            c3["tower_frac_executed"] = p5.get("conv_flops_executed", p5["conv_flops"]) / t5 / 1e12 / F32_MFMA_PEAK_TFLOPS
+                            c3["tower_avg_launch_ms"] = t5 * 1e3
                         extras["config_c3"] = c3
                 except Exception as ex:
                     extras["error"] = repr(ex)

@@ -275,6 +275,10 @@ typedef struct TgSearchConfig {
                                  5×5, ≈ 80 on 6×6); the subtree under the move played is kept (tree reuse) and the rest
                                  returns to the pool.  The reference's own workload — 32 games × 10 000 rollouts on 6×6 —
                                  peaks at ≈ 2^20 per game (31 M nodes, 0.75 GB in all: profiles/r02_soak_reference_workload.log); 4096 5×5 games at 400 rollouts ≈ 2^16 – 2^17.
+                                 Headroom for re-rooting: on a move the kept subtree is copied into fresh chunks BEFORE the old
+                                 tree's chunks are reusable (they are published at the next launch), so the pool must hold,
+                                 for every game that moves in the same call, its old tree plus its kept subtree (≤ the old
+                                 tree) — there is no per-game guarantee that a kept subtree fits, only the pool total.
                                  Exhausting the pool → TG_ERR_ARENA_OVERFLOW (sticky until reset).
                                  0 = auto: half of the free device memory, at most 2^22 nodes per game and 2^32 in all */
     float exploration_base;   /* EXPLORATION_BASE 500 (mcts.rs:7) */
@@ -309,8 +313,10 @@ int tg_search_apply_noise(TgEngine* e, const float* noise, float ratio, const ui
  * root_visits / root_q: games (any pointer may be NULL). */
 int tg_search_root(TgEngine* e, TgMove* moves, uint32_t* visits, float* prior, float* q,
                    int32_t* counts, uint32_t* root_visits, float* root_q);
-/* Node::play (play.rs:26-43) + Game::play: advance each active game by moves[g] with tree
- * reuse (the chosen child's subtree is compacted into the game's other arena). */
+/* Node::play (play.rs:26-43) + Game::play: advance each active game by moves[g] with tree reuse: the chosen child's
+ * subtree is copied breadth-first into fresh chunks of the shared node pool and the game's old chunks return to the pool.
+ * The returned chunks become available to allocators only at the next launch, so WHILE a move is played the pool holds the
+ * old trees and the kept subtrees at once (see arena_nodes: headroom). */
 int tg_search_play(TgEngine* e, const TgMove* moves, const uint8_t* active);
 /* current root states (games packed states) */
 int tg_search_states(TgEngine* e, void* states);
@@ -528,7 +534,11 @@ typedef struct TgProfile {
     uint64_t forwards;        /* network forwards timed end to end                               */
     double forward_ms;
     int64_t conv_rows;        /* M = positions × N² of the timed launches (all equal)            */
-    int64_t conv_flops;       /* algorithmic FLOPs of one timed launch: 2·M·9·F·F                */
+    int64_t conv_flops;       /* algorithmic FLOPs of one timed launch: 2·M·9·F·F (per-layer path) or, for the fused
+                                 tower, 2·M·9·(C_in·F + 2R·F·F) — every input plane counted as data                */
+    int64_t conv_flops_executed; /* FLOPs of the MFMAs the timed launch issues: less than conv_flops when the fused tower
+                                 takes the per-position constant input planes (reserves, colour, fcd) as a bias and runs
+                                 layer 0 over the board planes only — price the MFMA pipe against THIS figure       */
 } TgProfile;
 int tg_profile_enable(TgEngine* e, int sample_every); /* 0 disables */
 /* Board-path micro-benchmark: uploads n states + one legal move each, then runs `reps`

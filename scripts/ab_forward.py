@@ -59,6 +59,7 @@ def main():
                       "forward_us": round(dt * 1e6, 1), "tflops": round(B * flops / dt / 1e12, 1),
                       "tower_us": round(prof["conv_ms"] / max(prof["conv_launches"], 1) * 1e3, 1),
                       "tower_frac_of_peak": round(prof["conv_flops"] / (prof["conv_ms"] / max(prof["conv_launches"], 1) * 1e-3) / 157.3e12, 4) if prof["conv_launches"] else None,
+                      "tower_frac_executed": round(prof.get("conv_flops_executed", prof["conv_flops"]) / (prof["conv_ms"] / max(prof["conv_launches"], 1) * 1e-3) / 157.3e12, 4) if prof["conv_launches"] else None,
                       "checksum": chk}), flush=True)
     e.close()
 

@@ -38,6 +38,19 @@ struct TowerParams {
     // chunk) one contiguous KB — lane (position, q) of the FC's B operand at ((pos/16·K/16 + chunk)·64 + (pos%16)·4 + q)·16 B —
     // so that an FC wave's activation load is 8 whole cache lines instead of 16 half-used ones
     int frag_out;
+    // Constant input planes as a bias (states entry only; `cb` = 1 enables it).  Of the C_in input planes only the first
+    // board_channels(n) = 26 / 28 vary over the board; the reserves one-hots, the colour plane and the fcd plane (46 of 72 on
+    // 5×5, 64 of 92 on 6×6; alpha-tak/src/repr/reserves.rs:4-28, repr/game.rs:28-50) hold ONE value per position.  Their
+    // 3×3 convolution is therefore a per-position bias that depends only on which taps of a square stay on the board — 9
+    // border classes — and layer 0 runs its MFMAs over the board planes alone (K = 9·32 instead of 9·80 / 9·96):
+    //   w0_board      conv0 restricted to the board planes, Wp[9·32/16][CoutP][16], last chunk permuted (cb_last_t)
+    //   cplane_sums   S[plane − board_channels][class][F] = Σ over the taps valid in that class of the folded conv0 weight
+    // and the kernel adds bias + Σ_{planes set} S + fcd · S[fcd plane] (in that order) in the epilogue of layer 0.
+    int cb;
+    int cb_cin_pad;       // 32
+    int cb_last_t;        // 3: ten / twelve real channels in the last 16-channel chunk
+    const float* w0_board;
+    const float* cplane_sums;
 };
 // geometry of the halo image for a supported topology (positions per workgroup, position stride) and the slot table
 bool tower_halo_geometry(int n, int F, int* pw, int* ps);

@@ -35,6 +35,9 @@ struct Net {
     bool fused = false;  // whole tower in one launch (k_tower)
     TowerParams tower;
     ConvLayer conv0_tower;             // conv0 with the last input chunk permuted (layer 0 of the fused towers)
+    ConvLayer conv0_board;             // conv0 over the board planes only (TowerParams.cb)
+    DevBuf cplane_sums;                // S[constant plane][border class][F] (TowerParams.cb)
+    int64_t conv_flops_exec = 0;       // MFMA FLOPs the timed launch actually issues (≤ conv_flops when constant planes are a bias)
     DevBuf halo_map;                   // tile slot → square table of the halo tower (k_tower_halo)
     DevBuf s3_halo_map;                // the same for the split tower's workgroup (k_tower_s3_halo)
     size_t logit_row = 0;              // floats per position in `logits`
@@ -304,6 +307,39 @@ int net_finalize(TgEngine* e) {
             TG_HIP(upload_conv(f0, F, n->cin, n->cin_pad, n->conv0_tower, T.cin_last_t));
         }
         T.w[0] = n->conv0_tower.w.as<float>(); T.b[0] = n->conv0.b.as<float>();
+        // Constant planes as a bias (kernels.h TowerParams.cb; states entry): conv0 over the board planes, and per constant
+        // plane and border class the sum of its folded weights over the taps that stay on the board (tap order, f32)
+        T.cb = 0; T.cb_cin_pad = 32; T.cb_last_t = 3; T.w0_board = nullptr; T.cplane_sums = nullptr;
+        {
+            const int N = e->g.n, bc = board_channels(N), nconst = n->cin - bc;
+            if (!getenv("TG_NO_CONST_BIAS") && bc > 16 && bc <= 28 && nconst > 0) {
+                Folded f0, fb;
+                if (!fold_conv_bn(n, "conv0", "bn0", F, n->cin, f0, err)) return fail(TG_ERR_WEIGHTS, err);
+                fb.b = f0.b;
+                fb.w.resize((size_t)F * bc * 9);
+                for (int o = 0; o < F; o++)
+                    for (int c = 0; c < bc; c++)
+                        for (int tap = 0; tap < 9; tap++) fb.w[((size_t)o * bc + c) * 9 + tap] = f0.w[((size_t)o * n->cin + c) * 9 + tap];
+                TG_HIP(upload_conv(fb, F, bc, T.cb_cin_pad, n->conv0_board, T.cb_last_t));
+                std::vector<float> S((size_t)nconst * 9 * F, 0.0f);
+                for (int pl = 0; pl < nconst; pl++)
+                    for (int cls = 0; cls < 9; cls++) {
+                        const int cy = cls / 3, cx = cls % 3;  // 0: first row / column, 1: interior, 2: last
+                        for (int o = 0; o < F; o++) {
+                            float sum = 0.0f;
+                            for (int tap = 0; tap < 9; tap++) {
+                                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                                if ((cy == 0 && dy < 0) || (cy == 2 && dy > 0) || (cx == 0 && dx < 0) || (cx == 2 && dx > 0)) continue;
+                                sum += f0.w[((size_t)o * n->cin + bc + pl) * 9 + tap];
+                            }
+                            S[((size_t)pl * 9 + cls) * F + o] = sum;
+                        }
+                    }
+                TG_HIP(n->cplane_sums.ensure(S.size() * 4));
+                TG_HIP(hipMemcpy(n->cplane_sums.p, S.data(), S.size() * 4, hipMemcpyHostToDevice));
+                T.cb = 1; T.w0_board = n->conv0_board.w.as<float>(); T.cplane_sums = n->cplane_sums.as<float>();
+            }
+        }
         for (int i = 0; i < R; i++) {
             T.w[1 + 2 * i] = n->res1[i].w.as<float>(); T.b[1 + 2 * i] = n->res1[i].b.as<float>();
             T.w[2 + 2 * i] = n->res2[i].w.as<float>(); T.b[2 + 2 * i] = n->res2[i].b.as<float>();
@@ -486,6 +522,9 @@ static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const ui
         n->conv_rows = M;
         // algorithmic FLOPs of one timed launch: one F→F conv (per-layer path) or the whole tower (fused)
         n->conv_flops = (n->fused || n->s3) ? 2ll * M * 9 * ((long long)n->cin * F + 2ll * n->R * F * F) : 2ll * M * 9 * F * F;
+        // executed: with the constant planes as a bias layer 0 multiplies 16 + 4·cb_last_t input channels per tap, not cin
+        n->conv_flops_exec = (n->fused && !n->s3 && d_states && n->tower.cb)
+                                 ? 2ll * M * 9 * ((long long)(16 + 4 * n->tower.cb_last_t) * F + 2ll * n->R * F * F) : n->conv_flops;
         chain->push_back(prof_event(n, st));
     }
     if (n->s3) {
@@ -552,7 +591,7 @@ int net_profile_read(TgEngine* e, TgProfile* out) {
     TG_HIP(hipStreamSynchronize(e->stream));
     prof_collect(n);
     out->conv_launches = n->conv_n; out->conv_ms = n->conv_ms; out->forwards = n->fwd_n; out->forward_ms = n->fwd_ms;
-    out->conv_rows = n->conv_rows; out->conv_flops = n->conv_flops;
+    out->conv_rows = n->conv_rows; out->conv_flops = n->conv_flops; out->conv_flops_executed = n->conv_flops_exec;
     n->conv_n = n->fwd_n = 0;
     n->conv_ms = n->fwd_ms = 0.0;
     return TG_OK;

@@ -303,11 +303,81 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_pos(const float* __restric
 // tiles it produces).  Only the input planes are read from HBM and only the final activations are
 // written (for the policy / value heads); per layer the only global traffic is the L2-resident weights.
 // ------------------------------------------------------------------------------------------------
+// ---- constant input planes as a per-position bias (TowerParams.cb; states entry of the fused towers) ----
+// Stages what layer 0 needs for the positions of one workgroup: the 26 / 28 BOARD planes of every square as a plain image of
+// 32 channels per row (last chunk permuted for cb_last_t = 3), and the table PB[position][border class][F] =
+// bias + Σ_{constant planes that are set} S[plane][class] + fcd · S[fcd plane][class] — summed in exactly this order by
+// every kernel that uses it, so a position's result does not depend on the kernel (batch size) that evaluates it.
+// class = 3·(y = 0 ? 0 : y = n − 1 ? 2 : 1) + (x = 0 ? 0 : x = n − 1 ? 2 : 1): which of the 9 taps stay on the board.
+template <int NWAVES>
+__device__ __forceinline__ void tower_stage_states_cb(f32x4* lds4, f32x4* pb4, const uint8_t* states, int pos0, int npos, int n,
+                                                      int LS4, const TowerParams& T) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const Geom geo = make_geom(n);
+    const int nsq = n * n;
+    const int bc = board_channels(n);
+    int st0, cp0;
+    starting_stones(n, st0, cp0);
+    const int F4 = T.F >> 2;
+    const f32x4* S4 = (const f32x4*)T.cplane_sums;
+    const f32x4* B4 = (const f32x4*)T.b[0];
+    for (int p = wave; p < npos; p += NWAVES) {  // one wave per position at a time, lane = square
+        WState ws;
+        ws_load(ws, states + (size_t)(pos0 + p) * geo.bytes, geo);
+        const float fcd = fcd_value(ws, geo);
+        const RowMask m = ws_row_mask(ws, geo);
+        if (lane < nsq) {
+            f32x4* row = lds4 + (size_t)(p * nsq + lane) * LS4;
+            const uint32_t bits = m.w[0] & ((1u << bc) - 1u);  // the board planes of this square (bc ≤ 28)
+            f32x4 qd[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t nib = (bits >> (4 * k)) & 15u;
+                qd[k] = f32x4{(nib & 1u) ? 1.0f : 0.0f, (nib & 2u) ? 1.0f : 0.0f, (nib & 4u) ? 1.0f : 0.0f, (nib & 8u) ? 1.0f : 0.0f};
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) row[k] = qd[k];
+            const f32x4 lc[4] = {qd[4], qd[5], qd[6], qd[7]};
+            conv_last_chunk_store(row + 4, lc, T.cb_last_t);
+        }
+        // the constant planes that are set (ws_row_mask's rules), as indices into S
+        const bool w = ws.to_move == 0;
+        const int my_st = w ? ws.ws : ws.bs, en_st = w ? ws.bs : ws.ws, my_cp = w ? ws.wc : ws.bc, en_cp = w ? ws.bc : ws.wc;
+        int pl[5];
+        pl[0] = (my_st > 0 && my_st <= st0) ? my_st - 1 : -1;
+        pl[1] = (en_st > 0 && en_st <= st0) ? st0 + en_st - 1 : -1;
+        pl[2] = (my_cp > 0 && my_cp <= cp0) ? 2 * st0 + my_cp - 1 : -1;
+        pl[3] = (en_cp > 0 && en_cp <= cp0) ? 2 * st0 + cp0 + en_cp - 1 : -1;
+        pl[4] = w ? 2 * st0 + 2 * cp0 : -1;
+        const int fplane = 2 * st0 + 2 * cp0 + 1;
+        for (int idx = lane; idx < 9 * F4; idx += 64) {  // idx = class·F/4 + channel quad
+            const int cls = idx / F4;
+            f32x4 v = B4[idx - cls * F4];
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+                if (pl[k] >= 0) v += S4[(size_t)pl[k] * 9 * F4 + idx];
+            const f32x4 sf = S4[(size_t)fplane * 9 * F4 + idx];
+            v += f32x4{fcd * sf[0], fcd * sf[1], fcd * sf[2], fcd * sf[3]};
+            pb4[(size_t)p * 9 * F4 + idx] = v;
+        }
+    }
+}
+// index (in f32x4) of a row's entry of PB for this lane's 4 output channels
+__device__ __forceinline__ int tower_cb_index(int rho, int rows, int n, int nsq, int F4, int ch0, int q) {
+    if (rho >= rows) return (ch0 >> 2) + q;
+    const int p = rho / nsq, sq = rho - p * nsq, y = sq / n, x = sq - y * n;
+    const int cls = (y == 0 ? 0 : y == n - 1 ? 2 : 1) * 3 + (x == 0 ? 0 : x == n - 1 ? 2 : 1);
+    return (p * 9 + cls) * F4 + (ch0 >> 2) + q;
+}
+
 // FROM_STATES: `in` points at packed game states and the planes are encoded straight into the LDS image
 // (game_repr fused into the tower: the f32 planes never touch HBM).
-template <int RTW, int NWAVES, int CH0, int CH, bool FROM_STATES>
+// CB (with FROM_STATES): layer 0 over the board planes only, the constant planes as the per-position bias PB
+// (tower_stage_states_cb) — CH0 = 2 then.
+template <int RTW, int NWAVES, int CH0, int CH, bool FROM_STATES, bool CB = false>
 __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__ in, TowerParams T, float* __restrict__ out,
                                                        int B, int n, int PW, int CTW) {
+    static_assert(!CB || FROM_STATES, "the constant-plane bias needs the packed states");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     f32x4* lds4 = (f32x4*)lds;
     const int tid = threadIdx.x;
@@ -322,9 +392,13 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
     const int ch0 = ct * 16;
 
     // ---- stage the input planes (row pitch cin_pad + 4) ----
-    int Cpad = T.cin_pad;
+    int Cpad = CB ? T.cb_cin_pad : T.cin_pad;
     int LS4 = (Cpad + LDS_PAD16) >> 2;
-    if (FROM_STATES) {
+    f32x4* pb4 = lds4 + (size_t)(PW * nsq + 1) * LS4;  // CB: PB[position][class][F] behind the image and its zero row
+    if (CB) {
+        tower_stage_states_cb<NWAVES>(lds4, pb4, (const uint8_t*)in, pos0, npos, n, LS4, T);
+        for (int idx = tid; idx < LS4; idx += NWAVES * 64) lds4[rows * LS4 + idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    } else if (FROM_STATES) {
         const Geom geo = make_geom(n);
         const uint8_t* states = (const uint8_t*)in;
         const int C = input_channels(n);
@@ -390,14 +464,15 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
     if (short_group) vmask[RTW - 1] = 0;  // that tile belongs to the next row group
 
     for (int layer = 0; layer < T.nlayers; layer++) {
-        const f32x4* wp = (const f32x4*)T.w[layer] + ((size_t)(ch0 + r16) * 4 + q);
+        const f32x4* wp = (const f32x4*)(CB && layer == 0 ? T.w0_board : T.w[layer]) + ((size_t)(ch0 + r16) * 4 + q);
+        const int last_t0 = CB ? T.cb_last_t : T.cin_last_t;
         TG_STAMP(layer, 0);
         if (RTW > 1 && short_group) {
             f32x4 (&acs)[RTW - 1] = *reinterpret_cast<f32x4 (*)[RTW - 1]>(&acc[0]);
-            if (layer == 0) conv_mainloop<RTW - 1, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acs, T.cin_last_t);
+            if (layer == 0) conv_mainloop<RTW - 1, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acs, last_t0);
             else conv_mainloop<RTW - 1, CH>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acs);
         } else {
-            if (layer == 0) conv_mainloop<RTW, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acc, T.cin_last_t);
+            if (layer == 0) conv_mainloop<RTW, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acc, last_t0);
             else conv_mainloop<RTW, CH>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acc);
         }
         TG_STAMP(layer, 1);
@@ -405,7 +480,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
         const f32x4 bv = *(const f32x4*)&T.b[layer][ch0 + 4 * q];
 #pragma unroll
         for (int j = 0; j < RTW; j++) {
-            f32x4 v = acc[j] + bv;
+            f32x4 v = acc[j] + ((CB && layer == 0) ? pb4[tower_cb_index(rho0 + j * 16, rows, n, nsq, F >> 2, ch0, q)] : bv);
             v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f);
             acc[j] = v;
         }
@@ -457,9 +532,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
 // invisible in the results, that keeps every ds_read_b128 of the loop off its neighbours' banks.
 // Per-element arithmetic (taps, chunks, k-steps, bias, ReLU, skip) in k_tower's order → identical bits.
 // ------------------------------------------------------------------------------------------------
-template <int RTW, int NWAVES, int CH0, int CH, int NB, bool FROM_STATES>
+template <int RTW, int NWAVES, int CH0, int CH, int NB, bool FROM_STATES, bool CB = false>
 __global__ __launch_bounds__(NWAVES * 64) void k_tower_halo(const float* __restrict__ in, TowerParams T, float* __restrict__ out,
                                                             int B, int PW, int CTW) {
+    static_assert(!CB || FROM_STATES, "the constant-plane bias needs the packed states");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     f32x4* lds4 = (f32x4*)lds;
     constexpr int n = NB, nsq = NB * NB, RS = NB + 1, LEAD = NB + 2, F = 16 * CH, P4 = 4 * CH + 1;
@@ -474,9 +550,12 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower_halo(const float* __restr
     const int ch0 = ct * 16;
 
     // ---- stage the input planes: plain image, row pitch cin_pad + 8 floats, one zero row behind it ----
-    const int Cpad = T.cin_pad;
+    const int Cpad = CB ? T.cb_cin_pad : T.cin_pad;
     const int LS4 = (Cpad + LDS_PAD16) >> 2;
-    if (FROM_STATES) {
+    f32x4* pb4 = lds4 + (size_t)(PW * nsq + 1) * LS4;  // CB: PB[position][class][F] behind the image and its zero row
+    if (CB) {
+        tower_stage_states_cb<NWAVES>(lds4, pb4, (const uint8_t*)in, pos0, npos, n, LS4, T);
+    } else if (FROM_STATES) {
         const Geom geo = make_geom(n);
         const uint8_t* states = (const uint8_t*)in;
         const int C = input_channels(n);
@@ -539,20 +618,21 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower_halo(const float* __restr
         int vmask[RTW];
         conv_tap_masks<RTW>(rows, n, nsq, rho0, vmask);
         if (short_group) vmask[RTW - 1] = 0;
-        const f32x4* wp = (const f32x4*)T.w[0] + ((size_t)(ch0 + r16) * 4 + q);
+        const f32x4* wp = (const f32x4*)(CB ? T.w0_board : T.w[0]) + ((size_t)(ch0 + r16) * 4 + q);
+        const int last_t0 = CB ? T.cb_last_t : T.cin_last_t;
         TG_STAMP(0, 0);
         if (RTW > 1 && short_group) {
             f32x4 (&acs)[RTW - 1] = *reinterpret_cast<f32x4 (*)[RTW - 1]>(&acc[0]);
-            conv_mainloop<RTW - 1, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acs, T.cin_last_t);
+            conv_mainloop<RTW - 1, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acs, last_t0);
         } else {
-            conv_mainloop<RTW, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acc, T.cin_last_t);
+            conv_mainloop<RTW, CH0>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho0, q, vmask, acc, last_t0);
         }
         TG_STAMP(0, 1);
         if (T.nlayers > 1) conv_halo_first_weights<CH>(T.w[1], wlane, w0, w1);  // in flight during the change of images
         const f32x4 bv = *(const f32x4*)&T.b[0][ch0 + 4 * q];
 #pragma unroll
         for (int j = 0; j < RTW; j++) {
-            f32x4 v = acc[j] + bv;
+            f32x4 v = acc[j] + (CB ? pb4[tower_cb_index(rho0 + j * 16, rows, n, nsq, F >> 2, ch0, q)] : bv);
             v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f);
             acc[j] = v;
         }
@@ -1267,17 +1347,22 @@ hipError_t launch_conv3x3(hipStream_t st, const float* in, const float* Wp, cons
 }
 
 
-template <int RTW, int NWAVES, int CH0, int CH, bool FROM_STATES>
+// bytes of the per-position bias table PB behind the layer-0 image (TowerParams.cb)
+static size_t tower_cb_table_bytes(int PW, int F) { return (size_t)PW * 9 * F * sizeof(float); }
+
+template <int RTW, int NWAVES, int CH0, int CH, bool FROM_STATES, bool CB = false>
 static hipError_t launch_tower_t(hipStream_t st, const float* in, const TowerParams& T, float* out, int B, int n, int PW, int CTW) {
-    int cmax = T.cin_pad > T.F ? T.cin_pad : T.F;
-    size_t lds = (size_t)(PW * n * n + 1) * (cmax + LDS_PAD16) * sizeof(float);
+    const size_t rows1 = (size_t)(PW * n * n + 1);
+    const size_t first = rows1 * ((CB ? T.cb_cin_pad : T.cin_pad) + LDS_PAD16) * sizeof(float) + (CB ? tower_cb_table_bytes(PW, T.F) : 0);
+    const size_t later = rows1 * (T.F + LDS_PAD16) * sizeof(float);
+    const size_t lds = first > later ? first : later;
     static size_t configured = 0;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_tower<RTW, NWAVES, CH0, CH, FROM_STATES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_tower<RTW, NWAVES, CH0, CH, FROM_STATES, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    hipLaunchKernelGGL((k_tower<RTW, NWAVES, CH0, CH, FROM_STATES>), dim3((B + PW - 1) / PW), dim3(NWAVES * 64), lds, st, in, T, out, B, n, PW, CTW);
+    hipLaunchKernelGGL((k_tower<RTW, NWAVES, CH0, CH, FROM_STATES, CB>), dim3((B + PW - 1) / PW), dim3(NWAVES * 64), lds, st, in, T, out, B, n, PW, CTW);
     return hipGetLastError();
 }
 
@@ -1328,19 +1413,20 @@ void tower_halo_slotmap(int n, int pw, int ps, uint32_t* out) {
     }
 }
 
-template <int RTW, int NWAVES, int CH0, int CH, int NB, bool FROM_STATES>
+template <int RTW, int NWAVES, int CH0, int CH, int NB, bool FROM_STATES, bool CB = false>
 static hipError_t launch_tower_halo_t(hipStream_t st, const float* in, const TowerParams& T, float* out, int B, int CTW) {
     const int PW = T.halo_pw;
-    const size_t plain = (size_t)(PW * NB * NB + 1) * (T.cin_pad + LDS_PAD16) * sizeof(float);
+    const size_t plain = (size_t)(PW * NB * NB + 1) * ((CB ? T.cb_cin_pad : T.cin_pad) + LDS_PAD16) * sizeof(float) +
+                         (CB ? tower_cb_table_bytes(PW, 16 * CH) : 0);
     const size_t halo = (size_t)(NB + 2 + PW * T.halo_ps + 1) * (16 * CH + 4) * sizeof(float);  // + the spare cell
     const size_t lds = plain > halo ? plain : halo;
     static size_t configured = 0;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_tower_halo<RTW, NWAVES, CH0, CH, NB, FROM_STATES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_tower_halo<RTW, NWAVES, CH0, CH, NB, FROM_STATES, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    hipLaunchKernelGGL((k_tower_halo<RTW, NWAVES, CH0, CH, NB, FROM_STATES>), dim3((B + PW - 1) / PW), dim3(NWAVES * 64), lds, st, in, T, out, B, PW, CTW);
+    hipLaunchKernelGGL((k_tower_halo<RTW, NWAVES, CH0, CH, NB, FROM_STATES, CB>), dim3((B + PW - 1) / PW), dim3(NWAVES * 64), lds, st, in, T, out, B, PW, CTW);
     return hipGetLastError();
 }
 
@@ -1349,6 +1435,12 @@ template <bool FROM_STATES>
 static bool launch_tower_halo(hipStream_t st, const float* in, const TowerParams& T, float* out, int B, int n, hipError_t* err) {
     static const bool off = getenv("TG_NO_HALO_TOWER") != nullptr;
     if (off || !T.slotmap) return false;
+    if (FROM_STATES && T.cb) {  // layer 0 over the board planes, constant planes as a bias (CH0 = 2)
+        if (n == 5 && T.F == 64 && B > 2048) { *err = launch_tower_halo_t<13, 8, 2, 4, 5, FROM_STATES, FROM_STATES>(st, in, T, out, B, 4); return true; }
+        if (n == 6 && T.F == 128 && B > 512) { *err = launch_tower_halo_t<9, 8, 2, 8, 6, FROM_STATES, FROM_STATES>(st, in, T, out, B, 8); return true; }
+        if (n == 5 && T.F == 128 && B > 1024) { *err = launch_tower_halo_t<13, 8, 2, 8, 5, FROM_STATES, FROM_STATES>(st, in, T, out, B, 8); return true; }
+        return false;
+    }
     if (n == 5 && T.F == 64 && T.cin_pad == 80 && B > 2048) { *err = launch_tower_halo_t<13, 8, 5, 4, 5, FROM_STATES>(st, in, T, out, B, 4); return true; }
     if (n == 6 && T.F == 128 && T.cin_pad == 96 && B > 512) { *err = launch_tower_halo_t<9, 8, 6, 8, 6, FROM_STATES>(st, in, T, out, B, 8); return true; }
     if (n == 5 && T.F == 128 && T.cin_pad == 80 && B > 1024) { *err = launch_tower_halo_t<13, 8, 5, 8, 5, FROM_STATES>(st, in, T, out, B, 8); return true; }
@@ -1398,6 +1490,27 @@ hipError_t launch_tower_states(hipStream_t st, const uint8_t* states, const Towe
     {
         hipError_t herr;
         if (launch_tower_halo<true>(st, in, T, out, B, n, &herr)) return herr;
+    }
+    if (T.cb) {  // the same tilings with layer 0 over the board planes (identical bits for every batch size)
+        if (n == 5 && T.F == 64) {
+            if (B <= 256) return launch_tower_t<2, 4, 2, 4, true, true>(st, in, T, out, B, n, 1, 4);
+            if (B <= 512) return launch_tower_t<4, 4, 2, 4, true, true>(st, in, T, out, B, n, 2, 4);
+            if (B <= 1024) return launch_tower_t<7, 4, 2, 4, true, true>(st, in, T, out, B, n, 4, 4);
+            if (B <= 2048) return launch_tower_t<13, 4, 2, 4, true, true>(st, in, T, out, B, n, 8, 4);
+            return launch_tower_t<13, 8, 2, 4, true, true>(st, in, T, out, B, n, 16, 4);
+        }
+        if (n == 6 && T.F == 128) {
+            if (B <= 256) return launch_tower_t<3, 8, 2, 8, true, true>(st, in, T, out, B, n, 1, 8);
+            if (B <= 512) return launch_tower_t<5, 8, 2, 8, true, true>(st, in, T, out, B, n, 2, 8);
+            return launch_tower_t<9, 8, 2, 8, true, true>(st, in, T, out, B, n, 4, 8);
+        }
+        if (n == 5 && T.F == 128) {
+            if (B <= 256) return launch_tower_t<2, 8, 2, 8, true, true>(st, in, T, out, B, n, 1, 8);
+            if (B <= 512) return launch_tower_t<4, 8, 2, 8, true, true>(st, in, T, out, B, n, 2, 8);
+            if (B <= 1024) return launch_tower_t<7, 8, 2, 8, true, true>(st, in, T, out, B, n, 4, 8);
+            return launch_tower_t<13, 8, 2, 8, true, true>(st, in, T, out, B, n, 8, 8);
+        }
+        return hipErrorInvalidValue;
     }
     if (n == 5 && T.F == 64 && T.cin_pad == 80) {
         // fewer positions per workgroup for small batches (see tower_small_batch below): identical bits, shorter critical path

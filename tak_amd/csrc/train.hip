@@ -111,7 +111,7 @@ struct Trainer {
     int64_t ar_count = 0;
     DevBuf err_flag;  // one float: the ranks agree on an argument error before the first chunk of tg_train
     ~Trainer() {
-        for (auto& p : ar_events) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+        for (auto& p : ar_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
     }
 };
@@ -297,7 +297,7 @@ int optimizer_step(TgEngine* e) {
         }
         int rc = all_reduce_sum(e, t->grads.as<float>(), t->n_params, "gradients", &reduced);
         if (timed) {
-            hipEventRecord(ev1, st);
+            (void)hipEventRecord(ev1, st);
             t->ar_events.emplace_back(ev0, ev1);
         }
         if (rc) return rc;
@@ -722,8 +722,8 @@ int tg_train_comm_stats(TgEngine* e, double* ms_total, int64_t* reductions) {
     for (auto& p : t->ar_events) {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { t->ar_ms += ms; t->ar_count++; }
-        hipEventDestroy(p.first);
-        hipEventDestroy(p.second);
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
     }
     t->ar_events.clear();
     if (ms_total) *ms_total = t->ar_ms;

@@ -39,7 +39,7 @@ class TgSearchConfig(C.Structure):
 
 class TgProfile(C.Structure):
     _fields_ = [("conv_launches", C.c_uint64), ("conv_ms", C.c_double), ("forwards", C.c_uint64), ("forward_ms", C.c_double),
-                ("conv_rows", C.c_int64), ("conv_flops", C.c_int64)]
+                ("conv_rows", C.c_int64), ("conv_flops", C.c_int64), ("conv_flops_executed", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

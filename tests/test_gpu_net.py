@@ -35,9 +35,11 @@ def test_golden_fixture(path, orc):
     assert np.abs(p - z["policy"]).max() <= TOL
     assert np.abs(v - z["eval"]).max() <= TOL
     assert np.abs(p.sum(1) - 1).max() < 1e-5
-    # forward_mcts on caller-encoded planes gives the same numbers
+    # forward_mcts on caller-encoded planes gives the same numbers (to the last bits: the fused towers take the constant
+    # planes of a packed state as a per-position bias, arbitrary caller planes as data — another summation order in layer 0)
     p2, v2 = e.forward_mcts(orc.encode(n, z["states"]))
-    assert np.array_equal(p, p2) and np.array_equal(v, v2)
+    assert np.abs(p - p2).max() <= 1e-6 and np.abs(v - v2).max() <= 1e-6
+    assert np.abs(p2 - z["policy"]).max() <= TOL and np.abs(v2 - z["eval"]).max() <= TOL
     e.close()
 
 
@@ -226,7 +228,16 @@ def test_planes_entry_equals_states_entry_at_full_batch(orc, n, blocks, filters,
     e.load_state_dict(torch_ref.abi_tensors(net))
     p, v = e.policy_eval(sts)
     p2, v2 = e.forward_mcts(orc.encode(n, sts))
-    assert np.array_equal(p, p2) and np.array_equal(v, v2)
+    if precision == "f32":
+        # the f32 towers take a packed state's constant planes (reserves, colour, fcd) as a per-position bias and run layer 0
+        # over the board planes only; caller-encoded planes are arbitrary data and go through layer 0 whole: the same sums in
+        # another order, equal to the last bits but not bit for bit — both within 1e-4 of PyTorch
+        assert np.abs(p - p2).max() <= 1e-6 and np.abs(v - v2).max() <= 1e-6
+        p_ref, v_ref = torch_ref.forward(net, orc.encode(n, sts[:256]))
+        for pp, vv in ((p, v), (p2, v2)):
+            assert np.abs(pp[:256] - p_ref).max() <= TOL and np.abs(vv[:256] - v_ref).max() <= TOL
+    else:
+        assert np.array_equal(p, p2) and np.array_equal(v, v2)
     e.close()
 
 

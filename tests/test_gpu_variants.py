@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _digest(cfg, batch, **env):
     e = dict(os.environ)
-    for k in ("TG_NO_HALO_TOWER", "TG_FC_BARRIER", "TG_NO_FRAG_OUT", "TG_PRECISION"):
+    for k in ("TG_NO_HALO_TOWER", "TG_FC_BARRIER", "TG_NO_FRAG_OUT", "TG_PRECISION", "TG_NO_CONST_BIAS"):
         e.pop(k, None)
     e.update(env)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "ab_bits.py"), cfg, str(batch)], env=e, check=True,
@@ -31,6 +31,11 @@ def test_launcher_variants_return_identical_bits(cfg, batch):
         assert _digest(cfg, batch, TG_FC_BARRIER="1") == base
         assert _digest(cfg, batch, TG_NO_FRAG_OUT="1") == base  # row-major tower output into the ring FC
         assert _digest(cfg, batch, TG_NO_FRAG_OUT="1", TG_FC_BARRIER="1") == base
+    # layer 0 with every input plane as data (the order of round 2) is another summation order: other low bits, and ITS
+    # halo / plain variants agree with each other
+    dense = _digest(cfg, batch, TG_NO_CONST_BIAS="1")
+    assert dense != base
+    assert _digest(cfg, batch, TG_NO_CONST_BIAS="1", TG_NO_HALO_TOWER="1") == dense
     s3 = _digest(cfg, batch, TG_PRECISION="bf16x3")
     assert s3 != base
     assert _digest(cfg, batch, TG_PRECISION="bf16x3", TG_NO_HALO_TOWER="1") == s3

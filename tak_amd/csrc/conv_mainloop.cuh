@@ -168,14 +168,15 @@ __device__ __forceinline__ void conv_mainloop(const f32x4* __restrict__ lds4, co
 // `turn` (0 / 1, wave-uniform): the two waves that share a SIMD take turns at s_setprio 1, one chunk each.  Left alone the
 // arbiter prefers the older wave throughout: it finishes its tiles at ≈ 3/4 of the layer and the younger one runs the
 // last quarter alone, where nothing fills the gaps between its own MFMA groups (37 instead of 33 cycles per MFMA).
-template <int RTW, int CH, int NB, int NM>
+// COT = output channel tiles of the layer's weight matrix (CoutP / 16): CH in the towers (F → F), more for a wider head.
+template <int RTW, int CH, int NB, int NM, int COT = CH>
 __device__ __forceinline__ void conv_mainloop_halo(const f32x4* __restrict__ lds4, const float* __restrict__ wlayer,
                                                    const float* __restrict__ wnext, uint32_t wlane, const int (&addr4)[NM],
                                                    f32x4 (&acc)[RTW], const int turn, f32x4& w0, f32x4& w1) {
     static_assert(NM >= RTW, "an address for every row tile");
     constexpr int P4 = 4 * CH + 1, RS = NB + 1;
     constexpr int H1 = (RTW + 1) / 2;
-    constexpr size_t WCHUNK = (size_t)16 * CH * 4 * 16;  // bytes of one 16-k chunk of the layer's weights: [F][4 slots][16 B]
+    constexpr size_t WCHUNK = (size_t)16 * COT * 4 * 16;  // bytes of one 16-k chunk of the layer's weights: [CoutP][4 slots][16 B]
 #ifndef TG_PRIO_PERIOD
 #define TG_PRIO_PERIOD 2
 #endif
@@ -258,9 +259,9 @@ __device__ __forceinline__ void conv_mainloop_halo(const f32x4* __restrict__ lds
 }
 
 // chunks 0 and 1 of a layer's weights for the first conv_mainloop_halo call of a kernel
-template <int CH>
+template <int CH, int COT = CH>
 __device__ __forceinline__ void conv_halo_first_weights(const float* __restrict__ wlayer, uint32_t wlane, f32x4& w0, f32x4& w1) {
-    constexpr size_t WCHUNK = (size_t)16 * CH * 4 * 16;
+    constexpr size_t WCHUNK = (size_t)16 * COT * 4 * 16;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wlayer, 0, (int)(9 * CH * WCHUNK), 0x00020000);
     w0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, 0, 0));
     w1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, (int)WCHUNK, 0));

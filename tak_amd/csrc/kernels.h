@@ -87,9 +87,14 @@ hipError_t launch_fc_s3(hipStream_t st, const float* act_split, const void* Wp, 
                         int out_stride, int n_valid);
 hipError_t launch_value_head_s3(hipStream_t st, const float* act_split, const float* wv, float bv, int B, int len, float* eval);
 // a_frag: A is in the fragment-major order of TowerParams.frag_out (needs fc_frag_supported(K, NP))
+// stats (optional, needs fc_stats_supported): the block-wise softmax statistics of softmax.cuh over columns < n_soft,
+// [M][NP/208][2] floats — emitted by the FC's epilogue (full batches) or by a small kernel behind it (≤ 512 rows): same bits
 hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp, const float* bias, float* out, int M, int K,
-                       int NP, int out_stride, int n_valid, bool a_frag = false);
+                       int NP, int out_stride, int n_valid, bool a_frag = false, float* stats = nullptr, int n_soft = 0);
 bool fc_frag_supported(int K, int NP);
+bool fc_stats_supported(int K, int NP, int out_stride);
+hipError_t launch_softmax_stats(hipStream_t st, const float* logits, int row_stride, const float* stats, int blocks, int P, int B,
+                                float* policy, float* eval);
 hipError_t launch_value_head(hipStream_t st, const float* act, const float* wv, float bv, int B, int len, float* eval);
 hipError_t launch_softmax(hipStream_t st, const float* logits, int row_stride, bool conv_head, int nsq, int ch_stride, int P,
                           int B, float* policy, float* eval = nullptr);

@@ -32,6 +32,8 @@ struct Net {
     float value_b = 0.0f;
     // activations (max_batch positions)
     DevBuf x, y, logits, planes_nhwc, planes_nchw;
+    DevBuf fc_stats;                  // [max_batch][policy_np / 208][2]: block-wise softmax statistics of the f32 policy FC (softmax.cuh)
+    bool fc_stats_on = false;
     bool fused = false;  // whole tower in one launch (k_tower)
     TowerParams tower;
     ConvLayer conv0_tower;             // conv0 with the last input chunk permuted (layer 0 of the fused towers)
@@ -451,6 +453,10 @@ int net_finalize(TgEngine* e) {
     n->logit_row = logit_row;
     TG_HIP(n->logits.ensure(mb * logit_row * 4));
     TG_HIP(n->planes_nhwc.ensure(mb * nsq * n->cin_pad * 4));
+    // f32 FC head with the value column: the FC emits the softmax statistics per column block, nobody re-reads whole rows
+    n->fc_stats_on = e->cfg.policy_head == TG_HEAD_FC5 && n->value_in_fc && !(n->s3 && n->s3_fc_on) &&
+                     fc_stats_supported(nsq * F, n->policy_np, n->policy_np) && !getenv("TG_NO_FC_STATS");
+    if (n->fc_stats_on) TG_HIP(n->fc_stats.ensure(mb * (size_t)(n->policy_np / 208) * 2 * 4));
     n->ready = true;
     return TG_OK;
 }
@@ -474,6 +480,14 @@ const float* net_fc_logits(const TgEngine* e, int* ld) {
     if (n->s3 && !n->s3_fc_on) return nullptr;  // split tower with the f32 FC: keep the plain path
     *ld = n->s3 && n->s3_fc_on ? n->s3_np : n->policy_np;  // the row stride the FC kernel in use writes
     return n->logits.as<float>();
+}
+
+// the block statistics that go with net_fc_logits' buffer ([max_batch][*blocks][2]), or nullptr: the consumer then takes max and
+// Σexp over the whole row itself (softmax_stats_wave)
+const float* net_fc_stats(const TgEngine* e, int* blocks) {
+    if (!net_ready(e) || !e->net->fc_stats_on || (e->net->s3 && e->net->s3_fc_on)) return nullptr;
+    *blocks = e->net->policy_np / 208;
+    return e->net->fc_stats.as<float>();
 }
 
 // half batch on its own stream (only when the tower encodes from states); see search.hip
@@ -563,9 +577,12 @@ static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const ui
         TG_HIP(launch_fc_s3(st, x, n->s3_fc.p, n->s3_fc_b.as<float>(), logits, nb, nsq * F, n->s3_np, n->s3_np, e->policy_size + (n->value_in_fc ? 1 : 0)));
         if (d_policy) TG_HIP(launch_softmax(st, logits, n->s3_np, false, nsq, 0, e->policy_size, nb, d_policy, n->value_in_fc ? d_eval : nullptr));
     } else {
+        float* stats = n->fc_stats_on ? n->fc_stats.as<float>() + (size_t)pos0 * (n->policy_np / 208) * 2 : nullptr;
         TG_HIP(launch_gemm(st, x, nsq * F, n->policy_w.as<float>(), n->policy_b.as<float>(), logits, nb, nsq * F, n->policy_np,
-                           n->policy_np, e->policy_size + (n->value_in_fc ? 1 : 0), !n->s3 && n->fused && n->tower.frag_out));
-        if (d_policy) TG_HIP(launch_softmax(st, logits, n->policy_np, false, nsq, 0, e->policy_size, nb, d_policy, n->value_in_fc ? d_eval : nullptr));
+                           n->policy_np, e->policy_size + (n->value_in_fc ? 1 : 0), !n->s3 && n->fused && n->tower.frag_out,
+                           stats, e->policy_size));
+        if (d_policy && stats) TG_HIP(launch_softmax_stats(st, logits, n->policy_np, stats, n->policy_np / 208, e->policy_size, nb, d_policy, d_eval));
+        else if (d_policy) TG_HIP(launch_softmax(st, logits, n->policy_np, false, nsq, 0, e->policy_size, nb, d_policy, n->value_in_fc ? d_eval : nullptr));
     }
     if (!d_policy && !(e->cfg.policy_head == TG_HEAD_FC5 && n->value_in_fc)) return fail(TG_ERR_STATE, "logits-only forward needs the FC head with the value column");
     if (e->cfg.policy_head == TG_HEAD_FC5 && n->value_in_fc) {

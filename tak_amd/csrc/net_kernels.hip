@@ -720,6 +720,103 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower_halo(const float* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ONE 3×3 layer on the halo image (the main loop of k_tower_halo for a layer that stands alone): the convolutions of the
+// training step — forward in training mode and the data gradient, F → F, activations in HBM between them because
+// BatchNorm's batch statistics sit between two layers — and the conv policy head of Net6 (F → 251 in 256).  The input rows
+// of the workgroup's PW positions are staged from global straight into halo cells; taps are ds_read immediates, the
+// weights stream through a buffer descriptor two chunks ahead, slots come from the same slot table as the tower's.
+// Epilogue: + bias, + res (optional), ReLU (optional).  COT = CoutP / 16; blockIdx.y picks a group of CTW channel tiles.
+// ------------------------------------------------------------------------------------------------
+template <int RTW, int NWAVES, int CH, int NB, int COT>
+__global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restrict__ in, const float* __restrict__ Wp,
+                                                           const float* __restrict__ bias, const float* __restrict__ res,
+                                                           float* __restrict__ out, const uint32_t* __restrict__ slotmap, int B, int PW,
+                                                           int PS, int CTW, int out_stride, int cout_valid, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    f32x4* lds4 = (f32x4*)lds;
+    constexpr int n = NB, nsq = NB * NB, RS = NB + 1, LEAD = NB + 2, F4 = 4 * CH, P4 = 4 * CH + 1;
+    const int tid = threadIdx.x;
+    const int pos0 = blockIdx.x * PW;
+    const int npos = min(PW, B - pos0);
+    const int rows = npos * nsq;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int ct = wave % CTW, rg = wave / CTW;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int ch0 = (blockIdx.y * CTW + ct) * 16;
+    const uint32_t wlane = (uint32_t)(((ch0 + r16) * 4 + q) * 16);
+    f32x4 w0, w1;
+    conv_halo_first_weights<CH, COT>(Wp, wlane, w0, w1);  // in flight while the image is staged
+    // zero cells (behind every board row, the zero row behind every position, lead and tail) …
+    const int cells = LEAD + PW * PS + 1;
+    for (int idx = tid; idx < cells * P4; idx += NWAVES * 64) {
+        const int c = idx / P4 - LEAD;
+        const int o = c < 0 || c >= PW * PS ? n * RS : c % PS;
+        if (o >= n * RS || o % RS == n) lds4[idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    // … and the squares' rows from global (row-major [row][16·CH]), 8 loads in flight per lane
+    {
+        const f32x4* src = (const f32x4*)(in + (size_t)pos0 * nsq * (16 * CH));
+        const int total = rows * F4;
+        constexpr int UNR = 8;
+        for (int base = 0; base < total; base += NWAVES * 64 * UNR) {
+            f32x4 tmp[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int idx = base + u * NWAVES * 64 + tid;
+                tmp[u] = src[idx < total ? idx : total - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int idx = base + u * NWAVES * 64 + tid;
+                if (idx < total) {
+                    const int r = idx / F4, v = idx - r * F4;
+                    const int p = r / nsq, sq = r - p * nsq, y = sq / n, x = sq - y * n;
+                    lds4[(LEAD + p * PS + y * RS + x) * P4 + v] = tmp[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int NRG = NWAVES / CTW;
+    const int ntiles = (PW * nsq + 15) >> 4;
+    const int tbase = ntiles / NRG, trem = ntiles - tbase * NRG;
+    const int my_tiles = tbase + (rg < trem ? 1 : 0);
+    const int tile0 = rg * tbase + min(rg, trem);
+    const bool short_group = my_tiles < RTW;
+    f32x4 acc[RTW];
+    int rowid[RTW], addr4[RTW];
+#pragma unroll
+    for (int j = 0; j < RTW; j++) {
+        acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const uint32_t e = j < my_tiles ? slotmap[(tile0 + j) * 16 + r16] : 0xFFFF0000u;
+        rowid[j] = (int)(e >> 16);
+        const bool idle = rowid[j] == 0xFFFF;  // a slot without a square reads around a zero cell and stores nothing
+        addr4[j] = ((idle ? LEAD + n * RS : (int)(e & 0xFFFFu)) - LEAD) * P4 + q;
+    }
+    const int turn = (wave >> 2) & 1;
+    if (RTW > 1 && short_group) {
+        f32x4 (&acs)[RTW - 1] = *reinterpret_cast<f32x4 (*)[RTW - 1]>(&acc[0]);
+        conv_mainloop_halo<RTW - 1, CH, NB, RTW, COT>(lds4, Wp, Wp, wlane, addr4, acs, turn, w0, w1);
+    } else {
+        conv_mainloop_halo<RTW, CH, NB, RTW, COT>(lds4, Wp, Wp, wlane, addr4, acc, turn, w0, w1);
+    }
+    const int ch = ch0 + 4 * q;
+    const f32x4 bv = *(const f32x4*)&bias[ch];
+#pragma unroll
+    for (int j = 0; j < RTW; j++) {
+        if (rowid[j] < rows && ch < cout_valid) {
+            const size_t o = ((size_t)pos0 * nsq + rowid[j]) * out_stride + ch;
+            f32x4 v = acc[j] + bv;
+            if (res) v += *(const f32x4*)&res[o];
+            if (relu) { v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f); }
+            if (ch + 3 < cout_valid) *(f32x4*)&out[o] = v;
+            else for (int t = 0; t < 4; t++) if (ch + t < cout_valid) out[o + t] = v[t];
+        }
+    }
+}
+
 // Plain GEMM out[M][N] = A[M][K]·W[K][N] + bias for the 5×5 policy FC (net5.rs:56-61,108): the same
 // fragments, A staged through LDS in K-chunks of 32.
 template <int RT, int CT>
@@ -810,9 +907,37 @@ constexpr int FC_COLS = FC_CT * 16;  // 208
 constexpr int FC_KSTEP = 64;         // 4 chunks of 16
 constexpr int FC_PLANE = (FC_KSTEP / 16) * FC_COLS;  // 832 slots per k-quarter plane (≡ 0 mod 16)
 
+static_assert(FC_COLS == FC_STAT_COLS && FC_CT == FC_STAT_TILES, "the statistics blocks of softmax.cuh are the FC's column blocks");
+// Epilogue of k_fc_lds / k_fc_ring: bias, the logits to `out`, and — stats != nullptr — the softmax statistics of this
+// workgroup's column block for every row (softmax.cuh: fc_block_stats), stats[(row·blocks + block)·2] = {m_b, s_b}.
+// bias holds NP entries, so it is read unguarded.
+__device__ __forceinline__ void fc_epilogue(const f32x4 (&acc)[FC_CT], const float* __restrict__ bias, float* __restrict__ out,
+                                            float* __restrict__ stats, int row, bool row_ok, int n0, int q, int out_stride,
+                                            int n_valid, int n_soft, int blocks) {
+    f32x4 v[FC_CT];
+#pragma unroll
+    for (int j = 0; j < FC_CT; j++) v[j] = acc[j] + *(const f32x4*)&bias[n0 + j * 16 + 4 * q];
+    if (row_ok) {
+#pragma unroll
+        for (int j = 0; j < FC_CT; j++) {
+            const int nn = n0 + j * 16 + 4 * q;
+            if (nn < n_valid) {
+                float* o = out + (size_t)row * out_stride + nn;
+                if (nn + 3 < n_valid) *(f32x4*)o = v[j];
+                else for (int t = 0; t < 4; t++) if (nn + t < n_valid) o[t] = v[j][t];
+            }
+        }
+    }
+    if (stats) {
+        float m, sm;
+        fc_block_stats(v, n0 + 4 * q, n_soft, m, sm);
+        if (row_ok && q == 0) *(float2*)&stats[((size_t)row * blocks + (n0 / FC_COLS)) * 2] = make_float2(m, sm);
+    }
+}
+
 __global__ __launch_bounds__(512) void k_fc_lds(const float* __restrict__ A, int lda, const float* __restrict__ Wp,
                                                 const float* __restrict__ bias, float* __restrict__ out, int M, int K, int NP,
-                                                int out_stride, int n_valid, int a_frag) {
+                                                int out_stride, int n_valid, int a_frag, float* __restrict__ stats, int n_soft) {
     __shared__ f32x4 wl[2][4][FC_PLANE];  // [buffer][k-quarter][chunk*208 + col]  = 106.5 KB
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -890,18 +1015,7 @@ __global__ __launch_bounds__(512) void k_fc_lds(const float* __restrict__ A, int
         __syncthreads();
         TG_STAMP(step, 3);
     }
-    if (row_ok) {
-#pragma unroll
-        for (int j = 0; j < FC_CT; j++) {
-            const int nn = n0 + j * 16 + 4 * q;
-            if (nn < n_valid) {
-                f32x4 v = acc[j] + *(const f32x4*)&bias[nn];
-                float* o = out + (size_t)row * out_stride + nn;
-                if (nn + 3 < n_valid) *(f32x4*)o = v;
-                else for (int t = 0; t < 4; t++) if (nn + t < n_valid) o[t] = v[t];
-            }
-        }
-    }
+    fc_epilogue(acc, bias, out, stats, row, row_ok, n0, q, out_stride, n_valid, n_soft, (int)gridDim.y);
 }
 
 
@@ -936,7 +1050,7 @@ __device__ __forceinline__ void fc_ring_signal(uint32_t flag_addr) {
 }
 __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, int lda, const float* __restrict__ Wp,
                                                  const float* __restrict__ bias, float* __restrict__ out, int M, int K, int NP,
-                                                 int out_stride, int n_valid, int a_frag) {
+                                                 int out_stride, int n_valid, int a_frag, float* __restrict__ stats, int n_soft) {
     extern __shared__ __attribute__((aligned(16))) float fc_ring_lds[];
     f32x4* wl = (f32x4*)fc_ring_lds;                                // [FC_RING][chunk][output tile][q][r16]
     uint32_t* flags = (uint32_t*)(wl + FC_RING * FC_RING_SLOTS);    // ready[FC_RING], done[FC_RING]
@@ -1052,18 +1166,7 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
 #undef TG_FC_LOAD
 #undef TG_FC_MFMA
 #undef TG_FC_CHUNK
-    if (row_ok) {
-#pragma unroll
-        for (int j = 0; j < FC_CT; j++) {
-            const int nn = n0 + j * 16 + 4 * q;
-            if (nn < n_valid) {
-                f32x4 v = acc[j] + *(const f32x4*)&bias[nn];
-                float* o = out + (size_t)row * out_stride + nn;
-                if (nn + 3 < n_valid) *(f32x4*)o = v;
-                else for (int t = 0; t < 4; t++) if (nn + t < n_valid) o[t] = v[t];
-            }
-        }
-    }
+    fc_epilogue(acc, bias, out, stats, row, row_ok, n0, q, out_stride, n_valid, n_soft, (int)gridDim.y);
 }
 
 // The same FC for SMALL batches (host-driven MCTS evaluates 16–32 leaves per call; Player, pit): k_fc_lds gives a row block
@@ -1127,6 +1230,40 @@ __global__ __launch_bounds__(256) void k_fc_small(const float* __restrict__ A, i
             }
         }
     }
+}
+
+// The softmax statistics of softmax.cuh from logits already in memory, for the producers that cannot emit them from their
+// accumulators (k_fc_small: a wave there owns 2 output tiles, not a block's 13).  A wave covers 16 (row, block) pairs with the
+// FC's own lane layout — lane = pair + 16·q holds columns 208·block + 16 j + 4 q + t — so fc_block_stats runs unchanged.
+__global__ __launch_bounds__(256) void k_fc_stats(const float* __restrict__ logits, int ld, int M, int blocks, int n_soft,
+                                                  float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
+    const long pair0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    const long total = (long)M * blocks;
+    if (pair0 >= total) return;
+    const long pair = pair0 + r16 < total ? pair0 + r16 : total - 1;
+    const int row = (int)(pair / blocks), b = (int)(pair - (long)row * blocks);
+    const float* x = logits + (size_t)row * ld + b * FC_COLS + 4 * q;
+    f32x4 v[FC_CT];
+#pragma unroll
+    for (int j = 0; j < FC_CT; j++) v[j] = *(const f32x4*)&x[16 * j];
+    float m, sm;
+    fc_block_stats(v, b * FC_COLS + 4 * q, n_soft, m, sm);
+    if (q == 0 && pair0 + r16 < total) *(float2*)&stats[(size_t)pair * 2] = make_float2(m, sm);
+}
+
+// softmax of the FC head from the block statistics (tg_policy_eval; the search never materialises probabilities): the same
+// exp(x − M) · (1 / S) the tree backup evaluates for a leaf's children, so host-side trees built from these probabilities
+// and the engine's own agree bit for bit.  One block per position.
+__global__ __launch_bounds__(256) void k_softmax_stats(const float* __restrict__ logits, int row_stride, const float* __restrict__ stats,
+                                                       int blocks, int P, float* __restrict__ policy, float* __restrict__ eval) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* x = logits + (size_t)b * row_stride;
+    float mx, inv;
+    fc_combine_stats(stats + (size_t)b * blocks * 2, blocks, mx, inv);
+    if (eval && tid == 0) eval[b] = tanhf(x[P]);
+    float* o = policy + (size_t)b * P;
+    for (int p = tid; p < P; p += 256) o[p] = stat_exp(x[p] - mx) * inv;
 }
 
 // value head: Linear(F·N² → 1) + tanh (net5.rs:62,109 / net6.rs:57,104-107).  One wave per position;
@@ -1312,9 +1449,55 @@ static hipError_t launch_conv_pos_t(hipStream_t st, const float* in, const float
     return hipGetLastError();
 }
 
+// slot table of the halo image for (n, F) on the current device, built on first use (launch_conv3x3's halo path; the fused
+// tower carries its own copy in TowerParams)
+static const uint32_t* conv_halo_slotmap(int n, int F, int pw, int ps) {
+    struct Entry { int dev, n, F; uint32_t* d; };
+    static std::vector<Entry> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    for (const Entry& e : cache) if (e.dev == dev && e.n == n && e.F == F) return e.d;
+    std::vector<uint32_t> map((size_t)((pw * n * n + 15) / 16) * 16);
+    tower_halo_slotmap(n, pw, ps, map.data());
+    uint32_t* d = nullptr;
+    if (hipMalloc((void**)&d, map.size() * 4) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, map.data(), map.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    cache.push_back({dev, n, F, d});
+    return d;
+}
+
+template <int RTW, int NWAVES, int CH, int NB, int COT>
+static hipError_t launch_conv_halo_t(hipStream_t st, const float* in, const float* Wp, const float* bias, const float* res, float* out,
+                                     const uint32_t* slotmap, int B, int PW, int PS, int CTW, int out_stride, int cout_valid, bool relu) {
+    const size_t lds = (size_t)(NB + 2 + PW * PS + 1) * (16 * CH + 4) * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_conv_halo<RTW, NWAVES, CH, NB, COT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    dim3 grid((B + PW - 1) / PW, COT / CTW);
+    hipLaunchKernelGGL((k_conv_halo<RTW, NWAVES, CH, NB, COT>), grid, dim3(NWAVES * 64), lds, st, in, Wp, bias, res, out, slotmap, B, PW, PS,
+                       CTW, out_stride, cout_valid, relu ? 1 : 0);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv3x3(hipStream_t st, const float* in, const float* Wp, const float* bias, const float* res, float* out,
                           int M, int n, int Cpad, int CoutP, int out_stride, int cout_valid, bool relu) {
     const int B = M / (n * n);
+    {   // F → F (and F → 2F) layers of the BASELINE topologies at full batches: the halo image (k_conv_halo), same bits as k_conv_pos
+        static const bool off = getenv("TG_NO_HALO_CONV") != nullptr;
+        int pw, ps;
+        if (!off && B >= 1024 && tower_halo_geometry(n, Cpad, &pw, &ps)) {
+            const uint32_t* map = conv_halo_slotmap(n, Cpad, pw, ps);
+            if (map) {
+                if (n == 5 && Cpad == 64 && CoutP == 64) return launch_conv_halo_t<13, 8, 4, 5, 4>(st, in, Wp, bias, res, out, map, B, pw, ps, 4, out_stride, cout_valid, relu);
+                if (n == 5 && Cpad == 128 && CoutP == 128) return launch_conv_halo_t<13, 8, 8, 5, 8>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu);
+                if (n == 6 && Cpad == 128 && CoutP == 128) return launch_conv_halo_t<9, 8, 8, 6, 8>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu);
+                if (n == 6 && Cpad == 128 && CoutP == 256) return launch_conv_halo_t<9, 8, 8, 6, 16>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu);
+            }
+        }
+    }
     // whole-positions kernel where the shape divides evenly (the BASELINE configs); generic tiles otherwise
     // small batches take fewer positions per workgroup (shorter critical path, same bits — see launch_tower)
 #define TG_CONV_POS(RTW, NW, PW, CTW) \
@@ -1539,12 +1722,22 @@ hipError_t launch_tower_states(hipStream_t st, const uint8_t* states, const Towe
 
 bool fc_frag_supported(int K, int NP) { return NP % FC_COLS == 0 && K % FC_KSTEP == 0 && NP % (FCS_CT * 16) == 0; }
 
+bool fc_stats_supported(int K, int NP, int out_stride) {
+    return NP % FC_COLS == 0 && K % FC_KSTEP == 0 && NP % (FCS_CT * 16) == 0 && out_stride == NP && NP / FC_COLS <= 64;
+}
+
 hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp, const float* bias, float* out, int M, int K,
-                       int NP, int out_stride, int n_valid, bool a_frag) {
+                       int NP, int out_stride, int n_valid, bool a_frag, float* stats, int n_soft) {
     if (a_frag && !fc_frag_supported(K, NP)) return hipErrorInvalidValue;
+    if (stats && !fc_stats_supported(K, NP, out_stride)) return hipErrorInvalidValue;
     if (NP % FC_COLS == 0 && K % FC_KSTEP == 0 && M <= FC_SMALL_ROWS && NP % (FCS_CT * 16) == 0) {
         dim3 grid((M + 15) / 16, (NP / (FCS_CT * 16) + 3) / 4);
         hipLaunchKernelGGL(k_fc_small, grid, dim3(256), 0, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid, a_frag ? 1 : 0);
+        if (stats) {  // (columns ≥ n_valid of `out` are never written by any FC kernel and never enter the statistics: n_soft ≤ n_valid)
+            const int blocks = NP / FC_COLS;
+            const long pairs = (long)M * blocks;
+            hipLaunchKernelGGL(k_fc_stats, dim3((unsigned)((pairs + 63) / 64)), dim3(256), 0, st, out, out_stride, M, blocks, n_soft, stats);
+        }
         return hipGetLastError();
     }
     if (NP % FC_COLS == 0 && K % FC_KSTEP == 0) {
@@ -1557,10 +1750,10 @@ hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp,
                 if (e != hipSuccess) return e;
                 configured = true;
             }
-            hipLaunchKernelGGL(k_fc_ring, grid, dim3(512), FC_RING_LDS, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid, a_frag ? 1 : 0);
+            hipLaunchKernelGGL(k_fc_ring, grid, dim3(512), FC_RING_LDS, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid, a_frag ? 1 : 0, stats, n_soft);
             return hipGetLastError();
         }
-        hipLaunchKernelGGL(k_fc_lds, grid, dim3(512), 0, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid, a_frag ? 1 : 0);
+        hipLaunchKernelGGL(k_fc_lds, grid, dim3(512), 0, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid, a_frag ? 1 : 0, stats, n_soft);
         return hipGetLastError();
     }
     dim3 grid((M + 127) / 128, NP / 64);
@@ -1580,6 +1773,12 @@ hipError_t launch_softmax(hipStream_t st, const float* logits, int row_stride, b
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_softmax, dim3(B), dim3(256), 0, st, logits, row_stride, conv_head ? 1 : 0, nsq, ch_stride, P, policy, conv_head ? nullptr : eval);
+    return hipGetLastError();
+}
+
+hipError_t launch_softmax_stats(hipStream_t st, const float* logits, int row_stride, const float* stats, int blocks, int P, int B,
+                                float* policy, float* eval) {
+    hipLaunchKernelGGL(k_softmax_stats, dim3(B), dim3(256), 0, st, logits, row_stride, stats, blocks, P, policy, eval);
     return hipGetLastError();
 }
 

@@ -85,6 +85,8 @@ struct SearchDev {
     const float* logits; // FC head: [G·batch][logit_ld] policy logits with the value pre-activation in column P; when set the
                          // backup takes softmax and tanh itself (softmax.cuh) and `policy` / `eval` are not produced
     int logit_ld;
+    const float* fc_stats; // with `logits`: per leaf and column block {max, Σexp(x − max)} emitted by the policy FC (softmax.cuh);
+    int fc_blocks;         // null → the backup reduces the whole logits row itself
     float* eval;         // [G]
     // constants
     const float* ctab;   // exploration_rate(n) for integer n (host logf, mcts.rs:10-12)

@@ -216,7 +216,7 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     d.legacy5 = e->legacy5 ? 1 : 0; d.evaluator = e->cfg.evaluator; d.slot_base = cfg->slot_base; d.seed = cfg->seed;
     d.batch = (int)B; d.pass = 0;
     d.retire = 0;  // tg_selfplay_create turns it on: only the self-play driver can restart a game on its own
-    d.logits = nullptr; d.logit_ld = 0;  // refreshed before every iteration (bind_logits)
+    d.logits = nullptr; d.logit_ld = 0; d.fc_stats = nullptr; d.fc_blocks = 0;  // refreshed before every iteration (bind_logits)
     e->search = sp.release();
     return TG_OK;
 }
@@ -240,11 +240,18 @@ static void bind_logits(TgEngine* e) {
     Search* s = e->search;
     s->d.logits = nullptr;
     s->d.logit_ld = 0;
+    s->d.fc_stats = nullptr;
+    s->d.fc_blocks = 0;
     static const bool off = getenv("TG_DUAL_STREAM") != nullptr || getenv("TG_NO_FUSED_SOFTMAX") != nullptr;
     if (off || e->cfg.evaluator != TG_EVAL_RESNET) return;
     int ld = 0;
     const float* lg = net_fc_logits(e, &ld);
-    if (lg) { s->d.logits = lg; s->d.logit_ld = ld; }
+    if (lg) {
+        s->d.logits = lg; s->d.logit_ld = ld;
+        int blocks = 0;
+        const float* fs = net_fc_stats(e, &blocks);
+        if (fs) { s->d.fc_stats = fs; s->d.fc_blocks = blocks; }
+    }
 }
 
 // one lock-step iteration: the body of train/src/self_play.rs:181-210

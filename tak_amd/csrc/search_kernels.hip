@@ -335,7 +335,9 @@ __device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, con
     const float* lrow = S.logits ? S.logits + slot * (size_t)S.logit_ld : nullptr;
     float lmx = 0.0f, linv = 0.0f;
     if (S.evaluator == TG_EVAL_RESNET && lrow) {
-        softmax_stats_wave(lrow, S.P, lmx, linv);
+        if (S.fc_stats)  // 64 B (wave-uniform address: scalar loads) instead of the whole row
+            fc_combine_stats(S.fc_stats + (size_t)uni((uint32_t)slot) * (size_t)S.fc_blocks * 2, S.fc_blocks, lmx, linv);
+        else softmax_stats_wave(lrow, S.P, lmx, linv);
         e = tanhf(lrow[S.P]);
     } else if (S.evaluator == TG_EVAL_RESNET) e = S.eval[slot];
     else if (S.evaluator == TG_EVAL_HASH) { hsh = S.leaf_hash[slot]; e = hash_eval(hsh); }
@@ -348,7 +350,7 @@ __device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, con
         int idx = move_index_dev(mv, S.n, S.legacy5 != 0, S.lut5);
         float p;
         if (idx < 0 || idx >= S.P) { bad = true; p = 0.0f; }
-        else if (S.evaluator == TG_EVAL_RESNET) p = lrow ? expf(lrow[idx] - lmx) * linv : pol[idx];
+        else if (S.evaluator == TG_EVAL_RESNET) p = !lrow ? pol[idx] : S.fc_stats ? stat_exp(lrow[idx] - lmx) * linv : expf(lrow[idx] - lmx) * linv;
         else if (S.evaluator == TG_EVAL_HASH) p = hash_policy(hsh, (uint32_t)idx);
         else p = 1.0f;
         hot[cb + i].prior = p;

@@ -52,4 +52,58 @@ __device__ inline void softmax_stats_wave(const float* __restrict__ x, int P, fl
     inv_out = 1.0f / s;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Block-wise softmax statistics of the FC policy head (full batches on the exact-f32 path).  The policy FC computes a row's
+// logits in 8 column blocks of 208 (13 MFMA tiles of 16; one workgroup column of k_fc_ring / k_fc_lds each), and the lane
+// that holds a value in its accumulators is the cheapest place to take max and Σexp: per (row, block) the FC's epilogue
+// emits  m_b = max of the block's policy columns,  s_b = Σ exp(x − m_b)  — 64 B per row instead of the tree backup
+// re-reading all 1575 logits (6.3 KB per game and iteration, 19 of its 56 k cycles).  The canonical association order,
+// followed by the FC epilogue (fc_block_stats), by k_fc_stats (any other producer of the logits) and therefore by
+// everything that consumes the statistics (k_softmax_stats for tg_policy_eval, the tree backup):
+//   lane (r16, q) of the row's wave holds columns  n0 + 16 j + 4 q + t  (j = 0..12, t = 0..3);
+//   lane partial = ((…(e(0,0) + e(0,1)) + e(0,2)) + …) + e(12,3),  e(j,t) = exp(x − m_b) (stat_exp) or 0 beyond the policy columns;
+//   s_b = (s_q + s_{q^1}) + (s_{q^2} + s_{q^3})   (butterfly over lanes 16 and 32 apart);
+//   M = max_b m_b,  S = ((s_0·exp(m_0 − M) + s_1·exp(m_1 − M)) + …) + s_7·exp(m_7 − M),  p(x) = exp(x − M) · (1 / S).
+// ------------------------------------------------------------------------------------------------------------------
+// exp of this path: v_exp_f32(x · log2 e) — two instructions where expf() is a dozen (52 of them per lane made the FC's epilogue
+// 2.2 µs longer than the 4 µs the backup saved).  Arguments are ≤ 0; relative error ≈ 1e-6 at x = −20, far inside the 1e-4
+// gate against PyTorch.  EVERY consumer of the statistics uses this same function, so they agree bit for bit.
+__device__ __forceinline__ float stat_exp(float x) { return __expf(x); }
+
+constexpr int FC_STAT_COLS = 208;   // columns per statistics block = FC_COLS of net_kernels.hip
+constexpr int FC_STAT_TILES = 13;
+
+using softmax_f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// v[j] = the lane's four logits of tile j (bias added); col0 = n0 + 4q: the lane's first column of tile 0.  All 64 lanes call.
+__device__ __forceinline__ void fc_block_stats(const softmax_f32x4 (&v)[FC_STAT_TILES], int col0, int n_soft, float& m_out, float& s_out) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < FC_STAT_TILES; j++)
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            if (col0 + 16 * j + t < n_soft) m = fmaxf(m, v[j][t]);
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < FC_STAT_TILES; j++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) s += (col0 + 16 * j + t < n_soft) ? stat_exp(v[j][t] - m) : 0.0f;
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    m_out = m;
+    s_out = s;
+}
+
+// (M, 1/S) of a row from its per-block statistics stats[2b] = m_b, stats[2b + 1] = s_b; nblocks ≤ 64, every lane gets the result
+__device__ __forceinline__ void fc_combine_stats(const float* __restrict__ stats, int nblocks, float& mx_out, float& inv_out) {
+    float M = -INFINITY;
+    for (int b = 0; b < nblocks; b++) M = fmaxf(M, stats[2 * b]);
+    float S = 0.0f;
+    for (int b = 0; b < nblocks; b++) S += stats[2 * b + 1] * stat_exp(stats[2 * b] - M);
+    mx_out = M;
+    inv_out = 1.0f / S;
+}
+
 }  // namespace tg

@@ -8,6 +8,7 @@
 // only a different packing of the weights (k_pack_conv_bwd).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "conv_mainloop.cuh"
 #include "kernels.h"
@@ -383,7 +384,8 @@ __global__ void k_value_wgrad_finalize(const double* __restrict__ part, int spli
 // gradient buffer in tch layout — deterministic, and the place where gradients accumulate over chunks.
 // part[((split·ntiles + tile)·nsub + sub)·4096 + co_l·64 + ci_l]
 // ------------------------------------------------------------------------------------------------
-template <bool CONV>
+// PF: float4 slots per thread of the register prefetch (CONV): a chunk holds at most 16·PF rows
+template <bool CONV, int PF = 4>
 __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ X, int xs, int xvalid, const float* __restrict__ G, int gs,
                                                int gvalid, int R, int n, int nsq, int rows_chunk, int chunks_per_split, int ncob,
                                                float* __restrict__ part) {
@@ -418,10 +420,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ X, int 
     const int row_begin = split * chunks_per_split * rows_chunk;
     // CONV: the next chunk's X / G slots travel through registers (≤ 4 + 4 float4 per thread, unconditional clamped loads)
     // while the current chunk's MFMAs run; they are written to LDS behind the barrier that ends the chunk
-    f32x4 px[4], pg[4];
+    f32x4 px[PF], pg[PF];
     auto prefetch = [&](int r0) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < PF; u++) {
             const int idx = u * 256 + tid;
             const int r = idx >> 4, v = idx & 15;
             const int rr = min(r0 + r, R - 1);
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ X, int 
         if (CONV) {
             const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < PF; u++) {
                 const int idx = u * 256 + tid;
                 const int r = idx >> 4, v = idx & 15;
                 if (idx < rows * 16) Xt[r * XLS4 + v] = (xc0 + 4 * v < xvalid) ? px[u] : zero;
@@ -698,7 +700,14 @@ hipError_t launch_value_bwd(hipStream_t st, const float* act, const float* dpre,
 
 // workspace floats needed by launch_wgrad_* for the given shape
 static void wgrad_plan_conv(int B, int nsq, int ntiles, int* pw, int* cps, int* splits) {
-    *pw = nsq >= 48 ? 1 : 48 / nsq;
+    // positions per chunk: what the register prefetch of PF = 4 carries (64 rows): 5×5 → 2 positions = 50 rows (one position
+    // = 25 rows padded to 28 wasted 11 % of the MFMAs and paid a pair of barriers every 7 k-steps: 23.2 → 22.4 ms per chunk of the
+    // C5 network); 4 positions = 100 rows need PF = 7, which leaves one wave per SIMD (112 + 144 registers) and is no faster
+    // (23.2 ms).  TG_WGRAD_PW overrides (A/B).
+    static const int forced = getenv("TG_WGRAD_PW") ? atoi(getenv("TG_WGRAD_PW")) : 0;
+    *pw = forced > 0 ? forced : 64 / nsq;
+    if (*pw * nsq > 112) *pw = 112 / nsq;
+    if (*pw < 1) *pw = 1;
     int chunks = (B + *pw - 1) / *pw;
     int target = 512 / ntiles;  // two resident workgroups per CU (register-limited): one full round, half the partials to reduce
     if (target < 1) target = 1;
@@ -719,8 +728,12 @@ hipError_t launch_wgrad_conv(hipStream_t st, const float* X, int xs, int I, cons
     size_t lds = ((size_t)(rows_chunk + 1) * 17 + (size_t)rows_pad * 17) * 16 + (size_t)rows_pad * 4;
     const int xvalid = xs < ncib * 64 ? xs : ncib * 64;  // columns that exist in memory
     const int gvalid = gs < ncob * 64 ? gs : ncob * 64;
-    hipLaunchKernelGGL((k_wgrad<true>), dim3(splits, ncib * ncob), dim3(256), lds, st, X, xs, xvalid, G, gs, gvalid, B * nsq, n, nsq,
-                       rows_chunk, cps, ncob, part);
+    if (rows_chunk <= 64)
+        hipLaunchKernelGGL((k_wgrad<true, 4>), dim3(splits, ncib * ncob), dim3(256), lds, st, X, xs, xvalid, G, gs, gvalid, B * nsq, n, nsq,
+                           rows_chunk, cps, ncob, part);
+    else
+        hipLaunchKernelGGL((k_wgrad<true, 7>), dim3(splits, ncib * ncob), dim3(256), lds, st, X, xs, xvalid, G, gs, gvalid, B * nsq, n, nsq,
+                           rows_chunk, cps, ncob, part);
     size_t total = (size_t)ncib * ncob * 9 * 4096;
     hipLaunchKernelGGL(k_wgrad_reduce_conv, dim3(blocks_for(total)), dim3(256), 0, st, part, splits, ncib, ncob, O, I, grad);
     return hipGetLastError();

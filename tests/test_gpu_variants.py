@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _digest(cfg, batch, **env):
     e = dict(os.environ)
-    for k in ("TG_NO_HALO_TOWER", "TG_FC_BARRIER", "TG_NO_FRAG_OUT", "TG_PRECISION", "TG_NO_CONST_BIAS"):
+    for k in ("TG_NO_HALO_TOWER", "TG_FC_BARRIER", "TG_NO_FRAG_OUT", "TG_PRECISION", "TG_NO_CONST_BIAS", "TG_NO_FC_STATS"):
         e.pop(k, None)
     e.update(env)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "ab_bits.py"), cfg, str(batch)], env=e, check=True,

@@ -309,13 +309,16 @@ __device__ inline int spread_count(int max_carry, int free_run, bool smash) {
     return T.c[max_carry][free_run][smash ? 1 : 0];
 }
 
+// Inclusive prefix sum over the 64 lanes with DPP adds (six v_add with a data-parallel-primitive operand: row_shr 1, 2, 4, 8
+// inside the rows of 16 lanes, then row_bcast15 / row_bcast31 carry the row totals on) instead of six ds_bpermute round trips
+// through the LDS crossbar with a select each.  Lanes that receive nothing add the identity 0 (`old` of update_dpp).
 __device__ inline int wave_inclusive_scan(int v) {
-    int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(v, d);
-        if (lane >= d) v += t;
-    }
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast15 → rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast31 → rows 2 and 3
     return v;
 }
 
@@ -482,8 +485,11 @@ __device__ inline float4 row_mask_value(const RowMask& m, int k, int C, float fc
 // Write the encoded planes of one game, fully coalesced.  NCHW: out[c*nsq + sq] (the reference
 // tensor); NHWC: out[sq*cstride + c] with channels C..cstride-1 zero (the layout the conv kernels
 // consume, rows padded to a multiple of 8 channels).
-template <bool NHWC>
+// CS: the NHWC row stride as a compile-time constant (0 = `cstride`): the division by cstride/4 of every store round then
+// is a multiply-shift instead of a ≈ 20-instruction software division
+template <bool NHWC, int CS = 0>
 __device__ inline void ws_encode(const WState& s, const Geom& g, float* out, int cstride) {
+    if (CS) cstride = CS;
     const int lane = lane_id();
     const int C = input_channels(g.n);
     if (!NHWC) cstride = C;

@@ -108,12 +108,14 @@ __global__ __launch_bounds__(256) void k_perft_expand(const uint8_t* __restrict_
 // One fused pass of the board path over a batch (the micro-benchmark of SURVEY.md §8d): play a move,
 // evaluate the terminal test, count the legal moves and encode the NHWC planes.  Algorithmic bytes per
 // position = state in + state out + f32 planes (256 + 256 + 7200 on 5×5).
+// NB: the board size as a compile-time constant (0 = `n`): geometry masks fold, divisions by n become multiply-shifts.
+template <int NB, int CS = 0>
 __global__ __launch_bounds__(256) void k_board_pass(const uint8_t* __restrict__ states, const uint16_t* __restrict__ moves, int count,
                                                     int n, uint8_t* __restrict__ out_states, uint8_t* __restrict__ results,
                                                     int32_t* __restrict__ counts, float* __restrict__ planes, int cstride) {
     int gi = wave_global_id();
     if (gi >= count) return;
-    Geom g = make_geom(n);
+    Geom g = make_geom(NB ? NB : n);
     WState s;
     ws_load(s, states + (size_t)gi * g.bytes, g);
     ws_play(s, uni((uint32_t)moves[gi]), g);
@@ -123,7 +125,12 @@ __global__ __launch_bounds__(256) void k_board_pass(const uint8_t* __restrict__ 
     uint32_t r = (BOARD_PROBE & 1) ? (uint32_t)TG_ONGOING : ws_result(s, g);
     int c = (r == TG_ONGOING && !(BOARD_PROBE & 2)) ? ws_movegen(s, g, 0, [](int, uint32_t) {}) : 0;
     ws_store(s, out_states + (size_t)gi * g.bytes, g);
-    if (!(BOARD_PROBE & 4)) ws_encode<true>(s, g, planes + (size_t)gi * cstride * g.nsq, cstride);
+    // CS: the planes' row stride as a constant (the launcher instantiates the unpadded row of the micro-benchmark, 72 / 92
+    // channels, and the 16-channel-padded one the per-layer conv kernels read)
+    if (!(BOARD_PROBE & 4)) {
+        if (CS) ws_encode<true, CS>(s, g, planes + (size_t)gi * CS * g.nsq, CS);
+        else ws_encode<true>(s, g, planes + (size_t)gi * cstride * g.nsq, cstride);
+    }
     if (lane_id() == 0) { results[gi] = (uint8_t)r; counts[gi] = c; }
 }
 
@@ -208,7 +215,14 @@ void launch_encode_nhwc(hipStream_t st, const uint8_t* states, int count, int n,
 }
 void launch_board_pass(hipStream_t st, const uint8_t* states, const uint16_t* moves, int count, int n, uint8_t* out_states,
                        uint8_t* results, int32_t* counts, float* planes, int cstride) {
-    if (count > 0) hipLaunchKernelGGL(k_board_pass, wave_grid(count), dim3(256), 0, st, states, moves, count, n, out_states, results, counts, planes, cstride);
+    if (count <= 0) return;
+#define TG_BP(NB, CS) hipLaunchKernelGGL((k_board_pass<NB, CS>), wave_grid(count), dim3(256), 0, st, states, moves, count, n, out_states, results, counts, planes, cstride)
+    if (n == 5 && cstride == 72) TG_BP(5, 72);
+    else if (n == 5 && cstride == 80) TG_BP(5, 80);
+    else if (n == 6 && cstride == 92) TG_BP(6, 92);
+    else if (n == 6 && cstride == 96) TG_BP(6, 96);
+    else TG_BP(0, 0);
+#undef TG_BP
 }
 void launch_augment(hipStream_t st, const uint8_t* states, const int32_t* n_moves, const uint16_t* moves, const uint32_t* visits, int count,
                     int n, int P, bool legacy5, const int16_t* lut5, uint8_t* out_states, float* pi) {

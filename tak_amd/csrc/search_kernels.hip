@@ -7,6 +7,8 @@
 // exploration rate comes from a host-computed table over the (integer) visit count, and both argmaxes
 // keep the LAST maximum like Iterator::max_by / max_by_key, so that search traces are reproducible bit
 // for bit against a scalar CPU statement of the same algorithm.
+#include <stdlib.h>
+
 #include "board.cuh"
 #include "kernels.h"
 #include "rng.cuh"
@@ -103,6 +105,10 @@ __device__ inline void update_concrete(NodeHot& h, float reward) {
 // virtual visit (or back a concrete result up when the rollout ends on a terminal node), and leave
 // the leaf encoded in the network input batch.
 // ------------------------------------------------------------------------------------------------
+// NB: board size as a compile-time constant (5, 6; 0 = read S.n).  With n known the geometry masks fold to immediates and the
+// many divisions by n / n² of move generation, play and the encoder become multiply-shifts instead of ≈ 20-instruction
+// software divisions — the tree kernels are bound by vector issue, so this is time.
+template <int NB>
 __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* __restrict__ active, const int g, const int pass,
                                             uint32_t* path, uint16_t* mvl) {
     const int lane = lane_id();
@@ -113,7 +119,7 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
         if (lane == 0) S.leaf_kind[slot] = 0;
         return;
     }
-    const Geom geo = make_geom(S.n);
+    const Geom geo = make_geom(NB ? NB : S.n);
     WState s;
     ws_load(s, S.root_state + (size_t)g * geo.bytes, geo);
     NodeHot* hot = S.hot;
@@ -299,6 +305,7 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
 // the other — a game's tree is only ever touched by its own wave, so the passes need no kernel boundary between them, only
 // the wave's own stores ordered before its later loads (s_waitcnt: a wave's accesses go through one in-order, write-through
 // L1 path; an agent-scope fence would write back the whole L2 per wave and cost more than the launches it replaces).
+template <int NB>
 __global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __restrict__ active) {
     __shared__ uint32_t path_lds[WPB][MAX_DEPTH];
     __shared__ uint16_t mv_lds[WPB][EX_MOVES];
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __re
     uint32_t* path = path_lds[threadIdx.x >> 6];
     const int p0 = S.pass < 0 ? 0 : S.pass, p1 = S.pass < 0 ? S.batch : S.pass + 1;
     for (int p = p0; p < p1; p++) {
-        select_pass(S, active, g, p, path, mv_lds[threadIdx.x >> 6]);
+        select_pass<NB>(S, active, g, p, path, mv_lds[threadIdx.x >> 6]);
         if (p + 1 < p1) wave_sync_mem();
     }
 }
@@ -316,6 +323,7 @@ __global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __re
 // devirtualize_path, mcts.rs:67-91: real priors for the leaf's children, value backed up with
 // alternating sign, virtual visits removed.
 // ------------------------------------------------------------------------------------------------
+template <int NB>
 __device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, const int pass) {
     const size_t slot = (size_t)g * (size_t)S.batch + (size_t)pass;
     if (S.leaf_kind[slot] != 1) return;
@@ -347,7 +355,7 @@ __device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, con
     TG_TSTAMP(g, 1);  // leaf record + softmax statistics done
     for (uint32_t i = lane; i < nchild; i += 64) {
         uint32_t mv = cold[cb + i].mv;
-        int idx = move_index_dev(mv, S.n, S.legacy5 != 0, S.lut5);
+        int idx = move_index_dev(mv, NB ? NB : S.n, S.legacy5 != 0, S.lut5);
         float p;
         if (idx < 0 || idx >= S.P) { bad = true; p = 0.0f; }
         else if (S.evaluator == TG_EVAL_RESNET) p = !lrow ? pol[idx] : S.fc_stats ? stat_exp(lrow[idx] - lmx) * linv : expf(lrow[idx] - lmx) * linv;
@@ -372,12 +380,13 @@ __device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, con
 }
 
 // S.pass as in k_select: one de-virtualisation, or all of the iteration's in rollout order
+template <int NB>
 __global__ __launch_bounds__(256) void k_backup(SearchDev S) {
     const int g = game_of_wave();
     if (g >= S.G) return;
     const int p0 = S.pass < 0 ? 0 : S.pass, p1 = S.pass < 0 ? S.batch : S.pass + 1;
     for (int p = p0; p < p1; p++) {
-        backup_pass(S, g, p);
+        backup_pass<NB>(S, g, p);
         if (p + 1 < p1) wave_sync_mem();
     }
 }
@@ -385,16 +394,17 @@ __global__ __launch_bounds__(256) void k_backup(SearchDev S) {
 // De-virtualise iteration i and select the leaf of iteration i + 1 in one launch (one leaf per game): the two touch the same
 // few nodes of the same tree from the same wave, so the second finds them in cache and one kernel boundary per iteration
 // disappears.  Same device functions as the separate kernels → same trees.
+template <int NB>
 __global__ __launch_bounds__(256) void k_backup_select(SearchDev S) {
     __shared__ uint32_t path_lds[WPB][MAX_DEPTH];
     __shared__ uint16_t mv_lds[WPB][EX_MOVES];
     const int g = game_of_wave();
     if (g >= S.G) return;
     TG_TSTAMP(g, 0);
-    backup_pass(S, g, 0);
+    backup_pass<NB>(S, g, 0);
     wave_sync_mem();
     TG_TSTAMP(g, 3);  // path updated
-    select_pass(S, nullptr, g, 0, path_lds[threadIdx.x >> 6], mv_lds[threadIdx.x >> 6]);
+    select_pass<NB>(S, nullptr, g, 0, path_lds[threadIdx.x >> 6], mv_lds[threadIdx.x >> 6]);
     TG_TSTAMP(g, 31);
 }
 
@@ -869,11 +879,17 @@ __global__ void k_sp_count_ply(SelfPlayDev P) { P.stats[ST_PLIES] += 1; }
 // ---- launchers --------------------------------------------------------------------------------
 static inline dim3 wgrid(int G) { return dim3((G + WPB - 1) / WPB); }
 
-void launch_select(hipStream_t st, const SearchDev& S, const uint8_t* active) {
-    hipLaunchKernelGGL(k_select, wgrid(S.G), dim3(256), 0, st, S, active);
-}
-void launch_backup(hipStream_t st, const SearchDev& S) { hipLaunchKernelGGL(k_backup, wgrid(S.G), dim3(256), 0, st, S); }
-void launch_backup_select(hipStream_t st, const SearchDev& S) { hipLaunchKernelGGL(k_backup_select, wgrid(S.G), dim3(256), 0, st, S); }
+// the tree kernels are compiled for the board sizes of the BASELINE configs (n as a constant) and once for any size
+static const bool g_runtime_n = getenv("TG_RUNTIME_N") != nullptr;  // A/B: the generic instantiation for every size (same results)
+#define TG_BY_BOARD(KERNEL, ...)                                                                          \
+    do {                                                                                                  \
+        if (S.n == 5 && !g_runtime_n) hipLaunchKernelGGL(KERNEL<5>, wgrid(S.G), dim3(256), 0, st, __VA_ARGS__);      \
+        else if (S.n == 6 && !g_runtime_n) hipLaunchKernelGGL(KERNEL<6>, wgrid(S.G), dim3(256), 0, st, __VA_ARGS__); \
+        else hipLaunchKernelGGL(KERNEL<0>, wgrid(S.G), dim3(256), 0, st, __VA_ARGS__);                    \
+    } while (0)
+void launch_select(hipStream_t st, const SearchDev& S, const uint8_t* active) { TG_BY_BOARD(k_select, S, active); }
+void launch_backup(hipStream_t st, const SearchDev& S) { TG_BY_BOARD(k_backup, S); }
+void launch_backup_select(hipStream_t st, const SearchDev& S) { TG_BY_BOARD(k_backup_select, S); }
 void launch_dirichlet(hipStream_t st, const SearchDev& S, const uint8_t* active, float alpha, float ratio) {
     hipLaunchKernelGGL(k_dirichlet, dim3(S.G), dim3(64), 0, st, S, active, alpha, ratio);
 }

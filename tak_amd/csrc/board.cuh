@@ -360,14 +360,18 @@ __device__ inline int ws_movegen(const WState& s, const Geom& g, int cap, F&& em
             } else if ((own_bb >> sq) & 1ull) {
                 kind = 3;
                 max_carry = (int)h < n ? (int)h : n;
-                int room = d == UP ? n - 1 - y : d == DOWN ? y : d == LEFT ? x : n - 1 - x;
-                int delta = d == UP ? n : d == DOWN ? -n : d == LEFT ? -1 : 1;
-                int pos = sq;
-                for (int t = 0; t < room; t++) {
-                    pos += delta;
-                    if ((cap_bb >> pos) & 1ull) break;
-                    if ((wall_bb >> pos) & 1ull) { smash = (tp == CAP); break; }
-                    free_run++;
+                // squares in direction d that accept any drop before the edge / a cap / a wall (the walk of move_gen.rs:66-87),
+                // without a per-lane loop: the first blocker on the ray is a find-first-bit of (caps | walls) under the ray's mask
+                const int room = d == UP ? n - 1 - y : d == DOWN ? y : d == LEFT ? x : n - 1 - x;
+                const uint64_t below = (1ull << sq) - 1ull, above = ~((2ull << sq) - 1ull);
+                const uint64_t line = (d == UP || d == DOWN) ? (g.col0 << x) : (g.row0 << (y * n));
+                const uint64_t hits = (cap_bb | wall_bb) & line & ((d == UP || d == RIGHT) ? above : below);
+                free_run = room;
+                if (hits) {
+                    const int pos = (d == UP || d == RIGHT) ? __builtin_ctzll(hits) : 63 - __builtin_clzll(hits);
+                    const int dist = (d == UP || d == RIGHT) ? pos - sq : sq - pos;
+                    free_run = ((d == UP || d == DOWN) ? dist / n : dist) - 1;
+                    smash = ((wall_bb >> pos) & 1ull) && tp == CAP;
                 }
             }
         }

@@ -528,6 +528,111 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ X, int 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The conv weight gradient with the X tile as a HALO image (round 3; k_wgrad<true> stays for other board sizes and as the
+// A/B reference, TG_NO_HALO_WGRAD).  Same decomposition — 64(co)×64(ci) block per workgroup, wave w = G sub-tile a = w × 9
+// taps × 4 X sub-tiles, chunks of PWC positions, split-K partials in the same layout — but the staged input rows sit in halo
+// cells (one zero cell behind every board row, a zero row behind every position, as in k_tower_halo): a tap is a constant cell
+// offset whether or not it stays on the board.  So the per-step work of a wave is 1 + 9 LDS reads at addresses that are a
+// per-kernel register (the cell of its row, the same in every chunk) plus an immediate, and 36 MFMAs: no tap masks, no selects,
+// no address arithmetic, no LDS read that another LDS read waits for (k_wgrad spent 93 vector instructions per step on those and
+// kept the MFMA pipe 65 % busy).  Row r of a chunk ↔ cell LEAD + (r / n²)·PS + (y·RS + x).
+// ------------------------------------------------------------------------------------------------
+template <int NB, int PWC>
+__global__ __launch_bounds__(256, 2) void k_wgrad_halo(const float* __restrict__ X, int xs, int xvalid, const float* __restrict__ G, int gs,
+                                                    int gvalid, int R, int chunks_per_split, int ncob, float* __restrict__ part) {
+    constexpr int n = NB, nsq = NB * NB, RS = NB + 1, LEAD = NB + 2, PS = (NB + 1) * RS;
+    constexpr int ROWS = PWC * nsq, ROWS_PAD = (ROWS + 3) & ~3, NSTEPS = ROWS_PAD / 4;
+    constexpr int CELLS = LEAD + PWC * PS + 1;
+    constexpr int XLS4 = 17, GLS4 = 17;
+    constexpr int PF = (ROWS * 16 + 255) / 256;  // float4 slots per thread of the register prefetch
+    static_assert(ROWS <= 64, "the register prefetch carries at most 64 rows");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    f32x4* Xh = (f32x4*)lds;                       // CELLS cells of XLS4 slots
+    f32x4* Gt = Xh + (size_t)CELLS * XLS4;         // ROWS_PAD rows of GLS4 slots
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int tile = blockIdx.y, cib = tile / ncob, cob = tile - cib * ncob;
+    const int xc0 = cib * 64, gc0 = cob * 64;
+    const int split = blockIdx.x;
+    auto cell_of = [](int r) { const int p = r / nsq, sq = r - p * nsq, y = sq / n, x = sq - y * n; return LEAD + p * PS + y * RS + x; };
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // every cell zero once; the squares' cells are overwritten chunk by chunk, the halo never again
+    for (int idx = tid; idx < CELLS * XLS4; idx += 256) Xh[idx] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this lane's rows 4s + q of a chunk: X address (cell, slot j) and G address (row, slot j, component `wave`) — per kernel
+    int xa[NSTEPS];
+#pragma unroll
+    for (int s = 0; s < NSTEPS; s++) {
+        const int r = 4 * s + q;
+        xa[s] = (r < ROWS ? cell_of(r) : LEAD) * XLS4 + j;  // (padding rows read a real cell against a zero gradient)
+    }
+    const int ga = (q * GLS4 + j) * 4 + wave;
+
+    const int row_begin = split * chunks_per_split * ROWS;
+    f32x4 px[PF], pg[PF];
+    auto prefetch = [&](int r0) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int idx = u * 256 + tid;
+            const int r = idx >> 4, v = idx & 15;
+            const int rr = min(r0 + r, R - 1);
+            const int cx = min(xc0 + 4 * v, xs - 4), cg = min(gc0 + 4 * v, gs - 4);
+            px[u] = *(const f32x4*)(X + (size_t)rr * xs + cx);
+            pg[u] = *(const f32x4*)(G + (size_t)rr * gs + cg);
+        }
+    };
+    if (row_begin < R) prefetch(row_begin);
+    for (int ch = 0; ch < chunks_per_split; ch++) {
+        const int r0 = row_begin + ch * ROWS;
+        if (r0 >= R) break;
+        const int rows = min(ROWS, R - r0);
+        __syncthreads();  // the previous chunk has been consumed (and, the first time, the zero fill is complete)
+        {
+            const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const int idx = u * 256 + tid;
+                const int r = idx >> 4, v = idx & 15;
+                if (idx < ROWS * 16) Xh[cell_of(r) * XLS4 + v] = (r < rows && xc0 + 4 * v < xvalid) ? px[u] : zero;
+                if (idx < ROWS_PAD * 16) Gt[r * GLS4 + v] = (r < rows && gc0 + 4 * v < gvalid) ? pg[u] : zero;
+            }
+        }
+        __syncthreads();
+        if (ch + 1 < chunks_per_split && r0 + ROWS < R) prefetch(r0 + ROWS);
+#pragma unroll
+        for (int s = 0; s < NSTEPS; s++) {
+            const float g = ((const float*)Gt)[ga + s * 4 * GLS4 * 4];
+            f32x4 x[9];
+#pragma unroll
+            for (int t = 0; t < 9; t++) x[t] = Xh[xa[s] + ((t / 3 - 1) * RS + (t % 3 - 1)) * XLS4];
+#pragma unroll
+            for (int t = 0; t < 9; t++)
+#pragma unroll
+                for (int u = 0; u < 4; u++) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(g, x[t][u], acc[t][u], 0, 0, 0);
+            // one step's operands at a time: left alone the scheduler hoists the reads of many steps ahead of the MFMAs (246
+            // registers, one wave per SIMD); the second wave of the SIMD covers this wave's LDS latency instead
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // lane (j, q), register v of sub-tile (a = wave, u): co_l = 16q + 4v + wave, ci_l = 4j + u   (k_wgrad's partial layout)
+    const int ntiles = gridDim.y;
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        float* dst = part + (((size_t)split * ntiles + tile) * 9 + t) * 4096;
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int co_l = 16 * q + 4 * v + wave;
+            f32x4 o = f32x4{acc[t][0][v], acc[t][1][v], acc[t][2][v], acc[t][3][v]};
+            *(f32x4*)(dst + co_l * 64 + 4 * j) = o;
+        }
+    }
+}
+
 // conv: grad[(co·I + ci)·9 + tap] += Σ_split part[…]
 __global__ __launch_bounds__(256) void k_wgrad_reduce_conv(const float* __restrict__ part, int splits, int ncib, int ncob, int O,
                                                            int I, float* __restrict__ grad) {
@@ -728,7 +833,14 @@ hipError_t launch_wgrad_conv(hipStream_t st, const float* X, int xs, int I, cons
     size_t lds = ((size_t)(rows_chunk + 1) * 17 + (size_t)rows_pad * 17) * 16 + (size_t)rows_pad * 4;
     const int xvalid = xs < ncib * 64 ? xs : ncib * 64;  // columns that exist in memory
     const int gvalid = gs < ncob * 64 ? gs : ncob * 64;
-    if (rows_chunk <= 64)
+    static const bool no_halo = getenv("TG_NO_HALO_WGRAD") != nullptr || getenv("TG_WGRAD_PW") != nullptr;
+    if (!no_halo && n == 5 && pw == 2) {
+        constexpr size_t hl = ((size_t)(5 + 2 + 2 * 36 + 1) * 17 + 52 * 17) * 16;
+        hipLaunchKernelGGL((k_wgrad_halo<5, 2>), dim3(splits, ncib * ncob), dim3(256), hl, st, X, xs, xvalid, G, gs, gvalid, B * nsq, cps, ncob, part);
+    } else if (!no_halo && n == 6 && pw == 1) {
+        constexpr size_t hl = ((size_t)(6 + 2 + 1 * 49 + 1) * 17 + 36 * 17) * 16;
+        hipLaunchKernelGGL((k_wgrad_halo<6, 1>), dim3(splits, ncib * ncob), dim3(256), hl, st, X, xs, xvalid, G, gs, gvalid, B * nsq, cps, ncob, part);
+    } else if (rows_chunk <= 64)
         hipLaunchKernelGGL((k_wgrad<true, 4>), dim3(splits, ncib * ncob), dim3(256), lds, st, X, xs, xvalid, G, gs, gvalid, B * nsq, n, nsq,
                            rows_chunk, cps, ncob, part);
     else

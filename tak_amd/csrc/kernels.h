@@ -21,8 +21,16 @@ void launch_perft_expand(hipStream_t st, const uint8_t* states, int count, int n
                          uint8_t* next_states, int32_t* next_root);
 
 // net_kernels.hip
+// stats_part / stats_blocks (optional, training forward): when the launch can emit BatchNorm's column sums from its
+// accumulators (the halo kernel, all channels in one workgroup column) it writes *stats_blocks partial rows
+// part[(block·2 + {Σ, Σ²})·CoutP + channel] as doubles and sets *stats_blocks > 0; otherwise *stats_blocks = 0 and the caller
+// reduces the output itself (launch_bn_stats)
 hipError_t launch_conv3x3(hipStream_t st, const float* in, const float* Wp, const float* bias, const float* res, float* out,
-                          int M, int n, int Cpad, int CoutP, int out_stride, int cout_valid, bool relu);
+                          int M, int n, int Cpad, int CoutP, int out_stride, int cout_valid, bool relu,
+                          double* stats_part = nullptr, int* stats_blocks = nullptr);
+// mean, 1/σ and the running statistics from such partial rows (Σz, Σz² in double): replaces launch_bn_stats' two passes over z
+hipError_t launch_bn_stats_from_partials(hipStream_t st, const double* part, int nblk, int M, int F, float eps, float momentum,
+                                         float* mean, float* invstd, float* running_mean, float* running_var);
 // fused residual tower (k_tower): per-layer weight / bias pointers
 struct TowerParams {
     const float* w[48];   // per layer: Wp[K/16][CoutP][16]
@@ -113,7 +121,7 @@ hipError_t launch_bn_stats(hipStream_t st, const float* z, int M, int F, float e
 hipError_t launch_bn_fwd_apply(hipStream_t st, const float* z, const float* mean, const float* invstd, const float* gamma,
                                const float* beta, const float* skip, float* y, int M, int F);
 hipError_t launch_bn_bwd(hipStream_t st, const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
-                         const float* gamma, int M, int F, double* part, float* mean_g, float* mean_gx, float* grad_gamma,
+                         const float* gamma, int M, int F, double* part, double* mean_g, double* mean_gx, float* grad_gamma,
                          float* grad_beta, float* dz, float* gskip);
 hipError_t launch_colsum_acc(hipStream_t st, const float* a, int M, int Fp, int valid, double* part, float* grad);
 hipError_t launch_policy_loss(hipStream_t st, const float* logits, int row_stride, bool conv_head, int nsq, int ch_stride, int P, int B,

@@ -728,14 +728,17 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower_halo(const float* __restr
 // weights stream through a buffer descriptor two chunks ahead, slots come from the same slot table as the tower's.
 // Epilogue: + bias, + res (optional), ReLU (optional).  COT = CoutP / 16; blockIdx.y picks a group of CTW channel tiles.
 // ------------------------------------------------------------------------------------------------
-template <int RTW, int NWAVES, int CH, int NB, int COT>
+// PSC: the position stride of the halo image (tower_halo_geometry) as a constant — the zero-cell fill divides by it 19 000 times
+template <int RTW, int NWAVES, int CH, int NB, int COT, int PSC>
 __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restrict__ in, const float* __restrict__ Wp,
                                                            const float* __restrict__ bias, const float* __restrict__ res,
                                                            float* __restrict__ out, const uint32_t* __restrict__ slotmap, int B, int PW,
-                                                           int PS, int CTW, int out_stride, int cout_valid, int relu) {
+                                                           int PS, int CTW, int out_stride, int cout_valid, int relu,
+                                                           double* __restrict__ stats_part) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     f32x4* lds4 = (f32x4*)lds;
     constexpr int n = NB, nsq = NB * NB, RS = NB + 1, LEAD = NB + 2, F4 = 4 * CH, P4 = 4 * CH + 1;
+    PS = PSC;
     const int tid = threadIdx.x;
     const int pos0 = blockIdx.x * PW;
     const int npos = min(PW, B - pos0);
@@ -804,6 +807,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restri
     }
     const int ch = ch0 + 4 * q;
     const f32x4 bv = *(const f32x4*)&bias[ch];
+    f32x4 s1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, s2 = s1;  // stats_part: Σ and Σ² of this lane's outputs, per channel
 #pragma unroll
     for (int j = 0; j < RTW; j++) {
         if (rowid[j] < rows && ch < cout_valid) {
@@ -813,6 +817,23 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restri
             if (relu) { v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f); }
             if (ch + 3 < cout_valid) *(f32x4*)&out[o] = v;
             else for (int t = 0; t < 4; t++) if (ch + t < cout_valid) out[o + t] = v[t];
+            s1 += v;
+            s2 += v * v;
+        }
+    }
+    if (stats_part) {
+        // BatchNorm's batch statistics from the accumulators (training forward): the column sums of this wave's rows — 16
+        // lanes of a q-group hold 16 rows of the same 4 channels — leave the kernel as doubles, one partial row per (workgroup,
+        // row group): part[((blockIdx.x·NRG + rg)·2 + {Σ, Σ²})·CoutP + channel], k_col_reduce's layout, summed in fixed order later
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1)
+#pragma unroll
+            for (int t = 0; t < 4; t++) { s1[t] += __shfl_xor(s1[t], d); s2[t] += __shfl_xor(s2[t], d); }
+        if (r16 == 0) {
+            const int CoutP = 16 * COT;
+            double* dst = stats_part + ((size_t)(blockIdx.x * NRG + rg) * 2) * CoutP + ch;
+#pragma unroll
+            for (int t = 0; t < 4; t++) { dst[t] = (double)s1[t]; dst[CoutP + t] = (double)s2[t]; }
         }
     }
 }
@@ -1466,35 +1487,41 @@ static const uint32_t* conv_halo_slotmap(int n, int F, int pw, int ps) {
     return d;
 }
 
-template <int RTW, int NWAVES, int CH, int NB, int COT>
+template <int RTW, int NWAVES, int CH, int NB, int COT, int PSC>
 static hipError_t launch_conv_halo_t(hipStream_t st, const float* in, const float* Wp, const float* bias, const float* res, float* out,
-                                     const uint32_t* slotmap, int B, int PW, int PS, int CTW, int out_stride, int cout_valid, bool relu) {
+                                     const uint32_t* slotmap, int B, int PW, int PS, int CTW, int out_stride, int cout_valid, bool relu,
+                                     double* stats_part, int* stats_blocks) {
+    if (PS != PSC) return hipErrorInvalidValue;
     const size_t lds = (size_t)(NB + 2 + PW * PS + 1) * (16 * CH + 4) * sizeof(float);
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_conv_halo<RTW, NWAVES, CH, NB, COT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_conv_halo<RTW, NWAVES, CH, NB, COT, PSC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = true;
     }
     dim3 grid((B + PW - 1) / PW, COT / CTW);
-    hipLaunchKernelGGL((k_conv_halo<RTW, NWAVES, CH, NB, COT>), grid, dim3(NWAVES * 64), lds, st, in, Wp, bias, res, out, slotmap, B, PW, PS,
-                       CTW, out_stride, cout_valid, relu ? 1 : 0);
+    if (grid.y != 1) stats_part = nullptr;  // (statistics only for layers whose channels one workgroup column covers)
+    hipLaunchKernelGGL((k_conv_halo<RTW, NWAVES, CH, NB, COT, PSC>), grid, dim3(NWAVES * 64), lds, st, in, Wp, bias, res, out, slotmap, B, PW, PS,
+                       CTW, out_stride, cout_valid, relu ? 1 : 0, stats_part);
+    if (stats_blocks) *stats_blocks = stats_part ? (int)grid.x * (NWAVES / CTW) : 0;
     return hipGetLastError();
 }
 
 hipError_t launch_conv3x3(hipStream_t st, const float* in, const float* Wp, const float* bias, const float* res, float* out,
-                          int M, int n, int Cpad, int CoutP, int out_stride, int cout_valid, bool relu) {
+                          int M, int n, int Cpad, int CoutP, int out_stride, int cout_valid, bool relu, double* stats_part,
+                          int* stats_blocks) {
     const int B = M / (n * n);
+    if (stats_blocks) *stats_blocks = 0;
     {   // F → F (and F → 2F) layers of the BASELINE topologies at full batches: the halo image (k_conv_halo), same bits as k_conv_pos
         static const bool off = getenv("TG_NO_HALO_CONV") != nullptr;
         int pw, ps;
         if (!off && B >= 1024 && tower_halo_geometry(n, Cpad, &pw, &ps)) {
             const uint32_t* map = conv_halo_slotmap(n, Cpad, pw, ps);
             if (map) {
-                if (n == 5 && Cpad == 64 && CoutP == 64) return launch_conv_halo_t<13, 8, 4, 5, 4>(st, in, Wp, bias, res, out, map, B, pw, ps, 4, out_stride, cout_valid, relu);
-                if (n == 5 && Cpad == 128 && CoutP == 128) return launch_conv_halo_t<13, 8, 8, 5, 8>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu);
-                if (n == 6 && Cpad == 128 && CoutP == 128) return launch_conv_halo_t<9, 8, 8, 6, 8>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu);
-                if (n == 6 && Cpad == 128 && CoutP == 256) return launch_conv_halo_t<9, 8, 8, 6, 16>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu);
+                if (n == 5 && Cpad == 64 && CoutP == 64) return launch_conv_halo_t<13, 8, 4, 5, 4, 36>(st, in, Wp, bias, res, out, map, B, pw, ps, 4, out_stride, cout_valid, relu, stats_part, stats_blocks);
+                if (n == 5 && Cpad == 128 && CoutP == 128) return launch_conv_halo_t<13, 8, 8, 5, 8, 37>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu, stats_part, stats_blocks);
+                if (n == 6 && Cpad == 128 && CoutP == 128) return launch_conv_halo_t<9, 8, 8, 6, 8, 51>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu, stats_part, stats_blocks);
+                if (n == 6 && Cpad == 128 && CoutP == 256) return launch_conv_halo_t<9, 8, 8, 6, 16, 51>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu, stats_part, stats_blocks);
             }
         }
     }

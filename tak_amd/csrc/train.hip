@@ -186,11 +186,20 @@ int forward_train(TgEngine* e, int B, bool with_targets, float* d_logp) {
     const float* in = t->planes.as<float>();
     for (size_t l = 0; l < t->convs.size(); l++) {
         TrainConv& c = t->convs[l];
-        TG_HIP(launch_conv3x3(st, in, c.wf.as<float>(), c.bias_pad.as<float>(), nullptr, c.z.as<float>(), M, N, c.in_stride, c.OP, F, F, false));
+        // the halo kernel (F → F layers at full chunks) hands out BatchNorm's column sums with the convolution; elsewhere two
+        // reduction passes over z follow
+        int stat_blocks = 0;
+        static const bool conv_stats = getenv("TG_NO_CONV_STATS") == nullptr;
+        TG_HIP(launch_conv3x3(st, in, c.wf.as<float>(), c.bias_pad.as<float>(), nullptr, c.z.as<float>(), M, N, c.in_stride, c.OP, F, F, false,
+                              (c.OP == F && conv_stats) ? t->part_d.as<double>() : nullptr, &stat_blocks));
         float* mean = stats + (size_t)c.bn * 2 * F;
         float* invstd = mean + F;
-        TG_HIP(launch_bn_stats(st, c.z.as<float>(), M, F, t->cfg.bn_eps, t->cfg.bn_momentum, t->part_d.as<double>(), mean, invstd,
-                               BN + c.rmean, BN + c.rvar));
+        if (stat_blocks > 0)
+            TG_HIP(launch_bn_stats_from_partials(st, t->part_d.as<double>(), stat_blocks, M, F, t->cfg.bn_eps, t->cfg.bn_momentum, mean, invstd,
+                                                 BN + c.rmean, BN + c.rvar));
+        else
+            TG_HIP(launch_bn_stats(st, c.z.as<float>(), M, F, t->cfg.bn_eps, t->cfg.bn_momentum, t->part_d.as<double>(), mean, invstd,
+                                   BN + c.rmean, BN + c.rvar));
         // conv2 of block i (l = 2, 4, …) adds the block input: y of layer l-2
         const float* skip = (l >= 2 && (l % 2) == 0) ? t->convs[l - 2].y.as<float>() : nullptr;
         TG_HIP(launch_bn_fwd_apply(st, c.z.as<float>(), mean, invstd, P + c.gamma, P + c.beta, skip, c.y.as<float>(), M, F));
@@ -250,8 +259,8 @@ int backward_train(TgEngine* e, int B) {
         float* mean = stats + (size_t)c.bn * 2 * F;
         float* invstd = mean + F;
         const bool block_end = l >= 2 && (l % 2) == 0;  // conv2: its masked gradient also flows into the skip
-        TG_HIP(launch_bn_bwd(st, dcur, c.y.as<float>(), c.z.as<float>(), mean, invstd, P + c.gamma, M, F, part_d, t->mean_g.as<float>(),
-                             t->mean_gx.as<float>(), G + c.gamma, G + c.beta, dz, block_end ? gskip : nullptr));
+        TG_HIP(launch_bn_bwd(st, dcur, c.y.as<float>(), c.z.as<float>(), mean, invstd, P + c.gamma, M, F, part_d, t->mean_g.as<double>(),
+                             t->mean_gx.as<double>(), G + c.gamma, G + c.beta, dz, block_end ? gskip : nullptr));
         const float* x = l == 0 ? t->planes.as<float>() : t->convs[l - 1].y.as<float>();
         TG_HIP(launch_wgrad_conv(st, x, c.in_stride, c.I, dz, F, c.O, B, N, part_w, G + c.w));
         TG_HIP(launch_colsum_acc(st, dz, M, F, F, part_d, G + c.b));
@@ -536,14 +545,15 @@ int tg_train_create(TgEngine* e, const TgTrainConfig* cfg) {
     TG_HIP(t->dz.ensure(M * F * 4));
     TG_HIP(t->gskip.ensure(M * F * 4));
     TG_HIP(t->stats.ensure((size_t)bn * 2 * F * 4));
-    TG_HIP(t->mean_g.ensure((size_t)F * 4));
-    TG_HIP(t->mean_gx.ensure((size_t)F * 4));
+    TG_HIP(t->mean_g.ensure((size_t)F * 8));
+    TG_HIP(t->mean_gx.ensure((size_t)F * 8));
     // double partials: column reductions over up to max(F, logit columns) channels, value weight gradient
     {
         int rpb;
         size_t a = (size_t)col_reduce_blocks((int)M, F, &rpb) * 2 * F;
         if (t->conv_head) a = std::max(a, (size_t)col_reduce_blocks((int)M, t->pol.OP, &rpb) * 2 * t->pol.OP);
         else a = std::max(a, (size_t)32 * 2 * t->NP);
+        a = std::max(a, (size_t)(2 * ((size_t)B + 16)) * 2 * F);  // the conv kernels' partial rows: ≤ 2 per position
         size_t b = (size_t)32 * ((size_t)F * nsq + 1);
         TG_HIP(t->part_d.ensure(std::max(a, b) * 8));
     }

@@ -171,15 +171,33 @@ __global__ __launch_bounds__(256) void k_bn_var_finalize(const double* __restric
     running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * (double)mean[c]);
     running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
 }
+// the same from Σz and Σz² (the conv kernel's epilogue partials, doubles): var = E[z²] − E[z]² in double
+__global__ __launch_bounds__(256) void k_bn_moments_finalize(const double* __restrict__ part, int nblk, int F, int M, float eps, float momentum,
+                                                             float* __restrict__ mean, float* __restrict__ invstd,
+                                                             float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x;
+    const double s1 = part_sum(part, nblk, F, 0, c), s2 = part_sum(part, nblk, F, 1, c);
+    if (threadIdx.x != 0) return;
+    const double mu = s1 / (double)M;
+    double var = s2 / (double)M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+    running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * (double)(float)mu);
+    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+}
 // Σg, Σg·x̂ → grad_beta += , grad_gamma += ; the per-row means used by the apply kernel
-__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const double* __restrict__ part, int nblk, int F, int M, float* __restrict__ mean_g,
-                                                         float* __restrict__ mean_gx, float* __restrict__ grad_gamma,
+// (the two means stay doubles: rounded to f32 they would shift every row's dz of a channel by the same 6e-8-relative amount,
+//  and the weight gradients that sum dz over all M rows would collect M times that — 1.5e-3 at the reference chunk size)
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const double* __restrict__ part, int nblk, int F, int M, double* __restrict__ mean_g,
+                                                         double* __restrict__ mean_gx, float* __restrict__ grad_gamma,
                                                          float* __restrict__ grad_beta) {
     const int c = blockIdx.x;
     double sg = part_sum(part, nblk, F, 0, c), sgx = part_sum(part, nblk, F, 1, c);
     if (threadIdx.x != 0) return;
-    mean_g[c] = (float)(sg / (double)M);
-    mean_gx[c] = (float)(sgx / (double)M);
+    mean_g[c] = sg / (double)M;
+    mean_gx[c] = sgx / (double)M;
     grad_beta[c] += (float)sg;
     grad_gamma[c] += (float)sgx;
 }
@@ -221,20 +239,21 @@ __global__ __launch_bounds__(256) void k_bn_fwd_apply(const float* __restrict__ 
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ y,
                                                       const float* __restrict__ z, const float* __restrict__ mean,
                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                      const float* __restrict__ mean_g, const float* __restrict__ mean_gx,
+                                                      const double* __restrict__ mean_g, const double* __restrict__ mean_gx,
                                                       float* __restrict__ dz, float* __restrict__ gskip, size_t total4, int vpr) {
     size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total4) return;
     int cv = (int)(idx % vpr);
     f32x4 d = ((const f32x4*)dy)[idx], yy = ((const f32x4*)y)[idx], zz = ((const f32x4*)z)[idx];
     f32x4 mu = ((const f32x4*)mean)[cv], is = ((const f32x4*)invstd)[cv], ga = ((const f32x4*)gamma)[cv];
-    f32x4 mg = ((const f32x4*)mean_g)[cv], mgx = ((const f32x4*)mean_gx)[cv];
     f32x4 g, o;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         g[t] = yy[t] > 0.0f ? d[t] : 0.0f;
         float xh = (zz[t] - mu[t]) * is[t];
-        o[t] = ga[t] * is[t] * (g[t] - mg[t] - xh * mgx[t]);
+        // the centring in double (see k_bn_bwd_finalize), the result back in f32
+        const double centred = (double)g[t] - mean_g[4 * cv + t] - (double)xh * mean_gx[4 * cv + t];
+        o[t] = (float)((double)(ga[t] * is[t]) * centred);
     }
     ((f32x4*)dz)[idx] = o;
     if (gskip) ((f32x4*)gskip)[idx] = g;
@@ -750,6 +769,12 @@ hipError_t launch_bn_stats(hipStream_t st, const float* z, int M, int F, float e
                        running_mean, running_var);
     return hipGetLastError();
 }
+hipError_t launch_bn_stats_from_partials(hipStream_t st, const double* part, int nblk, int M, int F, float eps, float momentum,
+                                         float* mean, float* invstd, float* running_mean, float* running_var) {
+    hipLaunchKernelGGL(k_bn_moments_finalize, dim3(F), dim3(256), 0, st, part, nblk, F, M, eps, momentum, mean, invstd, running_mean,
+                       running_var);
+    return hipGetLastError();
+}
 hipError_t launch_bn_fwd_apply(hipStream_t st, const float* z, const float* mean, const float* invstd, const float* gamma,
                                const float* beta, const float* skip, float* y, int M, int F) {
     size_t total4 = (size_t)M * F / 4;
@@ -757,7 +782,7 @@ hipError_t launch_bn_fwd_apply(hipStream_t st, const float* z, const float* mean
     return hipGetLastError();
 }
 hipError_t launch_bn_bwd(hipStream_t st, const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
-                         const float* gamma, int M, int F, double* part, float* mean_g, float* mean_gx, float* grad_gamma,
+                         const float* gamma, int M, int F, double* part, double* mean_g, double* mean_gx, float* grad_gamma,
                          float* grad_beta, float* dz, float* gskip) {
     int rpb, nblk = col_reduce_blocks(M, F, &rpb);
     hipLaunchKernelGGL((k_col_reduce<RED_BNBWD>), dim3(nblk), dim3(256), 0, st, dy, y, z, mean, invstd, M, F, rpb, part);

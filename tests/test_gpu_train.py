@@ -56,6 +56,11 @@ CASES = [
     (6, 2, 64, "conv", 12),
     (4, 1, 32, "conv", 20),
     (5, 2, 128, "fc5", 10),
+    # ≥ 1024 positions per chunk: the full-batch kernels of the training step — k_conv_halo for the F → F convolutions (forward
+    # and data gradient) with BatchNorm's column sums taken from its accumulators, k_wgrad_halo, the ring FC
+    (5, 1, 64, "fc5", 128),
+    (5, 1, 128, "fc5", 128),
+    (6, 1, 128, "conv", 128),
 ]
 
 
@@ -91,9 +96,28 @@ def test_chunk_gradients_vs_autograd(orc, n, blocks, filters, head, count):
     e.train_create(chunk_size=count, chunks_in_step=1000)
     shapes = _shapes(net)
     total_sq = 0.0
+    # Full-batch cases are judged against an fp64 run of the same network, with a bound that allows for ReLU flips: among the
+    # ≈ 10 M pre-activations of a 25 600-row chunk a handful lie within f32 rounding of zero, and ANY f32 implementation may put
+    # one on the other side than the exact arithmetic does.  That changes one row's contribution to the gradients of its layer
+    # and of every layer before it — ≈ |g|/√M per tensor — and it happens to PyTorch's own f32 result as often as to ours
+    # (measured, `scripts/probes/dbg_grad.py`: chunks of 24 and 127 examples: PyTorch-f32 2e-3 from fp64, ours 3e-6; 64 and 128:
+    # the other way round; 40, 41: both 3e-6).  So: within 2e-4 + 3/√M of fp64 — which still catches every wrong product — and
+    # the tight 2e-4 against PyTorch-f32 stays on the small chunks, where flips are rare.  The full-batch kernels are tied to the
+    # small-batch ones bit for bit in test_full_batch_training_kernels_return_identical_bits.
+    import copy
+
+    import torch
+
+    net64 = copy.deepcopy(net).double() if count >= 100 else None
     for rep in range(2):  # gradients accumulate over chunks (network.rs:89-96)
         ex = _examples(orc, n, count, seed=20 + rep)
         planes, pi, z, _ = _targets(orc, n, head, ex)
+        if net64 is not None:
+            net64.train()
+            logp64, v64 = net64.forward_training(torch.from_numpy(planes.astype(np.float64)))
+            loss64 = -(torch.from_numpy(pi.astype(np.float64)) * logp64).sum() / len(planes) + \
+                (torch.from_numpy(np.asarray(z, np.float64))[:, None] - v64).square().sum() / len(planes)
+            loss64.backward()
         lp_ref, lz_ref = torch_ref.train_chunk(net, planes, pi, z)
         lp, lz, stepped = e.train_chunk(*ex)
         assert not stepped
@@ -107,6 +131,11 @@ def test_chunk_gradients_vs_autograd(orc, n, blocks, filters, head, count):
         bias_before_bn = name.endswith(".bias") and "conv" in name and not name.startswith("policy")
         if bias_before_bn:  # true gradient is exactly zero; both sides hold rounding noise
             assert np.abs(g).max() <= 1e-3 * scale * np.sqrt(count * 8 * n * n), name
+        elif net64 is not None:
+            g64 = dict(net64.named_parameters())[[k for k, _ in net.named_parameters() if torch_ref.abi_name(k) == name][0]].grad.numpy()
+            ours = np.linalg.norm(g.astype(np.float64) - g64)
+            rows = 2 * count * 8 * n * n  # two accumulated chunks
+            assert ours <= (2e-4 + 3.0 / np.sqrt(rows)) * nrm + 1e-12, (name, ours, np.linalg.norm(g_ref.astype(np.float64) - g64), nrm)
         else:
             assert err <= 2e-4 * nrm + 1e-12, (name, err, nrm)
         total_sq += err * err
@@ -407,3 +436,49 @@ def test_data_parallel_two_ranks_on_one_gpu(orc):
                 if not (k_.endswith(".bias") and "conv" in k_):
                     assert np.quantile(d, 0.999) <= 0.02 * lr, (k_, float(np.quantile(d, 0.999)))
     c.close()
+
+
+GRAD_DIGEST = r"""
+import hashlib, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+import numpy as np
+import tak_amd, torch_ref
+from oracle import oracle as orc
+import test_gpu_train as T
+n, blocks, filters, head, count = {cfg!r}
+net = torch_ref.make_net(n, blocks, filters, head, seed=3)
+e = T._engine(n, blocks, filters, head)
+e.load_state_dict(torch_ref.abi_tensors(net))
+e.train_create(chunk_size=count, chunks_in_step=1000)
+ex = T._examples(orc, n, count, seed=7)
+lp, lz, _ = e.train_chunk(*ex)
+h = hashlib.sha256(np.float32([lp, lz]).tobytes())
+for name, shape in sorted(T._shapes(net).items()):
+    h.update(e.train_get_grad(name, shape).tobytes())
+print("DIGEST", h.hexdigest())
+"""
+
+
+@pytest.mark.parametrize("cfg", [(5, 1, 128, "fc5", 128), (5, 1, 64, "fc5", 128), (6, 1, 128, "conv", 128)])
+def test_full_batch_training_kernels_return_identical_bits(cfg):
+    """The kernels the training step switches to at ≥ 1024 positions per chunk — k_conv_halo for the F → F convolutions
+    (forward, data gradient), k_wgrad_halo for their weight gradients — perform the same products in the same order as the
+    kernels they replace (k_conv_pos, k_wgrad<true> with the same chunking): losses and every gradient tensor, bit for bit.
+    The switches are read once per process, so each variant runs in its own."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def digest(**env):
+        e = {k: v for k, v in os.environ.items() if not k.startswith("TG_")}
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", GRAD_DIGEST.format(root=root, cfg=cfg)], env=e, check=True, capture_output=True,
+                             text=True, timeout=600).stdout
+        return [l for l in out.splitlines() if l.startswith("DIGEST")][-1].split()[1]
+
+    base = digest(TG_NO_CONV_STATS="1")  # (BatchNorm's sums from the conv accumulators are another summation order: compared by value)
+    assert digest(TG_NO_CONV_STATS="1", TG_NO_HALO_CONV="1") == base
+    assert digest(TG_NO_CONV_STATS="1", TG_NO_HALO_WGRAD="1") == base
+    assert digest(TG_NO_CONV_STATS="1", TG_NO_HALO_CONV="1", TG_NO_HALO_WGRAD="1") == base

@@ -356,7 +356,7 @@ def main():
     ap.add_argument("--train-filters", type=int, default=128)
     ap.add_argument("--train-games", type=int, default=4096, help="concurrent games per GPU that produce the training examples")
     ap.add_argument("--train-example-rollouts", type=int, default=16, help="sims per move while producing the training examples")
-    ap.add_argument("--train-timeout", type=float, default=420.0,
+    ap.add_argument("--train-timeout", type=float, default=300.0,
                     help="N > 1: seconds the C5 phase (first RCCL all-reduce inside libtakgpu) may take before the headline line is printed without it")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="launcher plumbing only, for machines without a GPU: rendezvous, barrier and the max / sum reductions "

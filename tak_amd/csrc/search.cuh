@@ -78,6 +78,10 @@ struct SearchDev {
     int32_t* path_len;   // [G·batch]  (every per-leaf array below has G·batch entries, slot = g·batch + pass)
     uint32_t* path;      // [G·batch][MAX_DEPTH]
     uint8_t* leaf_kind;  // [G·batch] 0 skipped, 1 needs evaluation, 2 terminal (already backed up)
+    uint32_t* leaf_rec;  // [G·batch][2] children block and child count of the expanded leaf (written by the select: the backup
+                         // does not walk path → leaf → children)
+    uint16_t* child_pidx;// [G·batch][EX_MOVES] policy index of every child of the expanded leaf (move_index at expansion time,
+                         // 0xFFFF = unmapped): the backup gathers logits by it instead of re-deriving it from the moves
     uint64_t* leaf_hash; // [G] (TG_EVAL_HASH)
     float* planes;       // [G][nsq][cin_pad] NHWC network input (null when the tower encodes from leaf_state)
     uint8_t* leaf_state; // [G][state bytes] packed leaf positions

@@ -16,7 +16,7 @@ namespace tg {
 struct Search {
     TgSearchConfig cfg;
     SearchDev d;
-    DevBuf hot, cold, root, alloc, chunk_head, chunk_link, chunk_fwd, chunk_used, free_ring, pool_ctl, root_state, alive, generation, path_len, path, leaf_kind, leaf_hash, planes, leaf_state, policy, eval,
+    DevBuf hot, cold, root, alloc, chunk_head, chunk_link, chunk_fwd, chunk_used, free_ring, pool_ctl, root_state, alive, generation, path_len, path, leaf_kind, leaf_rec, child_pidx, leaf_hash, planes, leaf_state, policy, eval,
         ctab, err, counters, op, active, noise, abort;
     DevBuf r_moves, r_visits, r_prior, r_q, r_counts, r_rv, r_rq, s_moves;
     // self-play
@@ -158,6 +158,9 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     TG_HIP(s->path_len.ensure(G * B * 4));
     TG_HIP(s->path.ensure(G * B * MAX_DEPTH * 4));
     TG_HIP(s->leaf_kind.ensure(G * B));
+    TG_HIP(s->leaf_rec.ensure(G * B * 8));
+    TG_HIP(s->child_pidx.ensure(G * B * EX_MOVES * 2));
+    TG_HIP(hipMemsetAsync(s->leaf_rec.p, 0, G * B * 8, e->stream));
     TG_HIP(s->leaf_hash.ensure(G * B * 8));
     TG_HIP(s->op.ensure(G * 4));
     TG_HIP(s->active.ensure(G));
@@ -204,6 +207,7 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     d.pool_ctl = s->pool_ctl.as<unsigned long long>(); d.n_chunks = (uint32_t)n_chunks; d.chunk_shift = chunk_shift;
     d.root_state = s->root_state.as<uint8_t>(); d.alive = s->alive.as<uint8_t>(); d.abort = s->abort.as<uint8_t>(); d.generation = s->generation.as<uint32_t>();
     d.path_len = s->path_len.as<int32_t>(); d.path = s->path.as<uint32_t>(); d.leaf_kind = s->leaf_kind.as<uint8_t>();
+    d.leaf_rec = s->leaf_rec.as<uint32_t>(); d.child_pidx = s->child_pidx.as<uint16_t>();
     d.leaf_hash = s->leaf_hash.as<uint64_t>(); d.planes = s->planes.as<float>(); d.leaf_state = s->leaf_state.as<uint8_t>();
     d.policy = s->policy.as<float>();
     d.eval = s->eval.as<float>(); d.ctab = s->ctab.as<float>(); d.lut5 = e->lut5.as<int16_t>(); d.err = s->err.as<uint32_t>();
@@ -286,6 +290,7 @@ static SearchDev half_view(const SearchDev& d, int g0, int count, size_t state_b
     v.root += g0; v.alloc += 2 * (size_t)g0; v.chunk_head += g0;
     v.root_state += (size_t)g0 * state_bytes; v.alive += g0; v.generation += g0;
     v.path_len += g0; v.path += (size_t)g0 * MAX_DEPTH; v.leaf_kind += g0; v.leaf_hash += g0;
+    v.leaf_rec += 2 * (size_t)g0; v.child_pidx += (size_t)g0 * EX_MOVES; v.abort += g0;  // (dual stream runs with batch 1)
     v.leaf_state += (size_t)g0 * state_bytes; v.policy += (size_t)g0 * d.P; v.eval += g0;
     v.counters += (size_t)g0 * 2;
     v.slot_base += (uint32_t)g0;

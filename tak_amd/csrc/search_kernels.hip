@@ -108,9 +108,19 @@ __device__ inline void update_concrete(NodeHot& h, float reward) {
 // NB: board size as a compile-time constant (5, 6; 0 = read S.n).  With n known the geometry masks fold to immediates and the
 // many divisions by n / n² of move generation, play and the encoder become multiply-shifts instead of ≈ 20-instruction
 // software divisions — the tree kernels are bound by vector issue, so this is time.
+// What the fused kernel loads of the root BEFORE the backup runs (none of it is written by the backup), so that the select does
+// not start with a chain of dependent loads: the root's index, packed state and cold record; `hot_known`: the backup also handed
+// over the root's (visits, virtual) as it left them.
+struct RootPre {
+    bool on = false, hot_known = false;
+    uint32_t root = 0, vis = 0, vv = 0;
+    NodeCold cold;
+    WState state;
+};
+
 template <int NB>
 __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* __restrict__ active, const int g, const int pass,
-                                            uint32_t* path, uint16_t* mvl) {
+                                            uint32_t* path, uint16_t* mvl, const RootPre& pre = RootPre()) {
     const int lane = lane_id();
     // leaf slot of this pass: `batch` virtual rollouts per tree and iteration (Player's batching, player.rs:77-93), pass p
     // writing slot g·batch + p
@@ -121,10 +131,11 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
     }
     const Geom geo = make_geom(NB ? NB : S.n);
     WState s;
-    ws_load(s, S.root_state + (size_t)g * geo.bytes, geo);
+    if (pre.on) s = pre.state;
+    else ws_load(s, S.root_state + (size_t)g * geo.bytes, geo);
     NodeHot* hot = S.hot;
     NodeCold* cold = S.cold;
-    const uint32_t root = uni(S.root[g]);
+    const uint32_t root = pre.on ? pre.root : uni(S.root[g]);
     const uint32_t root_color = s.to_move;
     uint32_t node = root;
     int depth = 0;
@@ -136,11 +147,26 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
     // costs ONE dependent memory round trip (the coalesced hot + cold records of all children).
     uint32_t vis, vv, nres, cbase;
     {
-        NodeHot nh = hot[root];
-        NodeCold nc = cold[root];
-        vis = uni(nh.visits); vv = uni(nh.virt); nres = uni((uint32_t)nc.nres); cbase = uni(nc.child);
+        NodeCold nc = pre.on ? pre.cold : cold[root];
+        nres = uni((uint32_t)nc.nres); cbase = uni(nc.child);
+        if (pre.on && pre.hot_known) { vis = pre.vis; vv = pre.vv; }
+        else { NodeHot nh = hot[root]; vis = uni(nh.visits); vv = uni(nh.virt); }
     }
     TG_TSTAMP(g, 4);  // root state + root record loaded
+    // The records of the first 64 children of the node about to be visited are requested as soon as its children block is
+    // known — for the root here, for every later level right before the move is played on the wave's position — so that the
+    // round trip of the children scan passes under ws_play instead of after it.
+    NodeHot pf_h;
+    NodeCold pf_c;
+    pf_h.prior = 0.0f; pf_h.q = 0.0f; pf_h.visits = 0; pf_h.virt = 0;
+    pf_c.child = 0; pf_c.mv = 0; pf_c.nres = 0;
+    auto prefetch_children = [&]() {
+        if ((vis | vv) != 0u && (nres >> 12) == TG_ONGOING && (uint32_t)lane < (nres & 0xfffu)) {
+            pf_h = hot[cbase + (uint32_t)lane];
+            pf_c = cold[cbase + (uint32_t)lane];
+        }
+    };
+    prefetch_children();
     for (;;) {
         if (vis == 0 && vv == 0) {
             // uninitialised node: initialise it and stop (mcts.rs:41-53)
@@ -175,6 +201,7 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const float temp_policy = 1.0f / (float)count;
+                bool bad = false;
                 for (uint32_t i = lane; i < count; i += 64) {
                     NodeCold cc;
                     cc.child = 0; cc.mv = mvl[i]; cc.nres = 0;
@@ -182,13 +209,22 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
                     NodeHot c;
                     c.prior = temp_policy; c.q = 0.0f; c.visits = 0; c.virt = 0;
                     hot[a + i] = c;
+                    // the child's policy index now, while its move is at hand (move_index, move_map.rs:19-48): the backup of this
+                    // leaf gathers the network's output by it
+                    const int idx = move_index_dev((uint32_t)mvl[i], NB ? NB : S.n, S.legacy5 != 0, S.lut5);
+                    const bool ok = idx >= 0 && idx < S.P;
+                    bad |= !ok;
+                    S.child_pidx[slot * EX_MOVES + i] = ok ? (uint16_t)idx : (uint16_t)0xFFFF;
                 }
+                if (__ballot(bad)) flag(S, ERRF_MOVE);  // "could not map turn to index" (move_map.rs:24)
                 cb = a;
                 if (lane == 0) { S.alloc[2 * g] = a + count; S.alloc[2 * g + 1] = end; }
             }
             if (lane == 0) {
                 cold[node].child = cb;
                 cold[node].nres = (uint16_t)(count | (res << 12));
+                S.leaf_rec[2 * slot] = cb;
+                S.leaf_rec[2 * slot + 1] = count;
             }
             terminal = res != TG_ONGOING;
             TG_TSTAMP(g, 27);  // children created
@@ -219,8 +255,10 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
         bh.prior = 0.0f; bh.q = 0.0f; bh.visits = 0; bh.virt = 0;
         bc.child = 0; bc.mv = 0; bc.nres = 0;
         for (uint32_t i = lane; i < nchild; i += 64) {
-            NodeHot ch = hot[cbase + i];
-            NodeCold cc = cold[cbase + i];
+            NodeHot ch;
+            NodeCold cc;
+            if (i == (uint32_t)lane) { ch = pf_h; cc = pf_c; }  // the first 64 children were requested a level ago
+            else { ch = hot[cbase + i]; cc = cold[cbase + i]; }
             float cn = (float)(ch.visits + ch.virt);
             float qv = (ch.visits | ch.virt) ? (ch.q * (float)ch.visits - (float)ch.virt) / cn : 0.0f;
             float u = qv + c_rate * ch.prior * (root_n / (1.0f + cn));
@@ -250,6 +288,7 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
         nres = uni((uint32_t)__shfl((int)(uint32_t)bc.nres, src));
         cbase = uni((uint32_t)__shfl((int)bc.child, src));
         TG_TSTAMP(g, 5 + 2 * (depth < 9 ? depth : 9));  // children scanned, best child known
+        prefetch_children();  // of the chosen child, under the play of its move
         ws_play(s, mv, geo);
         TG_TSTAMP(g, 6 + 2 * (depth < 9 ? depth : 9));  // move played
         if (depth >= MAX_DEPTH) {
@@ -323,50 +362,64 @@ __global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __re
 // devirtualize_path, mcts.rs:67-91: real priors for the leaf's children, value backed up with
 // alternating sign, virtual visits removed.
 // ------------------------------------------------------------------------------------------------
+// Every load that does not depend on another load is issued first (leaf kind, path length, the leaf's children block and their
+// policy indices — both recorded by the select that expanded it —, the FC's softmax statistics, the value logit, this lane's
+// path entry); the second round is the gather of the children's logits and the path nodes' records; then the stores.  Round 2
+// walked path → leaf → children's moves → index table → logits, five dependent round trips (19 k of the wave's 56 k cycles).
+// Returns through `pre` the root's (visits, virtual) as this backup leaves them, for the select that follows in the same launch.
 template <int NB>
-__device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, const int pass) {
+__device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, const int pass, const uint32_t root, RootPre* pre = nullptr) {
     const size_t slot = (size_t)g * (size_t)S.batch + (size_t)pass;
-    if (S.leaf_kind[slot] != 1) return;
     const int lane = lane_id();
     NodeHot* hot = S.hot;
-    NodeCold* cold = S.cold;
-    const uint32_t root = uni(S.root[g]);
     const uint32_t* path = S.path + slot * MAX_DEPTH;
-    const int L = S.path_len[slot];
-    const uint32_t leaf = L ? path[L - 1] : root;
-    NodeCold lc = cold[leaf];
-    const uint32_t nchild = uni((uint32_t)lc.nres) & 0xfffu, cb = uni(lc.child);
+    const float* lrow = S.logits ? S.logits + slot * (size_t)S.logit_ld : nullptr;
+    const float* pol = S.policy + slot * S.P;
+    const uint16_t* pidx = S.child_pidx + slot * EX_MOVES;
+    // round 1 — every load whose address does not come out of another load, requested back to back and unconditionally (all
+    // addresses are valid whatever the slot holds; the wave-uniform values are made scalar only after the last request): the
+    // leaf's kind, path length and children block, this lane's child index and path entry, the statistics, the value logit
+    const uint32_t kind_v = (uint32_t)S.leaf_kind[slot];
+    const uint32_t len_v = (uint32_t)S.path_len[slot];
+    const uint32_t cb_v = S.leaf_rec[2 * slot], n_v = S.leaf_rec[2 * slot + 1];
+    const uint32_t raw_idx = (uint32_t)pidx[lane];
+    const uint32_t raw_nd = path[lane ? lane - 1 : 0];
+    const float vlogit_v = (S.evaluator == TG_EVAL_RESNET && lrow) ? lrow[S.P] : 0.0f;
+    const bool live = uni(kind_v) == 1u;
+    const int L = (int)uni(len_v);
+    const uint32_t cb = uni(cb_v), nchild = uni(n_v);
     float e;
     uint64_t hsh = 0;
-    // FC head: softmax statistics and tanh from the logits row, in k_softmax's order (the probabilities of the ≈ 45 children are
-    // all that is needed — the other 1530 never get written or read)
-    const float* lrow = S.logits ? S.logits + slot * (size_t)S.logit_ld : nullptr;
     float lmx = 0.0f, linv = 0.0f;
     if (S.evaluator == TG_EVAL_RESNET && lrow) {
+        const float vlogit = vlogit_v;
         if (S.fc_stats)  // 64 B (wave-uniform address: scalar loads) instead of the whole row
             fc_combine_stats(S.fc_stats + (size_t)uni((uint32_t)slot) * (size_t)S.fc_blocks * 2, S.fc_blocks, lmx, linv);
-        else softmax_stats_wave(lrow, S.P, lmx, linv);
-        e = tanhf(lrow[S.P]);
+        else if (live) softmax_stats_wave(lrow, S.P, lmx, linv);
+        e = tanhf(vlogit);
     } else if (S.evaluator == TG_EVAL_RESNET) e = S.eval[slot];
     else if (S.evaluator == TG_EVAL_HASH) { hsh = S.leaf_hash[slot]; e = hash_eval(hsh); }
     else e = 0.0f;
-    const float* pol = S.policy + slot * S.P;
+    if (!live) return;  // (terminal leaf: backed up concretely by the select; skipped game)
+    const uint32_t my_idx = (uint32_t)lane < nchild ? raw_idx : 0xFFFFu;
+    const uint32_t my_nd = lane == 0 ? root : raw_nd;
+    TG_TSTAMP(g, 1);  // independent loads done
+    // round 2: priors of the leaf's children (devirtualize_path, mcts.rs:80-84)
     bool bad = false;
-    TG_TSTAMP(g, 1);  // leaf record + softmax statistics done
     for (uint32_t i = lane; i < nchild; i += 64) {
-        uint32_t mv = cold[cb + i].mv;
-        int idx = move_index_dev(mv, NB ? NB : S.n, S.legacy5 != 0, S.lut5);
+        const uint32_t idx = i == (uint32_t)lane ? my_idx : (uint32_t)pidx[i];
         float p;
-        if (idx < 0 || idx >= S.P) { bad = true; p = 0.0f; }
+        if (idx == 0xFFFFu) { bad = true; p = 0.0f; }
         else if (S.evaluator == TG_EVAL_RESNET) p = !lrow ? pol[idx] : S.fc_stats ? stat_exp(lrow[idx] - lmx) * linv : expf(lrow[idx] - lmx) * linv;
-        else if (S.evaluator == TG_EVAL_HASH) p = hash_policy(hsh, (uint32_t)idx);
+        else if (S.evaluator == TG_EVAL_HASH) p = hash_policy(hsh, idx);
         else p = 1.0f;
         hot[cb + i].prior = p;
     }
     if (__ballot(bad)) flag(S, ERRF_MOVE);
     TG_TSTAMP(g, 2);  // priors written
+    uint32_t rv = 0, rvv = 0;
     for (int d = lane; d <= L; d += 64) {
-        uint32_t nd = d == 0 ? root : path[d - 1];
+        uint32_t nd = d == lane ? my_nd : path[d - 1];
         NodeHot h = hot[nd];
         h.virt -= 1;
         float ev = ((L - d) & 1) ? e : -e;  // the leaf sees -eval, its parent +eval, …
@@ -376,6 +429,12 @@ __device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, con
         hot[nd].q = h.q;
         hot[nd].visits = h.visits;
         hot[nd].virt = h.virt;
+        if (d == 0) { rv = h.visits; rvv = h.virt; }
+    }
+    if (pre) {  // lane 0 handled the root (d = 0)
+        pre->vis = uni(rv);
+        pre->vv = uni(rvv);
+        pre->hot_known = true;
     }
 }
 
@@ -386,7 +445,7 @@ __global__ __launch_bounds__(256) void k_backup(SearchDev S) {
     if (g >= S.G) return;
     const int p0 = S.pass < 0 ? 0 : S.pass, p1 = S.pass < 0 ? S.batch : S.pass + 1;
     for (int p = p0; p < p1; p++) {
-        backup_pass<NB>(S, g, p);
+        backup_pass<NB>(S, g, p, uni(S.root[g]));
         if (p + 1 < p1) wave_sync_mem();
     }
 }
@@ -401,10 +460,18 @@ __global__ __launch_bounds__(256) void k_backup_select(SearchDev S) {
     const int g = game_of_wave();
     if (g >= S.G) return;
     TG_TSTAMP(g, 0);
-    backup_pass<NB>(S, g, 0);
+    // what the select needs of the root and the backup does not write is requested before the backup: the root's index, its
+    // cold record and the packed root position arrive under the backup's own round trips
+    RootPre pre;
+    pre.root = uni(S.root[g]);
+    const Geom geo = make_geom(NB ? NB : S.n);
+    ws_load(pre.state, S.root_state + (size_t)g * geo.bytes, geo);
+    pre.cold = S.cold[pre.root];
+    pre.on = true;
+    backup_pass<NB>(S, g, 0, pre.root, &pre);
     wave_sync_mem();
     TG_TSTAMP(g, 3);  // path updated
-    select_pass<NB>(S, nullptr, g, 0, path_lds[threadIdx.x >> 6], mv_lds[threadIdx.x >> 6]);
+    select_pass<NB>(S, nullptr, g, 0, path_lds[threadIdx.x >> 6], mv_lds[threadIdx.x >> 6], pre);
     TG_TSTAMP(g, 31);
 }
 

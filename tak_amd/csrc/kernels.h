@@ -122,7 +122,7 @@ hipError_t launch_bn_fwd_apply(hipStream_t st, const float* z, const float* mean
                                const float* beta, const float* skip, float* y, int M, int F);
 hipError_t launch_bn_bwd(hipStream_t st, const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
                          const float* gamma, int M, int F, double* part, double* mean_g, double* mean_gx, float* grad_gamma,
-                         float* grad_beta, float* dz, float* gskip);
+                         float* grad_beta, float* dz, float* gskip, float* grad_conv_bias = nullptr);  // grad_conv_bias += column sums of dz
 hipError_t launch_colsum_acc(hipStream_t st, const float* a, int M, int Fp, int valid, double* part, float* grad);
 hipError_t launch_policy_loss(hipStream_t st, const float* logits, int row_stride, bool conv_head, int nsq, int ch_stride, int P, int B,
                               const float* pi, float inv_b, float* dlogits, float* logp_out, float* loss_rows);

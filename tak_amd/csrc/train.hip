@@ -260,10 +260,9 @@ int backward_train(TgEngine* e, int B) {
         float* invstd = mean + F;
         const bool block_end = l >= 2 && (l % 2) == 0;  // conv2: its masked gradient also flows into the skip
         TG_HIP(launch_bn_bwd(st, dcur, c.y.as<float>(), c.z.as<float>(), mean, invstd, P + c.gamma, M, F, part_d, t->mean_g.as<double>(),
-                             t->mean_gx.as<double>(), G + c.gamma, G + c.beta, dz, block_end ? gskip : nullptr));
+                             t->mean_gx.as<double>(), G + c.gamma, G + c.beta, dz, block_end ? gskip : nullptr, G + c.b));
         const float* x = l == 0 ? t->planes.as<float>() : t->convs[l - 1].y.as<float>();
         TG_HIP(launch_wgrad_conv(st, x, c.in_stride, c.I, dz, F, c.O, B, N, part_w, G + c.w));
-        TG_HIP(launch_colsum_acc(st, dz, M, F, F, part_d, G + c.b));
         if (l == 0) break;
         // conv1 (odd l) closes the block: its data gradient joins the gradient that went through the skip
         const bool block_begin = (l % 2) == 1;

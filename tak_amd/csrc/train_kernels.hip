@@ -259,6 +259,58 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     if (gskip) ((f32x4*)gskip)[idx] = g;
 }
 
+// k_bn_bwd_apply with the column sums of dz — the gradient of the bias of the convolution in front of the BatchNorm — taken while
+// dz is in registers, in k_col_reduce<RED_SUM>'s thread mapping and order (so the sums are the bits a separate pass over dz gave):
+// one pass over [M][F] and two launches less per layer.
+__global__ __launch_bounds__(256) void k_bn_bwd_apply_sum(const float* __restrict__ dy, const float* __restrict__ y,
+                                                          const float* __restrict__ z, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                          const double* __restrict__ mean_g, const double* __restrict__ mean_gx,
+                                                          float* __restrict__ dz, float* __restrict__ gskip, int M, int F, int rows_per_block,
+                                                          double* __restrict__ part) {
+    __shared__ double red[256][4];
+    const int tid = threadIdx.x;
+    const int vpr = F >> 2;
+    const int lanes_r = 256 / vpr;
+    const int cv = tid % vpr, rl = tid / vpr;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    const f32x4 mu = ((const f32x4*)mean)[cv], is = ((const f32x4*)invstd)[cv], ga = ((const f32x4*)gamma)[cv];
+    double mg[4], mgx[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) { mg[t] = mean_g[4 * cv + t]; mgx[t] = mean_gx[4 * cv + t]; }
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
+    if (rl < lanes_r) {
+        for (int r = r0 + rl; r < r1; r += lanes_r) {
+            const size_t idx = (size_t)r * vpr + cv;
+            const f32x4 d = ((const f32x4*)dy)[idx], yy = ((const f32x4*)y)[idx], zz = ((const f32x4*)z)[idx];
+            f32x4 g, o;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                g[t] = yy[t] > 0.0f ? d[t] : 0.0f;
+                const float xh = (zz[t] - mu[t]) * is[t];
+                const double centred = (double)g[t] - mg[t] - (double)xh * mgx[t];
+                o[t] = (float)((double)(ga[t] * is[t]) * centred);
+            }
+            ((f32x4*)dz)[idx] = o;
+            if (gskip) ((f32x4*)gskip)[idx] = g;
+            s1 += o;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) red[tid][t] = (double)s1[t];
+    __syncthreads();
+    if (tid < vpr) {
+        double acc[4] = {0, 0, 0, 0};
+        for (int l = 0; l < lanes_r; l++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) acc[t] += red[l * vpr + tid][t];
+        double* dst = part + ((size_t)blockIdx.x * 2) * F + tid * 4;
+#pragma unroll
+        for (int t = 0; t < 4; t++) dst[t] = acc[t];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Heads: losses of network.rs:81-84 and their gradients
 // ------------------------------------------------------------------------------------------------
@@ -655,10 +707,14 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_halo(const float* __restrict__
 // conv: grad[(co·I + ci)·9 + tap] += Σ_split part[…]
 __global__ __launch_bounds__(256) void k_wgrad_reduce_conv(const float* __restrict__ part, int splits, int ncib, int ncob, int O,
                                                            int I, float* __restrict__ grad) {
-    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // a thread sums four consecutive input channels (one 16-byte load per split, four splits in flight): the partials are a
+    // 70 MB stream, and one dword per thread and split left the loop waiting on latency (36 µs per layer); the splits are
+    // still added one after the other, in split order, per element
+    size_t idx4 = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int ntiles = ncib * ncob;
-    size_t total = (size_t)ntiles * 9 * 4096;
-    if (idx >= total) return;
+    const size_t total = (size_t)ntiles * 9 * 4096, total4 = total >> 2;
+    if (idx4 >= total4) return;
+    const size_t idx = idx4 << 2;
     int ci_l = (int)(idx & 63), co_l = (int)((idx >> 6) & 63);
     size_t t = idx >> 12;
     int tap = (int)(t % 9);
@@ -666,9 +722,17 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_conv(const float* __restri
     int cib = tile / ncob, cob = tile - cib * ncob;
     int co = cob * 64 + co_l, ci = cib * 64 + ci_l;
     if (co >= O || ci >= I) return;
-    float s = 0.0f;
-    for (int sp = 0; sp < splits; sp++) s += part[(size_t)sp * total + idx];
-    grad[((size_t)co * I + ci) * 9 + tap] += s;
+    const f32x4* p4 = (const f32x4*)part + idx4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int sp = 0;
+    for (; sp + 4 <= splits; sp += 4) {
+        const f32x4 a = p4[(size_t)sp * total4], b = p4[(size_t)(sp + 1) * total4], c = p4[(size_t)(sp + 2) * total4], d = p4[(size_t)(sp + 3) * total4];
+        s += a; s += b; s += c; s += d;
+    }
+    for (; sp < splits; sp++) s += p4[(size_t)sp * total4];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+        if (ci + u < I) grad[((size_t)co * I + ci + u) * 9 + tap] += s[u];
 }
 // policy FC: grad[p·K + c·nsq + sq] += Σ_split part[…],  k = (4·cit + w)·64 + ci_l = sq·F + c
 __global__ __launch_bounds__(256) void k_wgrad_reduce_fc(const float* __restrict__ part, int splits, int ncit, int ncob, int P, int F,
@@ -783,10 +847,16 @@ hipError_t launch_bn_fwd_apply(hipStream_t st, const float* z, const float* mean
 }
 hipError_t launch_bn_bwd(hipStream_t st, const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
                          const float* gamma, int M, int F, double* part, double* mean_g, double* mean_gx, float* grad_gamma,
-                         float* grad_beta, float* dz, float* gskip) {
+                         float* grad_beta, float* dz, float* gskip, float* grad_conv_bias) {
     int rpb, nblk = col_reduce_blocks(M, F, &rpb);
     hipLaunchKernelGGL((k_col_reduce<RED_BNBWD>), dim3(nblk), dim3(256), 0, st, dy, y, z, mean, invstd, M, F, rpb, part);
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(F), dim3(256), 0, st, part, nblk, F, M, mean_g, mean_gx, grad_gamma, grad_beta);
+    if (grad_conv_bias) {  // dz and its column sums in one pass (the bias gradient of the convolution in front)
+        hipLaunchKernelGGL(k_bn_bwd_apply_sum, dim3(nblk), dim3(256), 0, st, dy, y, z, mean, invstd, gamma, mean_g, mean_gx, dz, gskip, M, F,
+                           rpb, part);
+        hipLaunchKernelGGL(k_colsum_finalize, dim3(F), dim3(256), 0, st, part, nblk, F, F, grad_conv_bias);
+        return hipGetLastError();
+    }
     size_t total4 = (size_t)M * F / 4;
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(blocks_for(total4)), dim3(256), 0, st, dy, y, z, mean, invstd, gamma, mean_g, mean_gx, dz,
                        gskip, total4, F / 4);
@@ -872,7 +942,7 @@ hipError_t launch_wgrad_conv(hipStream_t st, const float* X, int xs, int I, cons
         hipLaunchKernelGGL((k_wgrad<true, 7>), dim3(splits, ncib * ncob), dim3(256), lds, st, X, xs, xvalid, G, gs, gvalid, B * nsq, n, nsq,
                            rows_chunk, cps, ncob, part);
     size_t total = (size_t)ncib * ncob * 9 * 4096;
-    hipLaunchKernelGGL(k_wgrad_reduce_conv, dim3(blocks_for(total)), dim3(256), 0, st, part, splits, ncib, ncob, O, I, grad);
+    hipLaunchKernelGGL(k_wgrad_reduce_conv, dim3(blocks_for(total / 4)), dim3(256), 0, st, part, splits, ncib, ncob, O, I, grad);
     return hipGetLastError();
 }
 static void wgrad_plan_fc(int B, int* cps, int* splits) {

@@ -26,6 +26,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
 #include <vector>
 
 #include "board.cuh"
@@ -1475,6 +1476,8 @@ static hipError_t launch_conv_pos_t(hipStream_t st, const float* in, const float
 static const uint32_t* conv_halo_slotmap(int n, int F, int pw, int ps) {
     struct Entry { int dev, n, F; uint32_t* d; };
     static std::vector<Entry> cache;
+    static std::mutex guard;  // trainers of several engines may run on several host threads (data-parallel tests)
+    std::lock_guard<std::mutex> lock(guard);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     for (const Entry& e : cache) if (e.dev == dev && e.n == n && e.F == F) return e.d;

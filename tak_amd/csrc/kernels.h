@@ -81,6 +81,11 @@ struct TowerS3Params {
     // halo image (k_tower_s3_halo): tile slot → cell | row << 16 for this topology's workgroup, position stride in cells
     const uint32_t* slotmap;
     int halo_ps;
+    // constant input planes as a per-position bias (states entry; see TowerParams.cb): layer 0 over one 32-channel chunk of
+    // board planes (w0_board: split fragments with KC = 1) + PB from the f32 table cplane_sums
+    int cb;
+    const void* w0_board;
+    const float* cplane_sums;
 };
 // positions per workgroup and position stride of the split tower's halo image
 bool tower_s3_halo_geometry(int n, int F, int* pw, int* ps);

@@ -47,6 +47,7 @@ struct Net {
     bool s3 = false;                   // split-bf16 tower in use
     TowerS3Params tower_s3;
     std::vector<DevBuf> s3_w;
+    DevBuf s3_w0_board;    // conv0 over the board planes only, split fragments with one 32-channel chunk (TowerS3Params.cb)
     DevBuf s3_head;        // conv policy head weights, split (computed inside k_tower_s3)
     bool s3_head_on = false;
     DevBuf s3_fc, s3_fc_b; // policy FC weights (split) and bias padded to s3_np
@@ -380,6 +381,20 @@ int net_finalize(TgEngine* e) {
             TG_HIP(upload_conv_s3(g, F, F, F / 32, n->s3_w[2 + 2 * i]));
             T.w[1 + 2 * i] = n->s3_w[1 + 2 * i].p; T.b[1 + 2 * i] = n->res1[i].b.as<float>();
             T.w[2 + 2 * i] = n->s3_w[2 + 2 * i].p; T.b[2 + 2 * i] = n->res2[i].b.as<float>();
+        }
+        // constant planes as a bias on the split towers too: the f32 table S of the exact path, conv0 restricted to the board planes
+        T.cb = 0; T.w0_board = nullptr; T.cplane_sums = nullptr;
+        if (n->fused && n->tower.cb) {
+            const int bc = board_channels(e->g.n);
+            Folded fb, g0;
+            if (!fold_conv_bn(n, "conv0", "bn0", F, n->cin, g0, err)) return fail(TG_ERR_WEIGHTS, err);
+            fb.b = g0.b;
+            fb.w.resize((size_t)F * bc * 9);
+            for (int o = 0; o < F; o++)
+                for (int c = 0; c < bc; c++)
+                    for (int tap = 0; tap < 9; tap++) fb.w[((size_t)o * bc + c) * 9 + tap] = g0.w[((size_t)o * n->cin + c) * 9 + tap];
+            TG_HIP(upload_conv_s3(fb, F, bc, 1, n->s3_w0_board));
+            T.cb = 1; T.w0_board = n->s3_w0_board.p; T.cplane_sums = n->cplane_sums.as<float>();
         }
         T.slotmap = nullptr; T.halo_ps = 0;
         int pw3, ps3;

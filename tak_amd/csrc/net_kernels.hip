@@ -32,6 +32,7 @@
 #include "board.cuh"
 #include "conv_mainloop.cuh"
 #include "softmax.cuh"
+#include "tower_cb.cuh"
 #include "kernels.h"
 
 namespace tg {
@@ -304,24 +305,15 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_pos(const float* __restric
 // tiles it produces).  Only the input planes are read from HBM and only the final activations are
 // written (for the policy / value heads); per layer the only global traffic is the L2-resident weights.
 // ------------------------------------------------------------------------------------------------
-// ---- constant input planes as a per-position bias (TowerParams.cb; states entry of the fused towers) ----
+// ---- constant input planes as a per-position bias (TowerParams.cb; states entry of the fused towers; tower_cb.cuh) ----
 // Stages what layer 0 needs for the positions of one workgroup: the 26 / 28 BOARD planes of every square as a plain image of
-// 32 channels per row (last chunk permuted for cb_last_t = 3), and the table PB[position][border class][F] =
-// bias + Σ_{constant planes that are set} S[plane][class] + fcd · S[fcd plane][class] — summed in exactly this order by
-// every kernel that uses it, so a position's result does not depend on the kernel (batch size) that evaluates it.
-// class = 3·(y = 0 ? 0 : y = n − 1 ? 2 : 1) + (x = 0 ? 0 : x = n − 1 ? 2 : 1): which of the 9 taps stay on the board.
+// 32 channels per row (last chunk permuted for cb_last_t = 3), and the table PB[position][border class][F].
 template <int NWAVES>
 __device__ __forceinline__ void tower_stage_states_cb(f32x4* lds4, f32x4* pb4, const uint8_t* states, int pos0, int npos, int n,
                                                       int LS4, const TowerParams& T) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const Geom geo = make_geom(n);
     const int nsq = n * n;
-    const int bc = board_channels(n);
-    int st0, cp0;
-    starting_stones(n, st0, cp0);
-    const int F4 = T.F >> 2;
-    const f32x4* S4 = (const f32x4*)T.cplane_sums;
-    const f32x4* B4 = (const f32x4*)T.b[0];
     for (int p = wave; p < npos; p += NWAVES) {  // one wave per position at a time, lane = square
         WState ws;
         ws_load(ws, states + (size_t)(pos0 + p) * geo.bytes, geo);
@@ -329,46 +321,15 @@ __device__ __forceinline__ void tower_stage_states_cb(f32x4* lds4, f32x4* pb4, c
         const RowMask m = ws_row_mask(ws, geo);
         if (lane < nsq) {
             f32x4* row = lds4 + (size_t)(p * nsq + lane) * LS4;
-            const uint32_t bits = m.w[0] & ((1u << bc) - 1u);  // the board planes of this square (bc ≤ 28)
             f32x4 qd[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const uint32_t nib = (bits >> (4 * k)) & 15u;
-                qd[k] = f32x4{(nib & 1u) ? 1.0f : 0.0f, (nib & 2u) ? 1.0f : 0.0f, (nib & 4u) ? 1.0f : 0.0f, (nib & 8u) ? 1.0f : 0.0f};
-            }
+            tower_cb_board_quads(m, n, qd);
 #pragma unroll
             for (int k = 0; k < 4; k++) row[k] = qd[k];
             const f32x4 lc[4] = {qd[4], qd[5], qd[6], qd[7]};
             conv_last_chunk_store(row + 4, lc, T.cb_last_t);
         }
-        // the constant planes that are set (ws_row_mask's rules), as indices into S
-        const bool w = ws.to_move == 0;
-        const int my_st = w ? ws.ws : ws.bs, en_st = w ? ws.bs : ws.ws, my_cp = w ? ws.wc : ws.bc, en_cp = w ? ws.bc : ws.wc;
-        int pl[5];
-        pl[0] = (my_st > 0 && my_st <= st0) ? my_st - 1 : -1;
-        pl[1] = (en_st > 0 && en_st <= st0) ? st0 + en_st - 1 : -1;
-        pl[2] = (my_cp > 0 && my_cp <= cp0) ? 2 * st0 + my_cp - 1 : -1;
-        pl[3] = (en_cp > 0 && en_cp <= cp0) ? 2 * st0 + cp0 + en_cp - 1 : -1;
-        pl[4] = w ? 2 * st0 + 2 * cp0 : -1;
-        const int fplane = 2 * st0 + 2 * cp0 + 1;
-        for (int idx = lane; idx < 9 * F4; idx += 64) {  // idx = class·F/4 + channel quad
-            const int cls = idx / F4;
-            f32x4 v = B4[idx - cls * F4];
-#pragma unroll
-            for (int k = 0; k < 5; k++)
-                if (pl[k] >= 0) v += S4[(size_t)pl[k] * 9 * F4 + idx];
-            const f32x4 sf = S4[(size_t)fplane * 9 * F4 + idx];
-            v += f32x4{fcd * sf[0], fcd * sf[1], fcd * sf[2], fcd * sf[3]};
-            pb4[(size_t)p * 9 * F4 + idx] = v;
-        }
+        tower_cb_table(ws, fcd, n, p, T.F >> 2, (const f32x4*)T.cplane_sums, (const f32x4*)T.b[0], pb4);
     }
-}
-// index (in f32x4) of a row's entry of PB for this lane's 4 output channels
-__device__ __forceinline__ int tower_cb_index(int rho, int rows, int n, int nsq, int F4, int ch0, int q) {
-    if (rho >= rows) return (ch0 >> 2) + q;
-    const int p = rho / nsq, sq = rho - p * nsq, y = sq / n, x = sq - y * n;
-    const int cls = (y == 0 ? 0 : y == n - 1 ? 2 : 1) * 3 + (x == 0 ? 0 : x == n - 1 ? 2 : 1);
-    return (p * 9 + cls) * F4 + (ch0 >> 2) + q;
 }
 
 // FROM_STATES: `in` points at packed game states and the planes are encoded straight into the LDS image
@@ -481,7 +442,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
         const f32x4 bv = *(const f32x4*)&T.b[layer][ch0 + 4 * q];
 #pragma unroll
         for (int j = 0; j < RTW; j++) {
-            f32x4 v = acc[j] + ((CB && layer == 0) ? pb4[tower_cb_index(rho0 + j * 16, rows, n, nsq, F >> 2, ch0, q)] : bv);
+            f32x4 v = acc[j] + ((CB && layer == 0) ? pb4[tower_cb_index(rho0 + j * 16, rows, n, nsq, F >> 2, (ch0 >> 2) + q)] : bv);
             v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f);
             acc[j] = v;
         }
@@ -633,7 +594,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower_halo(const float* __restr
         const f32x4 bv = *(const f32x4*)&T.b[0][ch0 + 4 * q];
 #pragma unroll
         for (int j = 0; j < RTW; j++) {
-            f32x4 v = acc[j] + (CB ? pb4[tower_cb_index(rho0 + j * 16, rows, n, nsq, F >> 2, ch0, q)] : bv);
+            f32x4 v = acc[j] + (CB ? pb4[tower_cb_index(rho0 + j * 16, rows, n, nsq, F >> 2, (ch0 >> 2) + q)] : bv);
             v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f);
             acc[j] = v;
         }

@@ -28,6 +28,7 @@
 
 #include "board.cuh"
 #include "conv_mainloop.cuh"
+#include "tower_cb.cuh"
 #include "kernels.h"
 
 #ifndef FC_PROBE
@@ -263,9 +264,11 @@ __device__ __forceinline__ void s3_mainloop_halo(const u32x4* __restrict__ lds4,
 // RTW: row tiles of a full row group; NRG row groups × NCG channel groups (of 2 tiles) = NW waves.  With NW = 4 two
 // workgroups share a CU (one wave of each per SIMD): they drift apart, so one's epilogue / barrier phases overlap the other's MFMAs.
 // (the second launch bound caps the 4-wave variant at 256 registers so that two of its workgroups fit on a CU)
-template <int RTW, int KC0, int KC, bool FROM_STATES, bool OUT_SPLIT, int NW>
+// CB (with FROM_STATES, KC0 = 1): layer 0 over the board planes only, the constant planes as the per-position bias PB (tower_cb.cuh)
+template <int RTW, int KC0, int KC, bool FROM_STATES, bool OUT_SPLIT, int NW, bool CB = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3(const void* __restrict__ in, TowerS3Params T, float* __restrict__ out, int B, int n,
                                                   int PW, int NCG, int pad0) {
+    static_assert(!CB || (FROM_STATES && KC0 == 1), "the constant-plane bias needs the packed states and one chunk of board planes");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     u32x4* lds4 = (u32x4*)lds;
     const int tid = threadIdx.x;
@@ -282,7 +285,32 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3(const voi
     // ---- stage the input: CP0 = 32·KC0 channels per row, hi/lo split ----
     constexpr int CP0 = 32 * KC0;
     int LS4 = (CP0 >> 2) + pad0;  // pad0 = 2 (conflict free) when the input image fits, else 1
-    if (FROM_STATES) {
+    // CB: PB[position][class][F] (f32) behind the image and its zero region
+    f32x4* pb4 = (f32x4*)(lds4 + (size_t)(((PW * nsq + n + 1 + 15) & ~15) + 16 + n + 1) * LS4);
+    if (CB) {
+        const Geom geo = make_geom(n);
+        const uint8_t* states = (const uint8_t*)in;
+        for (int p = wave; p < npos; p += NW) {
+            WState ws;
+            ws_load(ws, states + (size_t)(pos0 + p) * geo.bytes, geo);
+            const float fcd = fcd_value(ws, geo);
+            const RowMask m = ws_row_mask(ws, geo);
+            if (lane < nsq) {
+                u32x4* row = lds4 + (size_t)(p * nsq + lane) * LS4;
+                f32x4 qd[8];
+                tower_cb_board_quads(m, n, qd);
+#pragma unroll
+                for (int g8 = 0; g8 < 4; g8++) {  // 0 / 1 values: the lo halves are zero
+                    u32x2 h0, l0, h1, l1;
+                    split4(qd[2 * g8], h0, l0);
+                    split4(qd[2 * g8 + 1], h1, l1);
+                    row[g8] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+                    row[4 + g8] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+                }
+            }
+            tower_cb_table(ws, fcd, n, p, T.F >> 2, (const f32x4*)T.cplane_sums, (const f32x4*)T.b[0], pb4);
+        }
+    } else if (FROM_STATES) {
         const Geom geo = make_geom(n);
         const uint8_t* states = (const uint8_t*)in;
         const int C = input_channels(n);
@@ -344,7 +372,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3(const voi
     for (int layer = 0; layer < T.nlayers; layer++) {
         // this lane's weight slots: [chunk][channel tile][hi|lo][q][cout in tile] in 16-byte units — a fragment load is one
         // contiguous KB per wave
-        const u32x4* wp = (const u32x4*)T.w[layer] + (size_t)(ch0 >> 4) * 128 + q * 16 + r16;
+        const u32x4* wp = (const u32x4*)(CB && layer == 0 ? T.w0_board : T.w[layer]) + (size_t)(ch0 >> 4) * 128 + q * 16 + r16;
         const int t1 = 128, wstride = (F >> 4) * 128;
         const bool zregion = layer > 0 || zregion0;
         const int zrow = zregion ? zb + r16 : rows, zshift = zregion ? 1 : 0;
@@ -362,7 +390,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3(const voi
             const f32x4 bv = *(const f32x4*)&T.b[layer][ch0 + 8 * q + 4 * t];
 #pragma unroll
             for (int j = 0; j < RTW; j++) {
-                f32x4 v = acc[j][t] + bv;
+                f32x4 v = acc[j][t] + ((CB && layer == 0) ? pb4[tower_cb_index(rho0 + j * 16, rows, n, nsq, F >> 2, (ch0 + 8 * q + 4 * t) >> 2)] : bv);
                 v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f);
                 acc[j][t] = v;
             }
@@ -457,7 +485,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3(const voi
 // F-channel image in halo cells — see k_tower_halo (net_kernels.hip) for the layout, the slot table and why.
 // Same products in the same order as k_tower_s3 → identical bits.
 // ------------------------------------------------------------------------------------------------
-template <int RTW, int KC0, int KC, int NB, bool FROM_STATES, bool OUT_SPLIT, int NW>
+template <int RTW, int KC0, int KC, int NB, bool FROM_STATES, bool OUT_SPLIT, int NW, bool CB = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(const void* __restrict__ in, TowerS3Params T, float* __restrict__ out,
                                                                           int B, int PW, int NCG) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -477,7 +505,32 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
     // ---- stage the input: plain image, CP0 = 32·KC0 channels per row, hi/lo split, pitch + 16 B, one zero row ----
     constexpr int CP0 = 32 * KC0;
     constexpr int LS4 = (CP0 >> 2) + 1;
-    if (FROM_STATES) {
+    static_assert(!CB || (FROM_STATES && KC0 == 1), "the constant-plane bias needs the packed states and one chunk of board planes");
+    f32x4* pb4 = (f32x4*)(lds4 + (size_t)(PW * nsq + 1) * LS4);  // CB: PB[position][class][F] (f32) behind the image and its zero row
+    if (CB) {
+        const Geom geo = make_geom(n);
+        const uint8_t* states = (const uint8_t*)in;
+        for (int p = wave; p < npos; p += NW) {
+            WState ws;
+            ws_load(ws, states + (size_t)(pos0 + p) * geo.bytes, geo);
+            const float fcd = fcd_value(ws, geo);
+            const RowMask m = ws_row_mask(ws, geo);
+            if (lane < nsq) {
+                u32x4* row = lds4 + (size_t)(p * nsq + lane) * LS4;
+                f32x4 qd[8];
+                tower_cb_board_quads(m, n, qd);
+#pragma unroll
+                for (int g8 = 0; g8 < 4; g8++) {  // 0 / 1 values: the lo halves are zero
+                    u32x2 h0, l0, h1, l1;
+                    split4(qd[2 * g8], h0, l0);
+                    split4(qd[2 * g8 + 1], h1, l1);
+                    row[g8] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+                    row[4 + g8] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+                }
+            }
+            tower_cb_table(ws, fcd, n, p, F >> 2, (const f32x4*)T.cplane_sums, (const f32x4*)T.b[0], pb4);
+        }
+    } else if (FROM_STATES) {
         const Geom geo = make_geom(n);
         const uint8_t* states = (const uint8_t*)in;
         const int C = input_channels(n);
@@ -543,7 +596,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
         int vmask[RTW];
         conv_tap_masks<RTW>(rows, n, nsq, rho0, vmask);
         if (short_group) vmask[RTW - 1] = 0;
-        const u32x4* wp = (const u32x4*)T.w[0] + (size_t)(ch0 >> 4) * 128 + q * 16 + r16;
+        const u32x4* wp = (const u32x4*)(CB ? T.w0_board : T.w[0]) + (size_t)(ch0 >> 4) * 128 + q * 16 + r16;
         if (RTW > 1 && short_group) {
             f32x4 (&acs)[RTW - 1][2] = *reinterpret_cast<f32x4 (*)[RTW - 1][2]>(&acc[0][0]);
             s3_mainloop<RTW - 1, KC0>(lds4, wp, t1, wstride, LS4, rows, 0, n, rho0, q, vmask, acs);
@@ -560,7 +613,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
             const f32x4 bv = *(const f32x4*)&T.b[0][ch0 + 8 * q + 4 * t];
 #pragma unroll
             for (int j = 0; j < RTW; j++) {
-                f32x4 v = acc[j][t] + bv;
+                f32x4 v = acc[j][t] + (CB ? pb4[tower_cb_index(rho0 + j * 16, rows, n, nsq, F >> 2, (ch0 + 8 * q + 4 * t) >> 2)] : bv);
                 v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f);
                 acc[j][t] = v;
             }
@@ -980,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_value_head_s3(const u32x4* __restrict__
     if (lane == 0) eval[b] = tanhf(s + bv);
 }
 
-template <int RTW, int KC0, int KC, bool FROM_STATES, bool OUT_SPLIT, int NW>
+template <int RTW, int KC0, int KC, bool FROM_STATES, bool OUT_SPLIT, int NW, bool CB = false>
 static hipError_t launch_s3_t(hipStream_t st, const void* in, const TowerS3Params& T, float* out, int B, int n, int PW, int NCG) {
     // rows of C·4 + 32 B are bank-conflict free; the 96-channel input image of the 16-position workgroup only fits with + 16 B
     const size_t rows = (size_t)PW * n * n;
@@ -990,29 +1043,30 @@ static hipError_t launch_s3_t(hipStream_t st, const void* in, const TowerS3Param
     const size_t budget = (size_t)160 * 1024 / (NW == 4 ? 2 : 1);        // two 4-wave workgroups per CU
     if (zrows * (32 * KC0 + 8) * sizeof(float) > budget) pad0 = 1;      // input image: + 16 B pitch and the single zero row
     lds = std::max(lds, (pad0 == 2 ? zrows : rows + 1) * (32 * KC0 + 4 * pad0) * sizeof(float));
+    if (CB) lds = std::max(lds, zrows * (32 * KC0 + 4 * pad0) * sizeof(float) + (size_t)PW * 9 * T.F * sizeof(float));  // + PB behind the zero region
     static size_t configured = 0;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_tower_s3<RTW, KC0, KC, FROM_STATES, OUT_SPLIT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_tower_s3<RTW, KC0, KC, FROM_STATES, OUT_SPLIT, NW, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    hipLaunchKernelGGL((k_tower_s3<RTW, KC0, KC, FROM_STATES, OUT_SPLIT, NW>), dim3((B + PW - 1) / PW), dim3(NW * 64), lds, st, in, T, out, B, n, PW, NCG, pad0);
+    hipLaunchKernelGGL((k_tower_s3<RTW, KC0, KC, FROM_STATES, OUT_SPLIT, NW, CB>), dim3((B + PW - 1) / PW), dim3(NW * 64), lds, st, in, T, out, B, n, PW, NCG, pad0);
     return hipGetLastError();
 }
 
 
-template <int RTW, int KC0, int KC, int NB, bool FROM_STATES, bool OUT_SPLIT, int NW>
+template <int RTW, int KC0, int KC, int NB, bool FROM_STATES, bool OUT_SPLIT, int NW, bool CB = false>
 static hipError_t launch_s3_halo_t(hipStream_t st, const void* in, const TowerS3Params& T, float* out, int B, int PW, int NCG) {
-    const size_t plain = (size_t)(PW * NB * NB + 1) * (32 * KC0 + 4) * sizeof(float);
+    const size_t plain = (size_t)(PW * NB * NB + 1) * (32 * KC0 + 4) * sizeof(float) + (CB ? (size_t)PW * 9 * (32 * KC) * sizeof(float) : 0);
     const size_t halo = (size_t)(NB + 2 + PW * T.halo_ps + 1) * (32 * KC + 4) * sizeof(float);  // + the spare cell
     const size_t lds = std::max(plain, halo);
     static size_t configured = 0;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_tower_s3_halo<RTW, KC0, KC, NB, FROM_STATES, OUT_SPLIT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_tower_s3_halo<RTW, KC0, KC, NB, FROM_STATES, OUT_SPLIT, NW, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    hipLaunchKernelGGL((k_tower_s3_halo<RTW, KC0, KC, NB, FROM_STATES, OUT_SPLIT, NW>), dim3((B + PW - 1) / PW), dim3(NW * 64), lds, st, in, T, out, B, PW, NCG);
+    hipLaunchKernelGGL((k_tower_s3_halo<RTW, KC0, KC, NB, FROM_STATES, OUT_SPLIT, NW, CB>), dim3((B + PW - 1) / PW), dim3(NW * 64), lds, st, in, T, out, B, PW, NCG);
     return hipGetLastError();
 }
 
@@ -1028,6 +1082,17 @@ bool tower_s3_supported(int n, int F) { return (n == 5 && (F == 64 || F == 128))
 template <bool FROM_STATES, bool OUT_SPLIT>
 static hipError_t launch_s3(hipStream_t st, const void* in, const TowerS3Params& T, float* out, int B, int n) {
     static const bool no_halo = getenv("TG_NO_HALO_TOWER") != nullptr;
+    if (FROM_STATES && T.cb) {  // layer 0 over one chunk of board planes, constant planes as a bias (KC0 = 1): the same tilings
+        if (T.slotmap && !no_halo && B >= 256) {
+            if (n == 5 && T.F == 64) return launch_s3_halo_t<7, 1, 2, 5, FROM_STATES, OUT_SPLIT, 4, FROM_STATES>(st, in, T, out, B, 8, 2);
+            if (n == 5 && T.F == 128) return launch_s3_halo_t<7, 1, 4, 5, FROM_STATES, OUT_SPLIT, 8, FROM_STATES>(st, in, T, out, B, 8, 4);
+            if (n == 6 && T.F == 128) return launch_s3_halo_t<5, 1, 4, 6, FROM_STATES, OUT_SPLIT, 8, FROM_STATES>(st, in, T, out, B, 4, 4);
+        }
+        if (n == 5 && T.F == 64) return launch_s3_t<7, 1, 2, FROM_STATES, OUT_SPLIT, 4, FROM_STATES>(st, in, T, out, B, n, 8, 2);
+        if (n == 5 && T.F == 128) return launch_s3_t<7, 1, 4, FROM_STATES, OUT_SPLIT, 8, FROM_STATES>(st, in, T, out, B, n, 8, 4);
+        if (n == 6 && T.F == 128) return launch_s3_t<5, 1, 4, FROM_STATES, OUT_SPLIT, 8, FROM_STATES>(st, in, T, out, B, n, 4, 4);
+        return hipErrorInvalidValue;
+    }
     if (T.slotmap && !no_halo && B >= 256) {  // the halo image (same workgroup shapes as below; identical bits)
         if (n == 5 && T.F == 64) return launch_s3_halo_t<7, 3, 2, 5, FROM_STATES, OUT_SPLIT, 4>(st, in, T, out, B, 8, 2);
         if (n == 5 && T.F == 128) return launch_s3_halo_t<7, 3, 4, 5, FROM_STATES, OUT_SPLIT, 8>(st, in, T, out, B, 8, 4);

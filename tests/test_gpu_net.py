@@ -90,8 +90,9 @@ def test_bf16x3_tower_within_tolerance(orc, n, blocks, filters, head, batch):
     # batch independence and the planes entry point
     p1, v1 = e.policy_eval(sts[3:4])
     assert np.array_equal(p1[0], p[3]) and v1[0] == v[3]
-    p2, v2 = e.forward_mcts(orc.encode(n, sts))
-    assert np.array_equal(p, p2) and np.array_equal(v, v2)
+    p2, v2 = e.forward_mcts(orc.encode(n, sts))  # (planes entry: every plane through layer 0 — another summation order)
+    assert np.abs(p - p2).max() <= 2e-5 and np.abs(v - v2).max() <= 2e-5
+    assert np.abs(p2 - p_ref).max() <= TOL and np.abs(v2 - v_ref).max() <= TOL
     # back to the exact path on the same engine
     e.set_precision("f32")
     e.load_state_dict(torch_ref.abi_tensors(net))
@@ -228,16 +229,14 @@ def test_planes_entry_equals_states_entry_at_full_batch(orc, n, blocks, filters,
     e.load_state_dict(torch_ref.abi_tensors(net))
     p, v = e.policy_eval(sts)
     p2, v2 = e.forward_mcts(orc.encode(n, sts))
-    if precision == "f32":
-        # the f32 towers take a packed state's constant planes (reserves, colour, fcd) as a per-position bias and run layer 0
-        # over the board planes only; caller-encoded planes are arbitrary data and go through layer 0 whole: the same sums in
-        # another order, equal to the last bits but not bit for bit — both within 1e-4 of PyTorch
-        assert np.abs(p - p2).max() <= 1e-6 and np.abs(v - v2).max() <= 1e-6
-        p_ref, v_ref = torch_ref.forward(net, orc.encode(n, sts[:256]))
-        for pp, vv in ((p, v), (p2, v2)):
-            assert np.abs(pp[:256] - p_ref).max() <= TOL and np.abs(vv[:256] - v_ref).max() <= TOL
-    else:
-        assert np.array_equal(p, p2) and np.array_equal(v, v2)
+    # the towers (exact f32 and split-bf16 alike) take a packed state's constant planes (reserves, colour, fcd) as a per-position
+    # bias and run layer 0 over the board planes only; caller-encoded planes are arbitrary data and go through layer 0 whole:
+    # the same sums in another order, equal to the last bits but not bit for bit — both within 1e-4 of PyTorch
+    tol = 1e-6 if precision == "f32" else 2e-5
+    assert np.abs(p - p2).max() <= tol and np.abs(v - v2).max() <= tol
+    p_ref, v_ref = torch_ref.forward(net, orc.encode(n, sts[:256]))
+    for pp, vv in ((p, v), (p2, v2)):
+        assert np.abs(pp[:256] - p_ref).max() <= TOL and np.abs(vv[:256] - v_ref).max() <= TOL
     e.close()
 
 

@@ -32,8 +32,9 @@ struct Net {
     float value_b = 0.0f;
     // activations (max_batch positions)
     DevBuf x, y, logits, planes_nhwc, planes_nchw;
-    DevBuf fc_stats;                  // [max_batch][policy_np / 208][2]: block-wise softmax statistics of the f32 policy FC (softmax.cuh)
+    DevBuf fc_stats;                  // [max_batch][fc_stat_blocks][2]: block-wise softmax statistics of the policy FC (softmax.cuh)
     bool fc_stats_on = false;
+    int fc_stat_blocks = 0;           // policy_np / 208 on the exact path, s3_np / 112 on the split-bf16 FC
     bool fused = false;  // whole tower in one launch (k_tower)
     TowerParams tower;
     ConvLayer conv0_tower;             // conv0 with the last input chunk permuted (layer 0 of the fused towers)
@@ -469,9 +470,11 @@ int net_finalize(TgEngine* e) {
     TG_HIP(n->logits.ensure(mb * logit_row * 4));
     TG_HIP(n->planes_nhwc.ensure(mb * nsq * n->cin_pad * 4));
     // f32 FC head with the value column: the FC emits the softmax statistics per column block, nobody re-reads whole rows
-    n->fc_stats_on = e->cfg.policy_head == TG_HEAD_FC5 && n->value_in_fc && !(n->s3 && n->s3_fc_on) &&
-                     fc_stats_supported(nsq * F, n->policy_np, n->policy_np) && !getenv("TG_NO_FC_STATS");
-    if (n->fc_stats_on) TG_HIP(n->fc_stats.ensure(mb * (size_t)(n->policy_np / 208) * 2 * 4));
+    const bool s3fc = n->s3 && n->s3_fc_on;
+    n->fc_stats_on = e->cfg.policy_head == TG_HEAD_FC5 && n->value_in_fc && !getenv("TG_NO_FC_STATS") &&
+                     (s3fc ? (n->s3_np % 112 == 0 && n->s3_np / 112 <= 64) : fc_stats_supported(nsq * F, n->policy_np, n->policy_np));
+    n->fc_stat_blocks = n->fc_stats_on ? (s3fc ? n->s3_np / 112 : n->policy_np / 208) : 0;
+    if (n->fc_stats_on) TG_HIP(n->fc_stats.ensure(mb * (size_t)n->fc_stat_blocks * 2 * 4));
     n->ready = true;
     return TG_OK;
 }
@@ -500,8 +503,9 @@ const float* net_fc_logits(const TgEngine* e, int* ld) {
 // the block statistics that go with net_fc_logits' buffer ([max_batch][*blocks][2]), or nullptr: the consumer then takes max and
 // Σexp over the whole row itself (softmax_stats_wave)
 const float* net_fc_stats(const TgEngine* e, int* blocks) {
-    if (!net_ready(e) || !e->net->fc_stats_on || (e->net->s3 && e->net->s3_fc_on)) return nullptr;
-    *blocks = e->net->policy_np / 208;
+    if (!net_ready(e) || !e->net->fc_stats_on) return nullptr;
+    if (e->net->s3 && !e->net->s3_fc_on) return nullptr;  // split tower with the f32 FC: net_fc_logits declines too
+    *blocks = e->net->fc_stat_blocks;
     return e->net->fc_stats.as<float>();
 }
 
@@ -589,14 +593,17 @@ static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const ui
             TG_HIP(launch_conv3x3(st, x, L.w.as<float>(), L.b.as<float>(), nullptr, logits, M, N, F, L.cout_pad, L.cout_pad, L.cout, false));
         TG_HIP(launch_softmax(st, logits, nsq * L.cout_pad, true, nsq, L.cout_pad, e->policy_size, nb, d_policy));
     } else if (n->s3 && n->s3_fc_on) {
-        TG_HIP(launch_fc_s3(st, x, n->s3_fc.p, n->s3_fc_b.as<float>(), logits, nb, nsq * F, n->s3_np, n->s3_np, e->policy_size + (n->value_in_fc ? 1 : 0)));
-        if (d_policy) TG_HIP(launch_softmax(st, logits, n->s3_np, false, nsq, 0, e->policy_size, nb, d_policy, n->value_in_fc ? d_eval : nullptr));
+        float* stats = n->fc_stats_on ? n->fc_stats.as<float>() + (size_t)pos0 * n->fc_stat_blocks * 2 : nullptr;
+        TG_HIP(launch_fc_s3(st, x, n->s3_fc.p, n->s3_fc_b.as<float>(), logits, nb, nsq * F, n->s3_np, n->s3_np, e->policy_size + (n->value_in_fc ? 1 : 0),
+                            stats, e->policy_size));
+        if (d_policy && stats) TG_HIP(launch_softmax_stats(st, logits, n->s3_np, stats, n->fc_stat_blocks, e->policy_size, nb, d_policy, d_eval));
+        else if (d_policy) TG_HIP(launch_softmax(st, logits, n->s3_np, false, nsq, 0, e->policy_size, nb, d_policy, n->value_in_fc ? d_eval : nullptr));
     } else {
-        float* stats = n->fc_stats_on ? n->fc_stats.as<float>() + (size_t)pos0 * (n->policy_np / 208) * 2 : nullptr;
+        float* stats = n->fc_stats_on ? n->fc_stats.as<float>() + (size_t)pos0 * n->fc_stat_blocks * 2 : nullptr;
         TG_HIP(launch_gemm(st, x, nsq * F, n->policy_w.as<float>(), n->policy_b.as<float>(), logits, nb, nsq * F, n->policy_np,
                            n->policy_np, e->policy_size + (n->value_in_fc ? 1 : 0), !n->s3 && n->fused && n->tower.frag_out,
                            stats, e->policy_size));
-        if (d_policy && stats) TG_HIP(launch_softmax_stats(st, logits, n->policy_np, stats, n->policy_np / 208, e->policy_size, nb, d_policy, d_eval));
+        if (d_policy && stats) TG_HIP(launch_softmax_stats(st, logits, n->policy_np, stats, n->fc_stat_blocks, e->policy_size, nb, d_policy, d_eval));
         else if (d_policy) TG_HIP(launch_softmax(st, logits, n->policy_np, false, nsq, 0, e->policy_size, nb, d_policy, n->value_in_fc ? d_eval : nullptr));
     }
     if (!d_policy && !(e->cfg.policy_head == TG_HEAD_FC5 && n->value_in_fc)) return fail(TG_ERR_STATE, "logits-only forward needs the FC head with the value column");

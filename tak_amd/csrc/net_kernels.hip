@@ -913,7 +913,7 @@ __device__ __forceinline__ void fc_epilogue(const f32x4 (&acc)[FC_CT], const flo
     }
     if (stats) {
         float m, sm;
-        fc_block_stats(v, n0 + 4 * q, n_soft, m, sm);
+        fc_block_stats<FC_CT>(v, n0 + 4 * q, n_soft, m, sm);
         if (row_ok && q == 0) *(float2*)&stats[((size_t)row * blocks + (n0 / FC_COLS)) * 2] = make_float2(m, sm);
     }
 }
@@ -1231,7 +1231,7 @@ __global__ __launch_bounds__(256) void k_fc_stats(const float* __restrict__ logi
 #pragma unroll
     for (int j = 0; j < FC_CT; j++) v[j] = *(const f32x4*)&x[16 * j];
     float m, sm;
-    fc_block_stats(v, b * FC_COLS + 4 * q, n_soft, m, sm);
+    fc_block_stats<FC_CT>(v, b * FC_COLS + 4 * q, n_soft, m, sm);
     if (q == 0 && pair0 + r16 < total) *(float2*)&stats[(size_t)pair * 2] = make_float2(m, sm);
 }
 

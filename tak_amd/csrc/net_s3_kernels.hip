@@ -28,6 +28,7 @@
 
 #include "board.cuh"
 #include "conv_mainloop.cuh"
+#include "softmax.cuh"
 #include "tower_cb.cuh"
 #include "kernels.h"
 
@@ -901,9 +902,12 @@ __global__ __launch_bounds__(512) void k_fc_s3(const u32x4* __restrict__ A, cons
 // Variant with small workgroups: NW waves, each 2 position tiles × all CT output tiles (NW·32 positions × CT·16
 // outputs per workgroup).  CT = 7, NW = 4 needs 57 KB of LDS, so two workgroups share a CU and one's staging / barrier
 // phases overlap the other's MFMAs; nothing is loaded twice by a workgroup.
+// stats (optional): the block-wise softmax statistics of softmax.cuh over this workgroup's CT·16 columns, per row:
+// stats[(row·blocks + block)·2] = {max, Σ exp(x − max)} of the columns < n_soft — what the tree backup and k_softmax_stats combine
 template <int CT, int NW>
 __global__ __launch_bounds__(NW * 64) void k_fc_s3b(const u32x4* __restrict__ A, const u32x4* __restrict__ Wp, const float* __restrict__ bias,
-                                                    float* __restrict__ out, int M, int K, int NP, int out_stride, int n_valid) {
+                                                    float* __restrict__ out, int M, int K, int NP, int out_stride, int n_valid,
+                                                    float* __restrict__ stats, int n_soft) {
     constexpr int COLS = CT * 16, SLOTS = 2 * 4 * 2 * COLS, NT = NW * 64, PER = (SLOTS + NT - 1) / NT;
     __shared__ u32x4 wl[2][SLOTS];
     const int tid = threadIdx.x;
@@ -995,19 +999,27 @@ __global__ __launch_bounds__(NW * 64) void k_fc_s3b(const u32x4* __restrict__ A,
         __syncthreads();
     }
 #pragma unroll
-    for (int p = 0; p < 2; p++)
+    for (int p = 0; p < 2; p++) {
+        f32x4 v[CT];
+#pragma unroll
+        for (int j = 0; j < CT; j++) v[j] = acc[p][j] + *(const f32x4*)&bias[n0 + j * 16 + 4 * q];  // (bias holds NP entries)
         if (row_ok[p]) {
 #pragma unroll
             for (int j = 0; j < CT; j++) {
                 const int nn = n0 + j * 16 + 4 * q;
                 if (nn < n_valid) {
-                    f32x4 v = acc[p][j] + *(const f32x4*)&bias[nn];
                     float* o = out + (size_t)row[p] * out_stride + nn;
-                    if (nn + 3 < n_valid) *(f32x4*)o = v;
-                    else for (int t = 0; t < 4; t++) if (nn + t < n_valid) o[t] = v[t];
+                    if (nn + 3 < n_valid) *(f32x4*)o = v[j];
+                    else for (int t = 0; t < 4; t++) if (nn + t < n_valid) o[t] = v[j][t];
                 }
             }
         }
+        if (stats) {
+            float m, sm;
+            fc_block_stats<CT>(v, n0 + 4 * q, n_soft, m, sm);
+            if (row_ok[p] && q == 0) *(float2*)&stats[((size_t)row[p] * gridDim.y + blockIdx.y) * 2] = make_float2(m, sm);
+        }
+    }
 }
 
 // value head on the split activations: Linear(F·N² → 1) + tanh; wv in NHWC order (f32)
@@ -1119,12 +1131,14 @@ hipError_t launch_tower_s3_states(hipStream_t st, const uint8_t* states, const T
 bool fc_s3_supported(int K, int NP) { return K % 64 == 0 && (NP % FS_COLS == 0 || NP % 112 == 0); }
 int fc_s3_cols(int NP) { return NP % 112 == 0 ? 112 : FS_COLS; }  // column-block width of the weight layout
 hipError_t launch_fc_s3(hipStream_t st, const float* act_split, const void* Wp, const float* bias, float* out, int M, int K, int NP,
-                        int out_stride, int n_valid) {
+                        int out_stride, int n_valid, float* stats, int n_soft) {
     if (NP % 112 == 0) {
         dim3 grid((M + 127) / 128, NP / 112);
-        hipLaunchKernelGGL((k_fc_s3b<7, 4>), grid, dim3(256), 0, st, (const u32x4*)act_split, (const u32x4*)Wp, bias, out, M, K, NP, out_stride, n_valid);
+        hipLaunchKernelGGL((k_fc_s3b<7, 4>), grid, dim3(256), 0, st, (const u32x4*)act_split, (const u32x4*)Wp, bias, out, M, K, NP, out_stride, n_valid,
+                           stats, n_soft);
         return hipGetLastError();
     }
+    if (stats) return hipErrorInvalidValue;  // (only the 112-column kernel emits statistics)
     dim3 grid((M + 127) / 128, NP / FS_COLS);
     hipLaunchKernelGGL(k_fc_s3, grid, dim3(512), 0, st, (const u32x4*)act_split, (const u32x4*)Wp, bias, out, M, K, NP, out_stride, n_valid);
     return hipGetLastError();

@@ -76,10 +76,13 @@ constexpr int FC_STAT_TILES = 13;
 using softmax_f32x4 = __attribute__((ext_vector_type(4))) float;
 
 // v[j] = the lane's four logits of tile j (bias added); col0 = n0 + 4q: the lane's first column of tile 0.  All 64 lanes call.
-__device__ __forceinline__ void fc_block_stats(const softmax_f32x4 (&v)[FC_STAT_TILES], int col0, int n_soft, float& m_out, float& s_out) {
+// TILES = 13 on the exact-f32 FC (blocks of 208 columns), 7 on the split-bf16 FC (k_fc_s3b: blocks of 112): the block width
+// belongs to the path, and a path's consumers only ever see that path's statistics.
+template <int TILES>
+__device__ __forceinline__ void fc_block_stats(const softmax_f32x4 (&v)[TILES], int col0, int n_soft, float& m_out, float& s_out) {
     float m = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < FC_STAT_TILES; j++)
+    for (int j = 0; j < TILES; j++)
 #pragma unroll
         for (int t = 0; t < 4; t++)
             if (col0 + 16 * j + t < n_soft) m = fmaxf(m, v[j][t]);
@@ -87,7 +90,7 @@ __device__ __forceinline__ void fc_block_stats(const softmax_f32x4 (&v)[FC_STAT_
     m = fmaxf(m, __shfl_xor(m, 32));
     float s = 0.0f;
 #pragma unroll
-    for (int j = 0; j < FC_STAT_TILES; j++)
+    for (int j = 0; j < TILES; j++)
 #pragma unroll
         for (int t = 0; t < 4; t++) s += (col0 + 16 * j + t < n_soft) ? stat_exp(v[j][t] - m) : 0.0f;
     s += __shfl_xor(s, 16);

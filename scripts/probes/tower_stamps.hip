@@ -7,8 +7,9 @@
 #include "../../tak_amd/csrc/net_kernels.hip"
 using namespace tg;
 int main(int argc, char** argv) {
-    const int B = 4096, n = 5, F = 64, R = 6, cin_pad = 80, nl = 1 + 2 * R;
     const int variant = argc > 1 ? atoi(argv[1]) : 8;
+    const bool c5 = variant == 85;  // variant 85: the C5 network (10 blocks × 128 filters, 8 positions per workgroup), constant planes as a bias
+    const int B = 4096, n = 5, F = c5 ? 128 : 64, R = c5 ? 10 : 6, cin_pad = 80, nl = 1 + 2 * R;
     uint8_t* states; hipMalloc(&states, (size_t)B * 256); hipMemset(states, 0, (size_t)B * 256);
     std::vector<uint8_t> hs((size_t)B * 256, 0);
     for (int b = 0; b < B; b++) { uint8_t* h = &hs[(size_t)b * 256 + 240]; h[0] = 5; h[4] = 21; h[5] = 1; h[6] = 21; h[7] = 1; h[8] = 4; }
@@ -29,10 +30,22 @@ int main(int argc, char** argv) {
     hipMemcpyToSymbol(HIP_SYMBOL(g_tower_stamps), &stamps, sizeof(stamps));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     std::vector<uint32_t> map(25 * 16);
-    tower_halo_slotmap(5, 16, 36, map.data());
+    tower_halo_slotmap(5, c5 ? 8 : 16, c5 ? 37 : 36, map.data());
     uint32_t* dmap; hipMalloc(&dmap, map.size() * 4); hipMemcpy(dmap, map.data(), map.size() * 4, hipMemcpyHostToDevice);
-    T.slotmap = dmap; T.halo_pw = 16; T.halo_ps = 36;
+    T.slotmap = dmap; T.halo_pw = c5 ? 8 : 16; T.halo_ps = c5 ? 37 : 36;
+    // variant 82: the halo tower with the constant input planes as a per-position bias (TowerParams.cb): layer 0 over 32 channels
+    if (variant == 82 || c5) {
+        size_t wf = (size_t)9 * 32 * F;
+        float* w; hipMalloc(&w, wf * 4);
+        std::vector<float> hw(wf);
+        for (size_t i = 0; i < wf; i++) hw[i] = 0.01f * (float)((i * 2654435761u) % 97) - 0.45f;
+        hipMemcpy(w, hw.data(), wf * 4, hipMemcpyHostToDevice);
+        float* S; hipMalloc(&S, (size_t)46 * 9 * F * 4); hipMemset(S, 0, (size_t)46 * 9 * F * 4);
+        T.cb = 1; T.cb_cin_pad = 32; T.cb_last_t = 3; T.w0_board = w; T.cplane_sums = S;
+    }
     auto launch = [&]() {
+        if (c5) return launch_tower_halo_t<13, 8, 2, 8, 5, true, true>(nullptr, (const float*)states, T, out, B, 8);
+        if (variant == 82) return launch_tower_halo_t<13, 8, 2, 4, 5, true, true>(nullptr, (const float*)states, T, out, B, 4);
         if (variant == 80) return launch_tower_halo_t<13, 8, 5, 4, 5, true>(nullptr, (const float*)states, T, out, B, 4);
         if (variant == 16) return launch_tower_t<7, 16, 5, 4, true>(nullptr, (const float*)states, T, out, B, n, 16, 4);
         if (variant == 4) return launch_tower_t<25, 4, 5, 4, true>(nullptr, (const float*)states, T, out, B, n, 16, 4);
@@ -47,7 +60,7 @@ int main(int argc, char** argv) {
     printf("variant %d waves: %.1f us per launch\n", variant, ms * 100);
     std::vector<unsigned long long> h((size_t)nl * 16 * 8);
     hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
-    const int nw = variant == 80 ? 8 : variant;
+    const int nw = variant >= 80 ? 8 : variant;
     printf("layer wave |  mainloop  epilogue  barrier1  writeback  barrier2 | next-layer start - this start\n");
     for (int l = 0; l < nl - 1; l++)
         for (int w = 0; w < nw; w++) {
@@ -56,6 +69,10 @@ int main(int argc, char** argv) {
             if (l == 0 || l == 5 || l == 6)
                 printf("%5d %4d | %9llu %9llu %9llu %10llu %9llu | %llu\n", l, w, s[1] - s[0], s[2] - s[1], s[3] - s[2], s[4] - s[3], s[5] - s[4], nx[0] - s[0]);
         }
+    for (int w = 0; w < nw; w++) {
+        const unsigned long long* s = &h[((size_t)0 * 16 + w) * 8];
+        if (s[6]) printf("layer 0 wave %d: staging (start -> image ready) %llu cycles\n", w, s[0] - s[6]);
+    }
     // averages over layers 1..nl-2 and waves
     double acc[6] = {0, 0, 0, 0, 0, 0};
     int cnt = 0;

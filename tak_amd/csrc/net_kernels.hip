@@ -500,6 +500,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower_halo(const float* __restr
     static_assert(!CB || FROM_STATES, "the constant-plane bias needs the packed states");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     f32x4* lds4 = (f32x4*)lds;
+    TG_STAMP(0, 6);  // kernel start (diagnostic build only)
     constexpr int n = NB, nsq = NB * NB, RS = NB + 1, LEAD = NB + 2, F = 16 * CH, P4 = 4 * CH + 1;
     const int PS = T.halo_ps;
     const int tid = threadIdx.x;
@@ -691,6 +692,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower_halo(const float* __restr
 // Epilogue: + bias, + res (optional), ReLU (optional).  COT = CoutP / 16; blockIdx.y picks a group of CTW channel tiles.
 // ------------------------------------------------------------------------------------------------
 // PSC: the position stride of the halo image (tower_halo_geometry) as a constant — the zero-cell fill divides by it 19 000 times
+#ifndef TG_CONV_PROBE
+#define TG_CONV_PROBE 0  // timing probes (wrong results; scripts/probes/conv_halo_probe.hip): 1 = no main loop, 2 = no input rows, 4 = no output
+#endif
 template <int RTW, int NWAVES, int CH, int NB, int COT, int PSC>
 __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restrict__ in, const float* __restrict__ Wp,
                                                            const float* __restrict__ bias, const float* __restrict__ res,
@@ -711,6 +715,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restri
     const int ch0 = (blockIdx.y * CTW + ct) * 16;
     const uint32_t wlane = (uint32_t)(((ch0 + r16) * 4 + q) * 16);
     f32x4 w0, w1;
+    TG_STAMP(0, 0);
+#ifdef TG_TOWER_STAMPS  // wall-clock (100 MHz) start and end of every workgroup: dispatch skew and tail of a launch
+    if (g_tower_stamps && tid == 0) g_tower_stamps[128 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
     conv_halo_first_weights<CH, COT>(Wp, wlane, w0, w1);  // in flight while the image is staged
     // zero cells (behind every board row, the zero row behind every position, lead and tail) …
     const int cells = LEAD + PW * PS + 1;
@@ -720,7 +728,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restri
         if (o >= n * RS || o % RS == n) lds4[idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
     // … and the squares' rows from global (row-major [row][16·CH]), 8 loads in flight per lane
-    {
+    if (!(TG_CONV_PROBE & 2)) {
         const f32x4* src = (const f32x4*)(in + (size_t)pos0 * nsq * (16 * CH));
         const int total = rows * F4;
         constexpr int UNR = 8;
@@ -743,6 +751,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restri
         }
     }
     __syncthreads();
+    TG_STAMP(0, 1);
 
     const int NRG = NWAVES / CTW;
     const int ntiles = (PW * nsq + 15) >> 4;
@@ -761,11 +770,23 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restri
         addr4[j] = ((idle ? LEAD + n * RS : (int)(e & 0xFFFFu)) - LEAD) * P4 + q;
     }
     const int turn = (wave >> 2) & 1;
-    if (RTW > 1 && short_group) {
+    TG_STAMP(0, 2);
+    if (TG_CONV_PROBE & 1) {
+#pragma unroll
+        for (int j = 0; j < RTW; j++) acc[j] = lds4[addr4[j] + LEAD * P4] + w0 + w1;
+    } else if (RTW > 1 && short_group) {
         f32x4 (&acs)[RTW - 1] = *reinterpret_cast<f32x4 (*)[RTW - 1]>(&acc[0]);
         conv_mainloop_halo<RTW - 1, CH, NB, RTW, COT>(lds4, Wp, Wp, wlane, addr4, acs, turn, w0, w1);
     } else {
         conv_mainloop_halo<RTW, CH, NB, RTW, COT>(lds4, Wp, Wp, wlane, addr4, acc, turn, w0, w1);
+    }
+    TG_STAMP(0, 3);
+    if (TG_CONV_PROBE & 4) {
+        f32x4 t = acc[0];
+#pragma unroll
+        for (int j = 1; j < RTW; j++) t += acc[j];
+        if (t[0] + t[1] + t[2] + t[3] == 12345.678f) out[tid] = t[0];
+        return;
     }
     const int ch = ch0 + 4 * q;
     const f32x4 bv = *(const f32x4*)&bias[ch];
@@ -798,6 +819,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restri
             for (int t = 0; t < 4; t++) { dst[t] = (double)s1[t]; dst[CoutP + t] = (double)s2[t]; }
         }
     }
+    TG_STAMP(0, 4);
+#ifdef TG_TOWER_STAMPS
+    if (g_tower_stamps && tid == NWAVES * 64 - 64) g_tower_stamps[128 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // Plain GEMM out[M][N] = A[M][K]·W[K][N] + bias for the 5×5 policy FC (net5.rs:56-61,108): the same

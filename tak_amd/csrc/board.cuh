@@ -509,23 +509,39 @@ __device__ inline void ws_encode(const WState& s, const Geom& g, float* out, int
         const int per_sq = cstride >> 2;
         const int total = g.nsq * per_sq;
         float4* dst = (float4*)out;
-        for (int i0 = 0; i0 < total; i0 += 64) {
-            const int idx = i0 + lane;
-            const int ii = idx < total ? idx : total - 1;
-            const int sq = ii / per_sq, k = ii - sq * per_sq;
-            const int c0 = k << 2;
-            // the 32-bit word of the square's mask that holds channels c0..c0+3 (every lane takes part in the shuffles)
-            const uint32_t w0 = (uint32_t)__shfl((int)m.w[0], sq), w1 = (uint32_t)__shfl((int)m.w[1], sq);
-            const uint32_t w2 = (uint32_t)__shfl((int)m.w[2], sq), w3 = (uint32_t)__shfl((int)m.w[3], sq);
-            const uint32_t word = c0 < 32 ? w0 : c0 < 64 ? w1 : c0 < 96 ? w2 : w3;
+        // channels c0..c0+3 as floats from the 32-bit mask word that holds them; the fcd plane is the last channel
+        auto quad = [&](uint32_t word, int c0) {
             const uint32_t nib = (word >> (c0 & 31)) & 15u;
             float4 v;
             v.x = (nib & 1u) ? 1.0f : 0.0f;
             v.y = (nib & 2u) ? 1.0f : 0.0f;
             v.z = (nib & 4u) ? 1.0f : 0.0f;
             v.w = (nib & 8u) ? 1.0f : 0.0f;
-            const int r = C - 1 - c0;  // the fcd plane is the last channel
+            const int r = C - 1 - c0;
             if (r == 0) v.x = fcd; else if (r == 1) v.y = fcd; else if (r == 2) v.z = fcd; else if (r == 3) v.w = fcd;
+            return v;
+        };
+        // Only word 0 of a mask belongs to the square (the board channels, ≤ 32 of them up to 8×8, come first): it is fetched
+        // from the square's lane (every lane takes part in the shuffle); words 1-3 hold reserves and colour alone — the same
+        // in every lane's own mask
+        auto round = [&](int idx) {
+            const int sq = idx / per_sq, k = idx - sq * per_sq;
+            const int c0 = k << 2;
+            const uint32_t w0 = (uint32_t)__shfl((int)m.w[0], sq);
+            return quad(c0 < 32 ? w0 : c0 < 64 ? m.w[1] : c0 < 96 ? m.w[2] : m.w[3], c0);
+        };
+        const int full = total & ~63, rem = total - full;
+        for (int i0 = 0; i0 < full; i0 += 64) dst[i0 + lane] = round(i0 + lane);
+        if (rem && rem <= per_sq - 8) {
+            // the last few quads (2 of the 450 on 5×5 at 72 channels) are reserve / colour / fcd channels of the last square:
+            // no square to look up
+            const int c0 = (per_sq - rem + lane) << 2;
+            const int cc = c0 < 4 * per_sq ? c0 : 4 * per_sq - 4;
+            const float4 v = quad(cc < 64 ? m.w[1] : cc < 96 ? m.w[2] : m.w[3], cc);
+            if (lane < rem) dst[full + lane] = v;
+        } else if (rem) {
+            const int idx = full + lane;
+            const float4 v = round(idx < total ? idx : total - 1);
             if (idx < total) dst[idx] = v;
         }
         return;

@@ -1040,6 +1040,11 @@ __global__ __launch_bounds__(512) void k_fc_lds(const float* __restrict__ A, int
 // identical bits.  Measured (C2, 4096 rows): 173 – 175 µs against 178 – 180 µs; with neither refills nor flags the loop
 // takes 159 µs (of which ≈ 10 µs are the first fill and the 27 MB output burst), the flags alone cost 10 µs (waves held
 // back for a slower one run their SIMD alone), the refills alone 12 µs.  Fair-priority and operand-order variants: no change.
+// Round 3, measured and discarded: a ninth wave that does nothing but fill the ring (waits for done[], issues the 52 LDS-DMA
+// instructions of a K-step, publishes ready[]) so that the eight MFMA waves never issue an LDS-DMA, never wait vmcnt(0) and
+// never poll done[] — identical bits, 139 registers, and 8 – 10 µs SLOWER per launch (with the poll slowed to s_sleep 16:
+// 3 µs slower; with the fill paced in four groups: 12 µs slower).  What the refills cost is the LDS-DMA traffic beside the
+// fragment reads, not the instructions that start it; spread over eight waves in mid-step it disturbs least.
 constexpr int FC_RING = 3;
 constexpr int FC_RING_SLOTS = 4 * FC_PLANE;                                        // f32x4 slots per buffer (3328)
 constexpr size_t FC_RING_LDS = (size_t)FC_RING * FC_RING_SLOTS * 16 + 2 * FC_RING * sizeof(uint32_t);

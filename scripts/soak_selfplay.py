@@ -35,17 +35,20 @@ if args.evaluator == "resnet":  # random-init weights (tests/torch_ref.py builds
     if args.precision != "f32":
         e.set_precision(args.precision)
     e.load_state_dict(torch_ref.abi_tensors(torch_ref.make_net(args.board, args.blocks, args.filters, "fc5" if args.board == 5 else "conv", seed=0, randomize_bn=False)))
-e.selfplay_create(args.games, arena_nodes=args.arena, seed=1, rollouts=args.rollouts, max_examples=1 << 18)
+# the example ring holds two drain intervals of every game (a position per game and ply): nothing is dropped between drains
+ring = max(1 << 18, 2 * args.games * args.every)
+e.selfplay_create(args.games, arena_nodes=args.arena, seed=1, rollouts=args.rollouts, max_examples=ring)
 t0 = time.time()
 drained = 0
 lens = []
 for p in range(0, args.plies, args.every):
     e.selfplay_step(args.every)
     st = e.selfplay_stats()  # synchronises and raises on any device error flag
-    hdr, states, moves, visits = e.selfplay_drain(1 << 18)
+    hdr, states, moves, visits = e.selfplay_drain(ring)
     drained += len(hdr)
     pool = e.search_pool()
     print(json.dumps({"ply": p + args.every, "t": round(time.time() - t0, 1), **st, "drained": drained,
                       "pool_nodes_in_use": pool["in_use"], "pool_nodes_peak": pool["peak"], "pool_nodes_total": pool["total"]}), flush=True)
-assert drained == st["examples"] or st["examples"] - drained <= 0
+assert st["dropped_examples"] == 0, "the example ring was overrun between two drains"
+assert drained == st["examples"]
 print("soak ok")

@@ -511,16 +511,22 @@ __device__ inline void ws_encode(const WState& s, const Geom& g, float* out, int
         float4* dst = (float4*)out;
         // channels c0..c0+3 as floats from the 32-bit mask word that holds them; the fcd plane is the last channel
         auto quad = [&](uint32_t word, int c0) {
-            const uint32_t nib = (word >> (c0 & 31)) & 15u;
+            const uint32_t nib = word >> (c0 & 31);
+            // bit → 0.0f / 1.0f without a compare: sign-extend the bit over the word and mask the bits of 1.0f
+            auto one = [](uint32_t bits, int b) { return __uint_as_float((uint32_t)((int32_t)(bits << (31 - b)) >> 31) & 0x3f800000u); };
             float4 v;
-            v.x = (nib & 1u) ? 1.0f : 0.0f;
-            v.y = (nib & 2u) ? 1.0f : 0.0f;
-            v.z = (nib & 4u) ? 1.0f : 0.0f;
-            v.w = (nib & 8u) ? 1.0f : 0.0f;
+            v.x = one(nib, 0);
+            v.y = one(nib, 1);
+            v.z = one(nib, 2);
+            v.w = one(nib, 3);
             const int r = C - 1 - c0;
             if (r == 0) v.x = fcd; else if (r == 1) v.y = fcd; else if (r == 2) v.z = fcd; else if (r == 3) v.w = fcd;
             return v;
         };
+        // words 1-3 of the mask are the same in every lane: scalars, selected by compares (indexing m.w[] by a lane-dependent
+        // channel made hipcc park the mask in LDS and branch around the read in every round)
+        const uint32_t m1 = uni(m.w[1]), m2 = uni(m.w[2]), m3 = uni(m.w[3]);
+        auto const_word = [&](int c0) { return c0 < 64 ? m1 : c0 < 96 ? m2 : m3; };
         // Only word 0 of a mask belongs to the square (the board channels, ≤ 32 of them up to 8×8, come first): it is fetched
         // from the square's lane (every lane takes part in the shuffle); words 1-3 hold reserves and colour alone — the same
         // in every lane's own mask
@@ -528,7 +534,7 @@ __device__ inline void ws_encode(const WState& s, const Geom& g, float* out, int
             const int sq = idx / per_sq, k = idx - sq * per_sq;
             const int c0 = k << 2;
             const uint32_t w0 = (uint32_t)__shfl((int)m.w[0], sq);
-            return quad(c0 < 32 ? w0 : c0 < 64 ? m.w[1] : c0 < 96 ? m.w[2] : m.w[3], c0);
+            return quad(c0 < 32 ? w0 : const_word(c0), c0);
         };
         const int full = total & ~63, rem = total - full;
         for (int i0 = 0; i0 < full; i0 += 64) dst[i0 + lane] = round(i0 + lane);
@@ -537,7 +543,7 @@ __device__ inline void ws_encode(const WState& s, const Geom& g, float* out, int
             // no square to look up
             const int c0 = (per_sq - rem + lane) << 2;
             const int cc = c0 < 4 * per_sq ? c0 : 4 * per_sq - 4;
-            const float4 v = quad(cc < 64 ? m.w[1] : cc < 96 ? m.w[2] : m.w[3], cc);
+            const float4 v = quad(const_word(cc), cc);
             if (lane < rem) dst[full + lane] = v;
         } else if (rem) {
             const int idx = full + lane;

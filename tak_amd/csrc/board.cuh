@@ -89,6 +89,36 @@ __device__ inline void ws_load(WState& s, const uint8_t* st, const Geom& g) {
     s.rev = (h2 >> 8) & 0xff;
 }
 
+// ws_load in two halves, for a wave that stages several positions: the raw words of ALL of them are requested first
+// (ws_load_raw), each becomes a WState when its turn comes (ws_unpack) — one memory round trip instead of one per position
+struct WRaw { uint64_t stack; uint32_t meta, h0, h1, h2; };
+__device__ inline WRaw ws_load_raw(const uint8_t* st, const Geom& g) {
+    const int lane = lane_id();
+    const int l = lane < g.nsq ? lane : 0;  // unconditional loads (hipcc waits right behind an exec-masked one)
+    WRaw r;
+    r.stack = ((const uint64_t*)st)[l];
+    r.meta = (uint32_t)(st + 8 * g.slots)[l];
+    const uint32_t* h = (const uint32_t*)(st + g.bytes - 16);
+    r.h0 = h[0]; r.h1 = h[1]; r.h2 = h[2];
+    return r;
+}
+__device__ inline void ws_unpack(WState& s, const WRaw& r, const Geom& g) {
+    const bool on = lane_id() < g.nsq;
+    s.stack = on ? r.stack : 0ull;
+    const uint32_t m = on ? r.meta : 0u;
+    s.height = m & 63u;
+    s.top = m >> 6;
+    const uint32_t h0 = uni(r.h0), h1 = uni(r.h1), h2 = uni(r.h2);
+    s.to_move = (h0 >> 8) & 0xff;
+    s.ply = h0 >> 16;
+    s.ws = h1 & 0xff;
+    s.wc = (h1 >> 8) & 0xff;
+    s.bs = (h1 >> 16) & 0xff;
+    s.bc = h1 >> 24;
+    s.half_komi = (int32_t)(int8_t)(h2 & 0xff);
+    s.rev = (h2 >> 8) & 0xff;
+}
+
 __device__ inline void ws_store(const WState& s, uint8_t* st, const Geom& g) {
     int lane = lane_id();
     uint64_t* stk = (uint64_t*)st;

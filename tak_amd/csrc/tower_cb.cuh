@@ -28,15 +28,24 @@ __device__ __forceinline__ void tower_cb_table(const WState& ws, float fcd, int 
     pl[3] = (en_cp > 0 && en_cp <= cp0) ? 2 * st0 + cp0 + en_cp - 1 : -1;
     pl[4] = w ? 2 * st0 + 2 * cp0 : -1;
     const int fplane = 2 * st0 + 2 * cp0 + 1;
-    for (int idx = lane; idx < 9 * F4; idx += 64) {  // idx = class·F/4 + channel quad
+    for (int idx0 = 0; idx0 < 9 * F4; idx0 += 64) {  // idx = class·F/4 + channel quad
+        const int idx = min(idx0 + lane, 9 * F4 - 1);
         const int cls = idx / F4;
+        // all seven rows are requested before the first add (a row behind `if (plane is set)` was a load the next one waited
+        // for: six L2 round trips in a row, per round and position); an unset plane reads row 0 and is not added — the sum
+        // and its order are those of the conditional form, bit for bit
         f32x4 v = B4[idx - cls * F4];
+        f32x4 t[5];
 #pragma unroll
-        for (int k = 0; k < 5; k++)
-            if (pl[k] >= 0) v += S4[(size_t)pl[k] * 9 * F4 + idx];
+        for (int k = 0; k < 5; k++) t[k] = S4[(size_t)(pl[k] >= 0 ? pl[k] : 0) * 9 * F4 + idx];
         const f32x4 sf = S4[(size_t)fplane * 9 * F4 + idx];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const f32x4 u = v + t[k];
+            v = pl[k] >= 0 ? u : v;
+        }
         v += f32x4{fcd * sf[0], fcd * sf[1], fcd * sf[2], fcd * sf[3]};
-        pb4[(size_t)p * 9 * F4 + idx] = v;
+        if (idx0 + lane < 9 * F4) pb4[(size_t)p * 9 * F4 + idx] = v;
     }
 }
 // the 32 board-plane values of this lane's square as eight float quads (planes ≥ board_channels(n) are zero)

@@ -291,9 +291,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3(const voi
     if (CB) {
         const Geom geo = make_geom(n);
         const uint8_t* states = (const uint8_t*)in;
-        for (int p = wave; p < npos; p += NW) {
+        // a wave's positions are requested two at a time (tower_stage_states_cb, net_kernels.hip)
+        auto stage_one = [&](int p, const WRaw& raw) {
             WState ws;
-            ws_load(ws, states + (size_t)(pos0 + p) * geo.bytes, geo);
+            ws_unpack(ws, raw, geo);
             const float fcd = fcd_value(ws, geo);
             const RowMask m = ws_row_mask(ws, geo);
             if (lane < nsq) {
@@ -310,6 +311,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3(const voi
                 }
             }
             tower_cb_table(ws, fcd, n, p, T.F >> 2, (const f32x4*)T.cplane_sums, (const f32x4*)T.b[0], pb4);
+        };
+        for (int p = wave; p < npos; p += 2 * NW) {
+            const int p1 = p + NW;
+            const WRaw r0 = ws_load_raw(states + (size_t)(pos0 + p) * geo.bytes, geo);
+            const WRaw r1 = ws_load_raw(states + (size_t)(pos0 + (p1 < npos ? p1 : p)) * geo.bytes, geo);
+            stage_one(p, r0);
+            if (p1 < npos) stage_one(p1, r1);
         }
     } else if (FROM_STATES) {
         const Geom geo = make_geom(n);
@@ -511,9 +519,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
     if (CB) {
         const Geom geo = make_geom(n);
         const uint8_t* states = (const uint8_t*)in;
-        for (int p = wave; p < npos; p += NW) {
+        // a wave's positions are requested two at a time (tower_stage_states_cb, net_kernels.hip)
+        auto stage_one = [&](int p, const WRaw& raw) {
             WState ws;
-            ws_load(ws, states + (size_t)(pos0 + p) * geo.bytes, geo);
+            ws_unpack(ws, raw, geo);
             const float fcd = fcd_value(ws, geo);
             const RowMask m = ws_row_mask(ws, geo);
             if (lane < nsq) {
@@ -530,6 +539,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3_halo(cons
                 }
             }
             tower_cb_table(ws, fcd, n, p, F >> 2, (const f32x4*)T.cplane_sums, (const f32x4*)T.b[0], pb4);
+        };
+        for (int p = wave; p < npos; p += 2 * NW) {
+            const int p1 = p + NW;
+            const WRaw r0 = ws_load_raw(states + (size_t)(pos0 + p) * geo.bytes, geo);
+            const WRaw r1 = ws_load_raw(states + (size_t)(pos0 + (p1 < npos ? p1 : p)) * geo.bytes, geo);
+            stage_one(p, r0);
+            if (p1 < npos) stage_one(p1, r1);
         }
     } else if (FROM_STATES) {
         const Geom geo = make_geom(n);

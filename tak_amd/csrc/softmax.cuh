@@ -99,12 +99,17 @@ __device__ __forceinline__ void fc_block_stats(const softmax_f32x4 (&v)[TILES], 
     s_out = s;
 }
 
-// (M, 1/S) of a row from its per-block statistics stats[2b] = m_b, stats[2b + 1] = s_b; nblocks ≤ 64, every lane gets the result
+// (M, 1/S) of a row from its per-block statistics stats[2b] = m_b, stats[2b + 1] = s_b; nblocks ≤ 64; called by a whole wave with
+// a wave-uniform `stats`, every lane gets the result.  Lane b fetches block b's pair — ONE memory round trip; read one after
+// the other through a wave-uniform pointer the pairs became scalar loads in two loops, 12 round trips in a row on the tree
+// backup's critical path — and the sum runs over the lanes in block order, so the bits are those of the sequential loop.
 __device__ __forceinline__ void fc_combine_stats(const float* __restrict__ stats, int nblocks, float& mx_out, float& inv_out) {
-    float M = -INFINITY;
-    for (int b = 0; b < nblocks; b++) M = fmaxf(M, stats[2 * b]);
+    const int lane = threadIdx.x & 63;
+    const float2 ms = ((const float2*)stats)[lane < nblocks ? lane : 0];
+    const float M = wave_max(lane < nblocks ? ms.x : -INFINITY);
+    const float term = ms.y * stat_exp(ms.x - M);
     float S = 0.0f;
-    for (int b = 0; b < nblocks; b++) S += stats[2 * b + 1] * stat_exp(stats[2 * b] - M);
+    for (int b = 0; b < nblocks; b++) S += __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(term), b));
     mx_out = M;
     inv_out = 1.0f / S;
 }

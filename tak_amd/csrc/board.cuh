@@ -207,9 +207,13 @@ __device__ inline uint32_t ws_play(WState& s, uint32_t mv, const Geom& g) {
     bool swapped = s.ply < 2;
     uint32_t color = swapped ? (s.to_move ^ 1u) : s.to_move;
     if ((int)sq >= g.nsq) return TG_PLAY_OUT_OF_BOUNDS;
-    uint32_t src_h = (uint32_t)__shfl((int)s.height, (int)sq);
-    uint32_t src_top = (uint32_t)__shfl((int)s.top, (int)sq);
-    uint64_t src_stack = shfl64(s.stack, (int)sq);
+    // the move is wave-uniform: the source square's record comes by v_readlane, not through the LDS crossbar (four ds_bpermute
+    // round trips at the head of every move of every descent)
+    const int sql = (int)uni(sq);
+    uint32_t src_h = (uint32_t)__builtin_amdgcn_readlane((int)s.height, sql);
+    uint32_t src_top = (uint32_t)__builtin_amdgcn_readlane((int)s.top, sql);
+    uint64_t src_stack = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(s.stack >> 32), sql) << 32) |
+                         (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)s.stack, sql);
     if (pat == 0) {  // execute_place, game.rs:147-169
         uint32_t piece = f;
         if (piece > CAP) return TG_PLAY_OUT_OF_BOUNDS;
@@ -426,7 +430,7 @@ __device__ inline int ws_movegen(const WState& s, const Geom& g, int cap, F&& em
                 if (off + idx < cap) emit(off + idx, (uint32_t)sq | ((uint32_t)d << 6) | (pat << 8));
             });
         }
-        base += __shfl(incl, 63);
+        base += __builtin_amdgcn_readlane(incl, 63);  // (v_readlane: no LDS round trip)
     }
     return base;
 }

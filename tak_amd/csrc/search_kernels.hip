@@ -160,7 +160,11 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
     NodeCold pf_c;
     pf_h.prior = 0.0f; pf_h.q = 0.0f; pf_h.visits = 0; pf_h.virt = 0;
     pf_c.child = 0; pf_c.mv = 0; pf_c.nres = 0;
+    float c_pf = 0.0f;  // exploration_rate(visits + virtual) of the node about to be visited (mcts.rs:10-12), from the table
     auto prefetch_children = [&]() {
+        // (a vector load of one address: it returns with the children's records instead of on the scalar path in front of them)
+        const uint32_t tn = vis + vv;
+        c_pf = S.ctab[tn < (uint32_t)S.ctab_size ? tn : (uint32_t)S.ctab_size - 1u];
         if ((vis | vv) != 0u && (nres >> 12) == TG_ONGOING && (uint32_t)lane < (nres & 0xfffu)) {
             pf_h = hot[cbase + (uint32_t)lane];
             pf_c = cold[cbase + (uint32_t)lane];
@@ -245,7 +249,7 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
             }
             ti = (uint32_t)S.ctab_size - 1;
         }
-        const float c_rate = S.ctab[ti];
+        const float c_rate = c_pf;  // = S.ctab[ti], requested with the children
         const float root_n = sqrtf(visit_count);
         float best = -INFINITY;
         int best_i = -1;
@@ -265,14 +269,23 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
             if (u != u) nan = true;
             if (u >= best) { best = u; best_i = (int)i; bh = ch; bc = cc; }
         }
+        // the wave's best (value, index): the largest pair under (value, then index) — `max_by` keeps the LAST maximum
+        // (mcts.rs:107-117).  Six DPP steps (row_shr 1, 2, 4, 8, row_bcast15, row_bcast31: an inclusive max-scan whose lane 63
+        // holds the total) instead of six butterfly rounds of two ds_bpermute each — 12 trips through the LDS crossbar, one after
+        // the other, at every level of every descent.  The order of a total order's maximum does not matter: same winner.
         float wb = best;
         int wi = best_i;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            float ob = __shfl_xor(wb, d);
-            int oi = __shfl_xor(wi, d);
-            if (ob > wb || (ob == wb && oi > wi)) { wb = ob; wi = oi; }
+#define TG_ARGMAX_STEP(CTRL, ROWS)                                                                                               \
+        {                                                                                                                        \
+            const float ob = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-INFINITY), __float_as_int(wb), CTRL, ROWS, 0xf, false)); \
+            const int oi = __builtin_amdgcn_update_dpp(-1, wi, CTRL, ROWS, 0xf, false);                                        \
+            if (ob > wb || (ob == wb && oi > wi)) { wb = ob; wi = oi; }                                                          \
         }
+        TG_ARGMAX_STEP(0x111, 0xf) TG_ARGMAX_STEP(0x112, 0xf) TG_ARGMAX_STEP(0x114, 0xf) TG_ARGMAX_STEP(0x118, 0xf)
+        TG_ARGMAX_STEP(0x142, 0xa) TG_ARGMAX_STEP(0x143, 0xc)
+#undef TG_ARGMAX_STEP
+        wb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wb), 63));
+        wi = __builtin_amdgcn_readlane(wi, 63);
         if (__ballot(nan)) flag(S, ERRF_NAN);
         if (wi < 0) {  // cannot happen for a consistent tree; never index out of the arena
             flag(S, ERRF_NAN);
@@ -282,11 +295,11 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
         // the winning lane (the one whose own best is the wave's best) hands its child's records down
         const int src = __builtin_ctzll(__ballot(best_i == wi));
         const uint32_t chosen = cbase + (uint32_t)wi;
-        const uint32_t mv = uni((uint32_t)__shfl((int)(uint32_t)bc.mv, src));
-        vis = uni((uint32_t)__shfl((int)bh.visits, src));
-        vv = uni((uint32_t)__shfl((int)bh.virt, src));
-        nres = uni((uint32_t)__shfl((int)(uint32_t)bc.nres, src));
-        cbase = uni((uint32_t)__shfl((int)bc.child, src));
+        const uint32_t mv = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bc.mv, src);  // (v_readlane: no LDS round trip)
+        vis = (uint32_t)__builtin_amdgcn_readlane((int)bh.visits, src);
+        vv = (uint32_t)__builtin_amdgcn_readlane((int)bh.virt, src);
+        nres = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bc.nres, src);
+        cbase = (uint32_t)__builtin_amdgcn_readlane((int)bc.child, src);
         TG_TSTAMP(g, 5 + 2 * (depth < 9 ? depth : 9));  // children scanned, best child known
         prefetch_children();  // of the chosen child, under the play of its move
         ws_play(s, mv, geo);

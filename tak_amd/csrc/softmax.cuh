@@ -12,10 +12,15 @@ __device__ inline float wave_sum(float v) {
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
     return v;
 }
+// (the maximum does not depend on the order: six DPP steps — an inclusive max-scan, lane 63 holds the total — and a v_readlane
+// instead of six ds_bpermute round trips; wave_sum keeps its butterfly: its association order is part of the softmax's bits)
 __device__ inline float wave_max(float v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
-    return v;
+#define TG_WMAX_STEP(CTRL, ROWS) \
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-INFINITY), __float_as_int(v), CTRL, ROWS, 0xf, false)));
+    TG_WMAX_STEP(0x111, 0xf) TG_WMAX_STEP(0x112, 0xf) TG_WMAX_STEP(0x114, 0xf) TG_WMAX_STEP(0x118, 0xf)
+    TG_WMAX_STEP(0x142, 0xa) TG_WMAX_STEP(0x143, 0xc)
+#undef TG_WMAX_STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 constexpr int SOFTMAX_KEEP = 8;  // elements per thread of the 256-thread block: rows up to 2048 outputs stay in registers

@@ -115,7 +115,7 @@ struct RootPre {
     bool on = false, hot_known = false;
     uint32_t root = 0, vis = 0, vv = 0;
     NodeCold cold;
-    WState state;
+    WRaw raw;  // the packed root position as requested (ws_load_raw); unpacked by the select
 };
 
 template <int NB>
@@ -131,7 +131,7 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
     }
     const Geom geo = make_geom(NB ? NB : S.n);
     WState s;
-    if (pre.on) s = pre.state;
+    if (pre.on) ws_unpack(s, pre.raw, geo);
     else ws_load(s, S.root_state + (size_t)g * geo.bytes, geo);
     NodeHot* hot = S.hot;
     NodeCold* cold = S.cold;
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __re
 // walked path → leaf → children's moves → index table → logits, five dependent round trips (19 k of the wave's 56 k cycles).
 // Returns through `pre` the root's (visits, virtual) as this backup leaves them, for the select that follows in the same launch.
 template <int NB>
-__device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, const int pass, const uint32_t root, RootPre* pre = nullptr) {
+__device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, const int pass, const uint32_t root_v, RootPre* pre = nullptr) {
     const size_t slot = (size_t)g * (size_t)S.batch + (size_t)pass;
     const int lane = lane_id();
     NodeHot* hot = S.hot;
@@ -398,6 +398,10 @@ __device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, con
     const uint32_t raw_idx = (uint32_t)pidx[lane];
     const uint32_t raw_nd = path[lane ? lane - 1 : 0];
     const float vlogit_v = (S.evaluator == TG_EVAL_RESNET && lrow) ? lrow[S.P] : 0.0f;
+    // root_v = S.root[g] as the caller requested it, not yet waited for: it was the first request, so making it scalar here
+    // waits for that one load alone, and the select's cold record of the root joins the requests above
+    const uint32_t root = uni(root_v);
+    if (pre) { pre->root = root; pre->cold = S.cold[root]; }
     const bool live = uni(kind_v) == 1u;
     const int L = (int)uni(len_v);
     const uint32_t cb = uni(cb_v), nchild = uni(n_v);
@@ -458,7 +462,7 @@ __global__ __launch_bounds__(256) void k_backup(SearchDev S) {
     if (g >= S.G) return;
     const int p0 = S.pass < 0 ? 0 : S.pass, p1 = S.pass < 0 ? S.batch : S.pass + 1;
     for (int p = p0; p < p1; p++) {
-        backup_pass<NB>(S, g, p, uni(S.root[g]));
+        backup_pass<NB>(S, g, p, S.root[g]);
         if (p + 1 < p1) wave_sync_mem();
     }
 }
@@ -475,13 +479,13 @@ __global__ __launch_bounds__(256) void k_backup_select(SearchDev S) {
     TG_TSTAMP(g, 0);
     // what the select needs of the root and the backup does not write is requested before the backup: the root's index, its
     // cold record and the packed root position arrive under the backup's own round trips
+    // (requested, none of them waited for: the first wait is inside the backup, behind its own independent requests)
     RootPre pre;
-    pre.root = uni(S.root[g]);
+    const uint32_t root_v = S.root[g];
     const Geom geo = make_geom(NB ? NB : S.n);
-    ws_load(pre.state, S.root_state + (size_t)g * geo.bytes, geo);
-    pre.cold = S.cold[pre.root];
+    pre.raw = ws_load_raw(S.root_state + (size_t)g * geo.bytes, geo);
     pre.on = true;
-    backup_pass<NB>(S, g, 0, pre.root, &pre);
+    backup_pass<NB>(S, g, 0, root_v, &pre);
     wave_sync_mem();
     TG_TSTAMP(g, 3);  // path updated
     select_pass<NB>(S, nullptr, g, 0, path_lds[threadIdx.x >> 6], mv_lds[threadIdx.x >> 6], pre);

@@ -343,6 +343,53 @@ __device__ inline int spread_count(int max_carry, int free_run, bool smash) {
     return T.c[max_carry][free_run][smash ? 1 : 0];
 }
 
+// The same enumeration as a bit mask, for boards up to 6×6 (pickups up to 6: 63 candidates).  Candidate b = 2^(k-1) - 1 + v is
+// pickup k with drop pattern v in enum_spreads' order, so bit order = emission order; LE[f] holds the candidates in at most f
+// parts, SM[f] those in exactly f + 1 parts whose last part is one stone (a cap flattening the wall behind f free squares).
+// The patterns a (square, direction) emits are the set bits of (LE[free_run] | smash·SM[free_run]) below candidate 2^max_carry - 1:
+// their number is a popcount (no table in memory) and the enumeration visits only the patterns it emits — enum_spreads walks
+// all 2^max_carry - 1 candidates in every lane, the slowest lane setting the pace of the wave (a third of the tree kernel's
+// move generation).
+struct SpreadMasks {
+    uint64_t le[8], sm[8];
+    constexpr SpreadMasks() : le(), sm() {
+        for (int f = 0; f < 8; f++) {
+            uint64_t a = 0, c = 0;
+            for (int b = 0; b < 63; b++) {
+                int b1 = b + 1, k = 0;
+                while ((1 << k) <= b1) k++;  // b1 has k bits
+                const int v = b1 - (1 << (k - 1));
+                int parts = 1;
+                for (int t = v; t; t >>= 1) parts += t & 1;
+                if (parts <= f) a |= 1ull << b;
+                if (parts == f + 1 && (k == 1 || (v & 1))) c |= 1ull << b;
+            }
+            le[f] = a;
+            sm[f] = c;
+        }
+    }
+};
+__device__ inline uint64_t spread_mask(int max_carry, int free_run, bool smash) {
+    constexpr SpreadMasks M{};
+    // (selected by compares on constants: free_run ≤ 5 on a 6×6 board)
+    const int f = free_run;
+    const uint64_t le = f <= 0 ? M.le[0] : f == 1 ? M.le[1] : f == 2 ? M.le[2] : f == 3 ? M.le[3] : f == 4 ? M.le[4] : f == 5 ? M.le[5] : M.le[6];
+    const uint64_t sm = f <= 0 ? M.sm[0] : f == 1 ? M.sm[1] : f == 2 ? M.sm[2] : f == 3 ? M.sm[3] : f == 4 ? M.sm[4] : f == 5 ? M.sm[5] : M.sm[6];
+    const uint64_t below = (1ull << ((1u << max_carry) - 1u)) - 1ull;  // candidates of pickups 1 … max_carry (≤ 6: ≤ 63 bits)
+    return (le | (smash ? sm : 0ull)) & below;
+}
+template <class F>
+__device__ inline void enum_spread_mask(uint64_t m, F&& emit) {
+    int idx = 0;
+    while (m) {
+        const int b1 = __builtin_ctzll(m) + 1;
+        m &= m - 1ull;
+        const int k = 32 - __builtin_clz((unsigned)b1);
+        const uint32_t v = (uint32_t)b1 - (1u << (k - 1));
+        emit(idx++, ((v << 1) | 1u) << (8 - k));
+    }
+}
+
 // Inclusive prefix sum over the 64 lanes with DPP adds (six v_add with a data-parallel-primitive operand: row_shr 1, 2, 4, 8
 // inside the rows of 16 lanes, then row_bcast15 / row_bcast31 carry the row totals on) instead of six ds_bpermute round trips
 // through the LDS crossbar with a select each.  Lanes that receive nothing add the identity 0 (`old` of update_dpp).
@@ -412,7 +459,11 @@ __device__ inline int ws_movegen(const WState& s, const Geom& g, int cap, F&& em
         int cnt = 0;
         if (kind == 1) cnt = 1;
         else if (kind == 2) cnt = (stones > 0 ? 2 : 0) + (caps > 0 ? 1 : 0);
-        else if (kind == 3) cnt = spread_count(max_carry, free_run, smash);
+        uint64_t smask = 0;
+        if (kind == 3) {
+            if (n <= 6) { smask = spread_mask(max_carry, free_run, smash); cnt = __popcll(smask); }
+            else cnt = spread_count(max_carry, free_run, smash);
+        }
         int incl = wave_inclusive_scan(cnt);
         int off = base + incl - cnt;
         if (kind == 1) {
@@ -426,9 +477,11 @@ __device__ inline int ws_movegen(const WState& s, const Geom& g, int cap, F&& em
             }
             if (caps > 0 && o < cap) emit(o, (uint32_t)sq | (CAP << 6));
         } else if (kind == 3) {
-            enum_spreads(max_carry, free_run, smash, [&](int idx, uint32_t pat) {
+            auto put = [&](int idx, uint32_t pat) {
                 if (off + idx < cap) emit(off + idx, (uint32_t)sq | ((uint32_t)d << 6) | (pat << 8));
-            });
+            };
+            if (n <= 6) enum_spread_mask(smask, put);
+            else enum_spreads(max_carry, free_run, smash, put);
         }
         base += __builtin_amdgcn_readlane(incl, 63);  // (v_readlane: no LDS round trip)
     }

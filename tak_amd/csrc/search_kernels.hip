@@ -116,6 +116,7 @@ struct RootPre {
     uint32_t root = 0, vis = 0, vv = 0;
     NodeCold cold;
     WRaw raw;  // the packed root position as requested (ws_load_raw); unpacked by the select
+    uint32_t alive_v = 1, abort_v = 0;  // S.alive[g], S.abort[g] (neither changes between the request and the select)
 };
 
 template <int NB>
@@ -125,10 +126,18 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
     // leaf slot of this pass: `batch` virtual rollouts per tree and iteration (Player's batching, player.rs:77-93), pass p
     // writing slot g·batch + p
     const size_t slot = (size_t)g * (size_t)S.batch + (size_t)pass;
-    if (!S.alive[g] || (active && !active[g]) || (S.retire && S.abort[g])) {
-        if (lane == 0) S.leaf_kind[slot] = 0;
-        return;
+    {
+        // (both flags and the game's allocation cursor are requested together; read one after the other behind `||` they were
+        // two round trips in a row in front of the descent)
+        const uint32_t alive_v = pre.on ? pre.alive_v : (uint32_t)S.alive[g];
+        const uint32_t abort_v = pre.on ? pre.abort_v : (uint32_t)S.abort[g];
+        if (!uni(alive_v) || (active && !active[g]) || (S.retire && uni(abort_v))) {
+            if (lane == 0) S.leaf_kind[slot] = 0;
+            return;
+        }
     }
+    // the open chunk of the game's node allocation, needed only if this descent expands a leaf: requested now, it is there by then
+    const uint32_t alloc_a = S.alloc[2 * g], alloc_e = S.alloc[2 * g + 1];
     const Geom geo = make_geom(NB ? NB : S.n);
     WState s;
     if (pre.on) ws_unpack(s, pre.raw, geo);
@@ -187,7 +196,7 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
                     if (lane == 0) S.leaf_kind[slot] = 0;
                     return;
                 }
-                uint32_t a = uni(S.alloc[2 * g]), end = uni(S.alloc[2 * g + 1]);
+                uint32_t a = uni(alloc_a), end = uni(alloc_e);
                 if (a + count > end) {  // the block does not fit into the game's open chunk: take the next one
                     const uint32_t c = pool_take(S);
                     if (c == 0) {
@@ -484,6 +493,8 @@ __global__ __launch_bounds__(256) void k_backup_select(SearchDev S) {
     const uint32_t root_v = S.root[g];
     const Geom geo = make_geom(NB ? NB : S.n);
     pre.raw = ws_load_raw(S.root_state + (size_t)g * geo.bytes, geo);
+    pre.alive_v = (uint32_t)S.alive[g];
+    pre.abort_v = (uint32_t)S.abort[g];
     pre.on = true;
     backup_pass<NB>(S, g, 0, root_v, &pre);
     wave_sync_mem();

@@ -165,10 +165,11 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
     // The records of the first 64 children of the node about to be visited are requested as soon as its children block is
     // known — for the root here, for every later level right before the move is played on the wave's position — so that the
     // round trip of the children scan passes under ws_play instead of after it.
-    NodeHot pf_h;
-    NodeCold pf_c;
+    NodeHot pf_h, pf_h2;   // children lane and lane + 64 (the opening's 70-odd placements do not fit one round of the scan)
+    NodeCold pf_c, pf_c2;
     pf_h.prior = 0.0f; pf_h.q = 0.0f; pf_h.visits = 0; pf_h.virt = 0;
     pf_c.child = 0; pf_c.mv = 0; pf_c.nres = 0;
+    pf_h2 = pf_h; pf_c2 = pf_c;
     float c_pf = 0.0f;  // exploration_rate(visits + virtual) of the node about to be visited (mcts.rs:10-12), from the table
     auto prefetch_children = [&]() {
         // (a vector load of one address: it returns with the children's records instead of on the scalar path in front of them)
@@ -177,6 +178,10 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
         if ((vis | vv) != 0u && (nres >> 12) == TG_ONGOING && (uint32_t)lane < (nres & 0xfffu)) {
             pf_h = hot[cbase + (uint32_t)lane];
             pf_c = cold[cbase + (uint32_t)lane];
+            if ((uint32_t)lane + 64u < (nres & 0xfffu)) {
+                pf_h2 = hot[cbase + (uint32_t)lane + 64u];
+                pf_c2 = cold[cbase + (uint32_t)lane + 64u];
+            }
         }
     };
     prefetch_children();
@@ -270,7 +275,8 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
         for (uint32_t i = lane; i < nchild; i += 64) {
             NodeHot ch;
             NodeCold cc;
-            if (i == (uint32_t)lane) { ch = pf_h; cc = pf_c; }  // the first 64 children were requested a level ago
+            if (i == (uint32_t)lane) { ch = pf_h; cc = pf_c; }  // the first 128 children were requested a level ago
+            else if (i == (uint32_t)lane + 64u) { ch = pf_h2; cc = pf_c2; }
             else { ch = hot[cbase + i]; cc = cold[cbase + i]; }
             float cn = (float)(ch.visits + ch.virt);
             float qv = (ch.visits | ch.virt) ? (ch.q * (float)ch.visits - (float)ch.virt) / cn : 0.0f;
@@ -404,7 +410,7 @@ __device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, con
     const uint32_t kind_v = (uint32_t)S.leaf_kind[slot];
     const uint32_t len_v = (uint32_t)S.path_len[slot];
     const uint32_t cb_v = S.leaf_rec[2 * slot], n_v = S.leaf_rec[2 * slot + 1];
-    const uint32_t raw_idx = (uint32_t)pidx[lane];
+    const uint32_t raw_idx = (uint32_t)pidx[lane], raw_idx2 = (uint32_t)pidx[lane + 64];  // (EX_MOVES ≥ 128 entries per slot)
     const uint32_t raw_nd = path[lane ? lane - 1 : 0];
     const float vlogit_v = (S.evaluator == TG_EVAL_RESNET && lrow) ? lrow[S.P] : 0.0f;
     // root_v = S.root[g] as the caller requested it, not yet waited for: it was the first request, so making it scalar here
@@ -433,7 +439,7 @@ __device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, con
     // round 2: priors of the leaf's children (devirtualize_path, mcts.rs:80-84)
     bool bad = false;
     for (uint32_t i = lane; i < nchild; i += 64) {
-        const uint32_t idx = i == (uint32_t)lane ? my_idx : (uint32_t)pidx[i];
+        const uint32_t idx = i == (uint32_t)lane ? my_idx : i == (uint32_t)lane + 64u ? raw_idx2 : (uint32_t)pidx[i];
         float p;
         if (idx == 0xFFFFu) { bad = true; p = 0.0f; }
         else if (S.evaluator == TG_EVAL_RESNET) p = !lrow ? pol[idx] : S.fc_stats ? stat_exp(lrow[idx] - lmx) * linv : expf(lrow[idx] - lmx) * linv;

@@ -336,15 +336,22 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
     const uint32_t wcolor = (res == TG_WHITE_ROAD || res == TG_WHITE_FLAT) ? 0u : 1u;
     for (int d = lane; d <= depth; d += 64) {
         uint32_t nd = d == 0 ? root : path[d - 1];
-        NodeHot h = hot[nd];
-        if (terminal) {
-            uint32_t curr = root_color ^ (uint32_t)(d & 1);
-            float reward = winner ? (wcolor == curr ? -1.0f : 1.0f) : 0.0f;
-            update_concrete(h, reward);
+        if (!terminal && S.batch == 1) {
+            // virtual_visits += 1 as a returnless atomic: nothing to wait for (the record's load and store were a round trip
+            // in front of the leaf's stores); the tree belongs to this wave alone.  Only with one rollout per launch: the atomic
+            // is performed in L2, and a second pass of the same wave would read the record through its L1
+            __hip_atomic_fetch_add(&hot[nd].virt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            h.virt += 1;
+            NodeHot h = hot[nd];
+            if (terminal) {
+                uint32_t curr = root_color ^ (uint32_t)(d & 1);
+                float reward = winner ? (wcolor == curr ? -1.0f : 1.0f) : 0.0f;
+                update_concrete(h, reward);
+            } else {
+                h.virt += 1;
+            }
+            hot[nd] = h;
         }
-        hot[nd] = h;
     }
     TG_TSTAMP(g, 28);  // virtual visits marked
     uint32_t* gpath = S.path + slot * MAX_DEPTH;
@@ -363,8 +370,8 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
     if (lane == 0) {
         S.path_len[slot] = depth;
         S.leaf_kind[slot] = terminal ? 2 : 1;
-        S.counters[2 * (size_t)g] += 1ull;
-        if (!terminal) S.counters[2 * (size_t)g + 1] += 1ull;
+        __hip_atomic_fetch_add(&S.counters[2 * (size_t)g], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (returnless: no round trip)
+        if (!terminal) __hip_atomic_fetch_add(&S.counters[2 * (size_t)g + 1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -213,6 +213,53 @@ class Watchdog:
         return False
 
 
+def run_c5_phase(args, rank, world, out, phase, want_result=False):
+    """Config C5's phase — the only part of the bench with a data-path collective — under the rules that keep a bad day
+    visible: an exception is caught (rank 0's headline line survives, marked `train_c5_failed`), and at N > 1 a watchdog bounds
+    the phase: if a collective never completes, rank 0 prints the line it has (marked) and EVERY rank leaves with
+    EXIT_C5_FAILED straight from the timer thread (os._exit: a fresh exit, nothing is exec'ed).  → (out, failed[, result])"""
+    def give_up():
+        print(f"bench.py: rank {rank}: the C5 phase did not finish within {args.train_timeout:.0f} s", file=sys.stderr, flush=True)
+        if rank == 0 and out is not None:
+            out["train_c5_failed"] = True
+            out.setdefault("extra", {})["train_c5"] = {"error": f"timed out after {args.train_timeout:.0f} s (world {world})"}
+            print(json.dumps(out), flush=True)
+
+    failed = False
+    try:
+        if world > 1:
+            # (rank 0 first, so that its line is out before the launcher sees another rank's exit code and ends the rest)
+            with Watchdog(args.train_timeout + (0.0 if rank == 0 else 15.0), give_up, EXIT_C5_FAILED):
+                c5 = phase()
+        else:
+            c5 = phase()
+    except Exception as ex:
+        if args.train:
+            raise
+        c5, failed = {"error": repr(ex)}, True
+        print(f"bench.py: rank {rank}: config C5 failed: {ex!r}", file=sys.stderr, flush=True)
+    if rank == 0 and out is not None and not args.train:
+        out.setdefault("extra", {})["train_c5"] = c5
+        if failed:
+            out["train_c5_failed"] = True
+    return (out, failed, c5) if want_result else (out, failed)
+
+
+def finish(rank, world, out, c5_failed, dist):
+    """rank 0 prints THE line; then a clean shutdown — or, if config C5 failed at N > 1, a non-zero exit on every rank (the
+    headline is out, but a data-parallel run whose collective phase failed must not look green)"""
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if c5_failed and world > 1:
+        sys.stdout.flush()
+        if rank != 0:
+            time.sleep(3.0)  # rank 0's line first: the launcher ends the other ranks at the first non-zero exit
+        os._exit(EXIT_C5_FAILED)  # (no destroy_process_group: the other ranks may be gone)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+EXIT_C5_FAILED = 4  # N > 1: the C5 phase (the only collective data path) hung or raised; the headline line was still printed
 C5_FLOPS_FWD = 161_689_600  # SURVEY.md §8(d): 5x5, 10 blocks x 128 filters, FC-1575 head, 2·MAC per position (forward)
 
 
@@ -230,11 +277,19 @@ def train_c5(args, rank, world, local_rank, dist, backend, barrier_fn):
 
     n, blocks, filters = 5, args.train_blocks, args.train_filters
     games = args.train_games
-    net, weights = make_weights(n, blocks, filters, "fc5", seed=args.seed)  # the same weights on every rank
-    eng = tak_amd.Engine(n, res_blocks=blocks, filters=filters, policy_head=tak_amd.HEAD_FC5, evaluator=tak_amd.EVAL_RESNET,
-                         max_batch=games, device=local_rank)
-    eng.load_state_dict(weights)
-    eng.train_create(chunk_size=args.train_chunk, chunks_in_step=args.train_chunks_in_step)
+    dev = "cuda" if backend == "nccl" else "cpu"
+
+    stage = tdist.Stages(dist, rank, dev).run  # rank-local work, then all ranks agree that it succeeded everywhere
+
+    def setup():
+        net, weights = make_weights(n, blocks, filters, "fc5", seed=args.seed)  # the same weights on every rank
+        e = tak_amd.Engine(n, res_blocks=blocks, filters=filters, policy_head=tak_amd.HEAD_FC5, evaluator=tak_amd.EVAL_RESNET,
+                           max_batch=games, device=local_rank)
+        e.load_state_dict(weights)
+        e.train_create(chunk_size=args.train_chunk, chunks_in_step=args.train_chunks_in_step)
+        return e
+
+    eng = stage("engine setup", setup)
     transport = "single rank"
     if world > 1:
         if backend == "nccl":
@@ -245,34 +300,51 @@ def train_c5(args, rank, world, local_rank, dist, backend, barrier_fn):
             eng.train_set_allreduce(tdist.host_allreduce_hook(dist), world)
             transport = f"host all-reduce through torch.distributed/{backend} (ranks share a card)"
 
+    def communicator():
+        info = eng.train_comm_info()
+        # what RCCL itself says, checked on every rank: a communicator that saw fewer ranks than the launcher started would
+        # still "work" (and train on a fraction of the examples)
+        if world > 1 and backend == "nccl" and (info["nccl_count"] != world or info["nccl_rank"] != rank):
+            raise RuntimeError(f"rank {rank}: RCCL communicator reports {info['nccl_count']} ranks / rank {info['nccl_rank']}, expected {world} / {rank}")
+        return info
+
+    rccl = stage("communicator check", communicator)
+
     # 1. self-play on the C5 network at the headline search settings (2 plies timed after 1 warm-up ply)
-    eng.selfplay_create(games, arena_nodes=args.arena, seed=args.seed, rollouts=args.rollouts, max_examples=1 << 14,
-                        slot_base=tdist.slot_base(rank, games))
-    eng.selfplay_step(1)
-    barrier_fn(eng)
-    s0 = eng.selfplay_stats()
-    t0 = time.perf_counter()
-    eng.selfplay_step(2)
-    eng.sync()
-    dt_sp_local = time.perf_counter() - t0
-    barrier_fn(eng)
-    sp_exp = eng.selfplay_stats()["expansions"] - s0["expansions"]
-    dt_sp, sp_total = tdist.reduce_time_and_count(dist, dt_sp_local, sp_exp, device="cuda" if backend == "nccl" else "cpu")
+    def warm_up():
+        eng.selfplay_create(games, arena_nodes=args.arena, seed=args.seed, rollouts=args.rollouts, max_examples=1 << 14,
+                            slot_base=tdist.slot_base(rank, games))
+        eng.selfplay_step(1)
+        eng.sync()
+        return eng.selfplay_stats()
+
+    def two_plies():
+        t0 = time.perf_counter()
+        eng.selfplay_step(2)
+        eng.sync()
+        return time.perf_counter() - t0, eng.selfplay_stats()["expansions"]
+
+    s0 = stage("self-play warm-up", warm_up)
+    dt_sp_local, exp1 = stage("timed self-play", two_plies)
+    dt_sp, sp_total = tdist.reduce_time_and_count(dist, dt_sp_local, exp1 - s0["expansions"], device=dev)
 
     # 2. examples for the training step: the same network at a few rollouts per move until every rank holds enough
     need = args.train_steps * args.train_chunk * args.train_chunks_in_step
-    eng.selfplay_create(games, arena_nodes=1 << 12, seed=args.seed + 1, rollouts=args.train_example_rollouts,
-                        max_examples=max(1 << 16, 4 * need), slot_base=tdist.slot_base(rank, games))
-    got = None
-    t_gen = time.perf_counter()
-    while got is None or len(got[0]) < need:
-        eng.selfplay_step(8)
-        new = eng.selfplay_drain(2 * need)
-        got = new if got is None else [np.concatenate([a, b]) for a, b in zip(got, new)]
-        if time.perf_counter() - t_gen > 120:
-            raise RuntimeError(f"example generation: {len(got[0])} of {need} examples after 120 s")
-    t_gen = time.perf_counter() - t_gen
-    hdr, states, moves, visits = [a[:need] for a in got]
+
+    def examples():
+        eng.selfplay_create(games, arena_nodes=1 << 12, seed=args.seed + 1, rollouts=args.train_example_rollouts,
+                            max_examples=max(1 << 16, 4 * need), slot_base=tdist.slot_base(rank, games))
+        got = None
+        t_gen = time.perf_counter()
+        while got is None or len(got[0]) < need:
+            eng.selfplay_step(8)
+            new = eng.selfplay_drain(2 * need)
+            got = new if got is None else [np.concatenate([a, b]) for a, b in zip(got, new)]
+            if time.perf_counter() - t_gen > 120:
+                raise RuntimeError(f"example generation: {len(got[0])} of {need} examples after 120 s")
+        return time.perf_counter() - t_gen, [a[:need] for a in got]
+
+    t_gen, (hdr, states, moves, visits) = stage("example generation", examples)
 
     # 3. the training step(s), timed
     barrier_fn(eng)
@@ -281,13 +353,12 @@ def train_c5(args, rank, world, local_rank, dist, backend, barrier_fn):
     eng.sync()
     dt_local = time.perf_counter() - t0
     barrier_fn(eng)
-    dt, positions = tdist.reduce_time_and_count(dist, dt_local, need * 8, device="cuda" if backend == "nccl" else "cpu")
+    dt, positions = tdist.reduce_time_and_count(dist, dt_local, need * 8, device=dev)
     ar_ms, ar_n = eng.train_comm_stats()
     # identical parameters on every rank after the all-reduced steps
     w = eng.train_get_tensor("value.weight", (1, filters * n * n))
     same = True
     if dist is not None:
-        dev = "cuda" if backend == "nccl" else "cpu"
         t = torch.from_numpy(w).to(dev)
         lo, hi = t.clone(), t.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
@@ -303,7 +374,10 @@ def train_c5(args, rank, world, local_rank, dist, backend, barrier_fn):
         "positions_per_rank": need * 8, "loss_p": lp, "loss_z": lz,
         "frac_of_f32_mfma_peak": (per_gpu * flops / 1e12 / F32_MFMA_PEAK_TFLOPS) if flops else None,
         "gradient_allreduce": {"transport": transport, "bytes": None if world == 1 else int(eng_param_bytes(blocks, filters, n)),
-                               "count": ar_n, "ms_per_step_rank0": (ar_ms / ar_n) if ar_n else 0.0},
+                               "count": ar_n, "ms_per_step_rank0": (ar_ms / ar_n) if ar_n else 0.0,
+                               # rank 0's view of the communicator (every rank checked its own above): ncclCommCount,
+                               # ncclCommUserRank, ncclGetVersion, and the file ncclAllReduce was bound from
+                               "rccl": rccl},
         "parameters_identical_on_all_ranks": same,
         "selfplay_c5net": {"value": sp_total / dt_sp, "unit": "node-expansions/s", "ms_per_step": 1000.0 * dt_sp / 2,
                            "games_per_gpu": games, "sims_per_move": args.rollouts},
@@ -361,10 +435,17 @@ def main():
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="launcher plumbing only, for machines without a GPU: rendezvous, barrier and the max / sum reductions "
                          "of the N ranks, no engine, no measurement ('value' is null)")
+    ap.add_argument("--rehearse-hang-rank", type=int, default=-1,
+                    help="with --rehearse-launch: this rank never joins the rehearsed collective (the watchdog must end the run, non-zero)")
+    ap.add_argument("--rehearse-fail-rank", type=int, default=-1,
+                    help="with --rehearse-launch: this rank raises before the rehearsed collective (every rank must leave at once, non-zero)")
     args = ap.parse_args()
 
     from tak_amd import dist as tdist
 
+    # dmabuf IPC (RCCL between processes needs it on this driver): set before anything initialises the GPU, so the ranks behave
+    # the same whether launch_ranks or torch.distributed.run started them
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "RANK" not in os.environ:
         # invoked directly: become the launcher (before anything in this process touches the GPU)
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
@@ -380,9 +461,25 @@ def main():
         if dist is not None:
             dist.barrier()
         dt, total = tdist.reduce_time_and_count(dist, 1.0 + rank, 1 + rank)
+        out = {"metric": "launcher rehearsal (no measurement)", "value": None, "unit": "node-expansions/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "rehearsal": True, "max_over_ranks": dt, "sum_over_ranks": total}
+        if args.rehearse_hang_rank >= 0 or args.rehearse_fail_rank >= 0:
+            # the two ways config C5 can go wrong at N > 1, acted out with the code the real phase uses: a rank that fails before
+            # the collective (Stages: every rank leaves, nobody waits) and a collective that never completes (Watchdog)
+            def phase():
+                def local():
+                    if rank == args.rehearse_fail_rank:
+                        raise RuntimeError("rehearsed local failure")
+                tdist.Stages(dist, rank).run("rehearsed stage", local)
+                if rank == args.rehearse_hang_rank:
+                    time.sleep(3600.0)
+                tdist.reduce_min(dist, 1.0)  # the "gradient all-reduce" the hanging rank never joins
+                return {"rehearsed": True}
+            out, c5_failed = run_c5_phase(args, rank, world, out if rank == 0 else None, phase)
+            finish(rank, world, out, c5_failed, dist)
+            return
         if rank == 0:
-            print(json.dumps({"metric": "launcher rehearsal (no measurement)", "value": None, "unit": "node-expansions/s", "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "rehearsal": True, "max_over_ranks": dt, "sum_over_ranks": total}), flush=True)
+            print(json.dumps(out), flush=True)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -545,23 +642,9 @@ def main():
                     extras["error"] = repr(ex)
                 out["extra"] = extras
     # config C5 on every rank (the only part of the bench with a data-path collective)
+    c5_failed = False
     if args.train or not (args.no_train or args.no_extras or args.precision != "f32"):
-        def give_up():
-            print(f"bench.py: rank {rank}: the C5 phase did not finish within {args.train_timeout:.0f} s", file=sys.stderr, flush=True)
-            if rank == 0 and out is not None:
-                out.setdefault("extra", {})["train_c5"] = {"error": f"timed out after {args.train_timeout:.0f} s (world {world})"}
-                print(json.dumps(out), flush=True)
-
-        try:
-            if world > 1:
-                with Watchdog(args.train_timeout, give_up, 0 if out is not None or rank != 0 else 3):
-                    c5 = train_c5(args, rank, world, local_rank, dist, backend, barrier)
-            else:
-                c5 = train_c5(args, rank, world, local_rank, dist, backend, barrier)
-        except Exception as ex:
-            if args.train:
-                raise
-            c5 = {"error": repr(ex)}
+        out, c5_failed, c5 = run_c5_phase(args, rank, world, out, lambda: train_c5(args, rank, world, local_rank, dist, backend, barrier), want_result=True)
         if rank == 0 and args.train:
             out = {
                 "metric": c5["metric"], "value": c5["value"], "unit": c5["unit"], "n_gpus": world, "steps": c5["optimizer_steps"], "warmup": 0,
@@ -573,17 +656,13 @@ def main():
                              "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": c5["frac_of_f32_mfma_peak"], "traffic": None},
                 "train_c5": c5,
             }
-        elif rank == 0:
-            out.setdefault("extra", {})["train_c5"] = c5
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and not args.train:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, net)
             except Exception as ex:  # the checker failing must not hide the GPU number
                 out["cpu_baseline"] = {"error": repr(ex)}
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    finish(rank, world, out, c5_failed, dist)
 
 
 if __name__ == "__main__":

@@ -468,6 +468,23 @@ int tg_train_grad_buffer(TgEngine* e, float** d_grads, size_t* count);
  * milliseconds and their number since tg_train_create.  Zero reductions on a single-rank trainer. */
 int tg_train_comm_stats(TgEngine* e, double* ms_total, int64_t* reductions);
 
+/* What is attached to the optimiser step's reduction, as the library itself sees it — so that a launch log can answer "did
+ * RCCL see N ranks, and which RCCL": ncclCommCount / ncclCommUserRank of the communicator, ncclGetVersion, and the file
+ * ncclAllReduce was bound from (dladdr).  One copy of RCCL per process: a librccl.so.1 the process has already mapped
+ * (PyTorch's, when the host uses torch.distributed) is bound in preference to loading another (lib_was_mapped = 1). */
+typedef struct TgCommInfo {
+    int32_t attached;       /* 0 nothing, 1 RCCL communicator (tg_train_comm_init), 2 caller's function (tg_train_set_allreduce) */
+    int32_t world_size;     /* as given to tg_train_comm_init / tg_train_set_allreduce; 1 if nothing is attached */
+    int32_t rank;
+    int32_t nccl_count;     /* ncclCommCount(comm), -1 without a communicator */
+    int32_t nccl_rank;      /* ncclCommUserRank(comm), -1 without a communicator */
+    int32_t nccl_version;   /* ncclGetVersion, -1 if librccl was never loaded */
+    int32_t lib_was_mapped; /* 1: the bound librccl.so.1 was already in the process when libtakgpu first needed it */
+    int32_t reserved;
+    char lib_path[256];     /* the shared object ncclAllReduce resolves into; "" if librccl was never loaded */
+} TgCommInfo;
+int tg_train_comm_info(TgEngine* e, TgCommInfo* out);
+
 /* ---------------------------------------------------------------------------------------
  * Pit (replaces `pit`, train/src/pit.rs:15-96): the new network against the old one,
  * `pairs` openings × both colours, all 2·pairs games concurrently — one engine handle per weight set, each

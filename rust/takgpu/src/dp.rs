@@ -33,3 +33,12 @@ where
     let ctx = Box::into_raw(Box::new(reduce)) as *mut c_void; // lives as long as the engine uses it
     check(unsafe { sys::tg_train_set_allreduce(e, Some(trampoline::<F>), ctx, world) })
 }
+
+/// What is attached to the optimiser step's reduction, as the library sees it (`ncclCommCount`, `ncclGetVersion`, the file
+/// `ncclAllReduce` was bound from): log it once per rank after `init_rccl`, and refuse to train if `nccl_count != world`.
+pub fn comm_info<const N: usize>(net: &mut GpuNet<N>) -> Result<sys::TgCommInfo, crate::TgError> {
+    let e = net.trainer_handle()?;
+    let mut info = std::mem::MaybeUninit::<sys::TgCommInfo>::zeroed();
+    check(unsafe { sys::tg_train_comm_info(e, info.as_mut_ptr()) })?;
+    Ok(unsafe { info.assume_init() })
+}

@@ -43,12 +43,35 @@ impl Default for SelfPlaySettings {
     }
 }
 
-/// Drop-in for `self_play_parallel(&network)` at train/src/main.rs:120
+/// What the run did besides producing examples.  `aborted_games` is the one divergence from self_play.rs a caller must be
+/// able to see: the reference keeps a game of any length, the engine retires a game that exceeds a fixed capacity (512 plies,
+/// selection depth 256, 2²² visits of one node: `TG_LIMIT_*`) and discards its examples — a bias against very long games if it
+/// ever happens (it has not in any soak run: `profiles/*soak*`).
+#[derive(Clone, Copy, Debug, Default)]
+pub struct SelfPlayReport {
+    pub games_finished: u64,
+    pub aborted_games: u64,
+    pub examples: u64,
+}
+
+/// Drop-in for `self_play_parallel(&network)` at train/src/main.rs:120.  Games the engine had to retire are reported on
+/// stderr (the reference has no such case); use `self_play_with_report` to receive the count.
 pub fn self_play_parallel_gpu<const N: usize>(network: &GpuNet<N>) -> Vec<Example<N>> {
-    self_play_with(network, SelfPlaySettings { seed: rand::random(), ..Default::default() }).expect("self-play on the GPU")
+    let (examples, report) =
+        self_play_with_report(network, SelfPlaySettings { seed: rand::random(), ..Default::default() }).expect("self-play on the GPU");
+    if report.aborted_games > 0 {
+        eprintln!("self-play: {} of {} games exceeded an engine capacity (TG_LIMIT_*) and were retired without examples",
+                  report.aborted_games, report.aborted_games + report.games_finished);
+    }
+    examples
 }
 
 pub fn self_play_with<const N: usize>(network: &GpuNet<N>, s: SelfPlaySettings) -> Result<Vec<Example<N>>, crate::TgError> {
+    self_play_with_report(network, s).map(|(examples, _)| examples)
+}
+
+pub fn self_play_with_report<const N: usize>(network: &GpuNet<N>, s: SelfPlaySettings)
+                                             -> Result<(Vec<Example<N>>, SelfPlayReport), crate::TgError> {
     let scfg = sys::TgSearchConfig {
         games: s.games,
         arena_nodes: s.arena_nodes,
@@ -113,10 +136,10 @@ pub fn self_play_with<const N: usize>(network: &GpuNet<N>, s: SelfPlaySettings) 
         // ends with completed + WORKERS ≥ SELF_PLAY_GAMES (:151,237), and up to `games` games are still in flight when the first
         // slot retires.  So: until NO slot is alive, and every emitted example has been received.
         if st.alive_games == 0 && n_out == 0 && st.examples == examples.len() as u64 {
-            break;
+            let report = SelfPlayReport { games_finished: st.games_finished, aborted_games: st.aborted_games, examples: st.examples };
+            return Ok((examples, report));
         }
     }
-    Ok(examples)
 }
 
 /// `Network` is only needed as a bound by callers that stay generic over the network type

@@ -3,7 +3,25 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 namespace tg {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): one `static LdsAttr` per launcher remembers the
+// largest size it has set on each device of the process, under a lock (engines on several devices, trainers on several host threads).
+struct LdsAttr {
+    std::mutex guard;
+    size_t configured[16] = {};
+    hipError_t ensure(const void* kernel, size_t lds) {
+        int dev = 0;
+        if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+        std::lock_guard<std::mutex> lock(guard);
+        if (dev >= 0 && dev < 16 && lds <= configured[dev]) return hipSuccess;
+        if (hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess) return e;
+        if (dev >= 0 && dev < 16) configured[dev] = lds;
+        return hipSuccess;
+    }
+};
 
 // board_kernels.hip
 void launch_movegen(hipStream_t st, const uint8_t* states, int count, int n, uint16_t* moves, int32_t* counts);

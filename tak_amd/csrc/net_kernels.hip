@@ -799,7 +799,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restri
     }
     const int ch = ch0 + 4 * q;
     const f32x4 bv = *(const f32x4*)&bias[ch];
-    f32x4 s1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, s2 = s1;  // stats_part: Σ and Σ² of this lane's outputs, per channel
+    // stats_part: Σ and Σ² of this lane's outputs, per channel — in double from the first add on: var = E[z²] − E[z]² loses
+    // (mean/σ)² of the sums' relative accuracy, and f32 partials over up to 208 rows left 1e-4 of the variance at |mean| = 10σ
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int j = 0; j < RTW; j++) {
         if (rowid[j] < rows && ch < cout_valid) {
@@ -809,8 +811,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restri
             if (relu) { v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f); }
             if (ch + 3 < cout_valid) *(f32x4*)&out[o] = v;
             else for (int t = 0; t < 4; t++) if (ch + t < cout_valid) out[o + t] = v[t];
-            s1 += v;
-            s2 += v * v;
+            if (stats_part) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) { const double d = (double)v[t]; s1[t] += d; s2[t] = fma(d, d, s2[t]); }
+            }
         }
     }
     if (stats_part) {
@@ -825,7 +829,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restri
             const int CoutP = 16 * COT;
             double* dst = stats_part + ((size_t)(blockIdx.x * NRG + rg) * 2) * CoutP + ch;
 #pragma unroll
-            for (int t = 0; t < 4; t++) { dst[t] = (double)s1[t]; dst[CoutP + t] = (double)s2[t]; }
+            for (int t = 0; t < 4; t++) { dst[t] = s1[t]; dst[CoutP + t] = s2[t]; }
         }
     }
     TG_STAMP(0, 4);
@@ -1114,7 +1118,7 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
                                                  (__attribute__((address_space(3))) void*)(wl + buf * FC_RING_SLOTS + (wave + 8 * u) * 64), 16, 0, 0);
     };
 #ifndef TG_RING_PROBE
-#define TG_RING_PROBE 0  // timing probes (wrong results): 1 = no refills and no flags, 2 = no activation stream, 8 = MFMA operands swapped, 16 = flags only, 32 = refills only
+#define TG_RING_PROBE 0  // timing probes (wrong results): 1 = no refills and no flags, 2 = no activation stream, 8 = MFMA operands swapped, 16 = flags only, 32 = refills only, 64 = 25 instead of 26 output tiles per SIMD, 128 = no logits store
 #endif
     auto aload = [&](int kc) { return ap[(size_t)((TG_RING_PROBE & 2) ? 0 : (kc < nchunks ? kc : nchunks - 1)) * achunk]; };
     if (tid < 2 * FC_RING) flags[tid] = 0u;
@@ -1150,8 +1154,14 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
     if (NEXT) { TG_FC_LOAD((C) + 1, 0, FC_H1) }                                                                      \
     EARLY;                                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
-    TG_FC_MFMA(AV, FC_H1, FC_CT)                                                                                     \
+    if (TG_RING_PROBE & 64) {                                                                                        \
+        TG_FC_MFMA(AV, FC_H1, FC_CT - 1)                                                                             \
+        if (probe_13th) { TG_FC_MFMA(AV, FC_CT - 1, FC_CT) }                                                         \
+    } else {                                                                                                         \
+        TG_FC_MFMA(AV, FC_H1, FC_CT)                                                                                 \
+    }                                                                                                                \
     __builtin_amdgcn_sched_barrier(0);
+    const bool probe_13th = __builtin_amdgcn_readfirstlane(wave) < 4;  // TG_RING_PROBE & 64: waves 4-7 skip their 13th output tile
     const volatile __attribute__((address_space(3))) uint32_t* flag_lds = (const volatile __attribute__((address_space(3))) uint32_t*)flags;
     uint32_t early_ready = 0u, early_done = 0u;
     for (int step = 0; step < nsteps; step++) {
@@ -1188,7 +1198,7 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
 #undef TG_FC_LOAD
 #undef TG_FC_MFMA
 #undef TG_FC_CHUNK
-    fc_epilogue(acc, bias, out, stats, row, row_ok, n0, q, out_stride, n_valid, n_soft, (int)gridDim.y);
+    fc_epilogue(acc, bias, out, stats, row, row_ok && !(TG_RING_PROBE & 128), n0, q, out_stride, n_valid, n_soft, (int)gridDim.y);
 }
 
 // The same FC for SMALL batches (host-driven MCTS evaluates 16–32 leaves per call; Player, pit): k_fc_lds gives a row block
@@ -1442,12 +1452,8 @@ template <int RT, int CT>
 static hipError_t launch_conv_t(hipStream_t st, const float* in, const float* Wp, const float* bias, const float* res,
                                 float* out, int M, int n, int Cpad, int CoutP, int out_stride, int cout_valid, bool relu) {
     size_t lds = conv_lds_bytes(RT, n, Cpad);
-    static size_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_conv3x3<RT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = lds;
-    }
+    static LdsAttr lds_attr;
+    if (hipError_t e = lds_attr.ensure((const void*)k_conv3x3<RT, CT>, lds); e != hipSuccess) return e;
     dim3 grid((M + 64 * RT - 1) / (64 * RT), CoutP / (64 * CT));
     hipLaunchKernelGGL((k_conv3x3<RT, CT>), grid, dim3(256), lds, st, in, Wp, bias, res, out, M, n, Cpad, CoutP, out_stride,
                        cout_valid, relu ? 1 : 0);
@@ -1459,12 +1465,8 @@ static hipError_t launch_conv_pos_t(hipStream_t st, const float* in, const float
                                     float* out, int B, int n, int Cpad, int CoutP, int out_stride, int cout_valid, bool relu,
                                     int PW, int CTW) {
     size_t lds = (size_t)(PW * n * n + 1) * (Cpad + LDS_PAD16) * sizeof(float);
-    static size_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_conv_pos<RTW, NWAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = lds;
-    }
+    static LdsAttr lds_attr;
+    if (hipError_t e = lds_attr.ensure((const void*)k_conv_pos<RTW, NWAVES>, lds); e != hipSuccess) return e;
     dim3 grid((B + PW - 1) / PW, CoutP / (CTW * 16));
     hipLaunchKernelGGL((k_conv_pos<RTW, NWAVES>), grid, dim3(NWAVES * 64), lds, st, in, Wp, bias, res, out, B, n, Cpad, CoutP,
                        out_stride, cout_valid, relu ? 1 : 0, PW, CTW);
@@ -1496,12 +1498,8 @@ static hipError_t launch_conv_halo_t(hipStream_t st, const float* in, const floa
                                      double* stats_part, int* stats_blocks) {
     if (PS != PSC) return hipErrorInvalidValue;
     const size_t lds = (size_t)(NB + 2 + PW * PS + 1) * (16 * CH + 4) * sizeof(float);
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_conv_halo<RTW, NWAVES, CH, NB, COT, PSC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    static LdsAttr lds_attr;
+    if (hipError_t e = lds_attr.ensure((const void*)k_conv_halo<RTW, NWAVES, CH, NB, COT, PSC>, lds); e != hipSuccess) return e;
     dim3 grid((B + PW - 1) / PW, COT / CTW);
     if (grid.y != 1) stats_part = nullptr;  // (statistics only for layers whose channels one workgroup column covers)
     hipLaunchKernelGGL((k_conv_halo<RTW, NWAVES, CH, NB, COT, PSC>), grid, dim3(NWAVES * 64), lds, st, in, Wp, bias, res, out, slotmap, B, PW, PS,
@@ -1569,12 +1567,8 @@ static hipError_t launch_tower_t(hipStream_t st, const float* in, const TowerPar
     const size_t first = rows1 * ((CB ? T.cb_cin_pad : T.cin_pad) + LDS_PAD16) * sizeof(float) + (CB ? tower_cb_table_bytes(PW, T.F) : 0);
     const size_t later = rows1 * (T.F + LDS_PAD16) * sizeof(float);
     const size_t lds = first > later ? first : later;
-    static size_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_tower<RTW, NWAVES, CH0, CH, FROM_STATES, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = lds;
-    }
+    static LdsAttr lds_attr;
+    if (hipError_t e = lds_attr.ensure((const void*)k_tower<RTW, NWAVES, CH0, CH, FROM_STATES, CB>, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL((k_tower<RTW, NWAVES, CH0, CH, FROM_STATES, CB>), dim3((B + PW - 1) / PW), dim3(NWAVES * 64), lds, st, in, T, out, B, n, PW, CTW);
     return hipGetLastError();
 }
@@ -1633,12 +1627,8 @@ static hipError_t launch_tower_halo_t(hipStream_t st, const float* in, const Tow
                          (CB ? tower_cb_table_bytes(PW, 16 * CH) : 0);
     const size_t halo = (size_t)(NB + 2 + PW * T.halo_ps + 1) * (16 * CH + 4) * sizeof(float);  // + the spare cell
     const size_t lds = plain > halo ? plain : halo;
-    static size_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_tower_halo<RTW, NWAVES, CH0, CH, NB, FROM_STATES, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = lds;
-    }
+    static LdsAttr lds_attr;
+    if (hipError_t e = lds_attr.ensure((const void*)k_tower_halo<RTW, NWAVES, CH0, CH, NB, FROM_STATES, CB>, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL((k_tower_halo<RTW, NWAVES, CH0, CH, NB, FROM_STATES, CB>), dim3((B + PW - 1) / PW), dim3(NWAVES * 64), lds, st, in, T, out, B, PW, CTW);
     return hipGetLastError();
 }
@@ -1774,12 +1764,8 @@ hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp,
         dim3 grid((M + 127) / 128, NP / FC_COLS);
         static const bool ring = getenv("TG_FC_BARRIER") == nullptr;  // A/B switch: the version with a workgroup barrier per K-step
         if (ring) {
-            static bool configured = false;
-            if (!configured) {
-                hipError_t e = hipFuncSetAttribute((const void*)k_fc_ring, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FC_RING_LDS);
-                if (e != hipSuccess) return e;
-                configured = true;
-            }
+            static LdsAttr lds_attr;
+            if (hipError_t e = lds_attr.ensure((const void*)k_fc_ring, FC_RING_LDS); e != hipSuccess) return e;
             hipLaunchKernelGGL(k_fc_ring, grid, dim3(512), FC_RING_LDS, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid, a_frag ? 1 : 0, stats, n_soft);
             return hipGetLastError();
         }

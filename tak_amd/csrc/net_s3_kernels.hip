@@ -1072,12 +1072,8 @@ static hipError_t launch_s3_t(hipStream_t st, const void* in, const TowerS3Param
     if (zrows * (32 * KC0 + 8) * sizeof(float) > budget) pad0 = 1;      // input image: + 16 B pitch and the single zero row
     lds = std::max(lds, (pad0 == 2 ? zrows : rows + 1) * (32 * KC0 + 4 * pad0) * sizeof(float));
     if (CB) lds = std::max(lds, zrows * (32 * KC0 + 4 * pad0) * sizeof(float) + (size_t)PW * 9 * T.F * sizeof(float));  // + PB behind the zero region
-    static size_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_tower_s3<RTW, KC0, KC, FROM_STATES, OUT_SPLIT, NW, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = lds;
-    }
+    static LdsAttr lds_attr;
+    if (hipError_t e = lds_attr.ensure((const void*)k_tower_s3<RTW, KC0, KC, FROM_STATES, OUT_SPLIT, NW, CB>, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL((k_tower_s3<RTW, KC0, KC, FROM_STATES, OUT_SPLIT, NW, CB>), dim3((B + PW - 1) / PW), dim3(NW * 64), lds, st, in, T, out, B, n, PW, NCG, pad0);
     return hipGetLastError();
 }
@@ -1088,12 +1084,8 @@ static hipError_t launch_s3_halo_t(hipStream_t st, const void* in, const TowerS3
     const size_t plain = (size_t)(PW * NB * NB + 1) * (32 * KC0 + 4) * sizeof(float) + (CB ? (size_t)PW * 9 * (32 * KC) * sizeof(float) : 0);
     const size_t halo = (size_t)(NB + 2 + PW * T.halo_ps + 1) * (32 * KC + 4) * sizeof(float);  // + the spare cell
     const size_t lds = std::max(plain, halo);
-    static size_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_tower_s3_halo<RTW, KC0, KC, NB, FROM_STATES, OUT_SPLIT, NW, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = lds;
-    }
+    static LdsAttr lds_attr;
+    if (hipError_t e = lds_attr.ensure((const void*)k_tower_s3_halo<RTW, KC0, KC, NB, FROM_STATES, OUT_SPLIT, NW, CB>, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL((k_tower_s3_halo<RTW, KC0, KC, NB, FROM_STATES, OUT_SPLIT, NW, CB>), dim3((B + PW - 1) / PW), dim3(NW * 64), lds, st, in, T, out, B, PW, NCG);
     return hipGetLastError();
 }

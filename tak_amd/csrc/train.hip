@@ -45,19 +45,31 @@ struct TrainConv {
 };
 
 // ---- RCCL through dlopen: self-play users never load it -----------------------------------------
+// ONE copy of RCCL per process, on purpose: if the process has already mapped a librccl.so.1 — PyTorch's torch/lib/librccl.so
+// carries that soname, and torch.distributed's NCCL backend is how bench.py's ranks meet — that copy is bound
+// (dlopen RTLD_NOLOAD probe), so proxy threads, IPC handles and HSA signal pools exist once; only a process without one (the Rust
+// host, a C host) loads librccl.so.1 from the loader's search path (/opt/rocm/lib).  tg_train_comm_info reports which file
+// ncclAllReduce came from (dladdr) and what ncclGetVersion / ncclCommCount say, so a launch log answers "did RCCL see N ranks,
+// and which RCCL".
 struct Rccl {
     void* lib = nullptr;
+    bool was_mapped = false;  // the RTLD_NOLOAD probe found a copy already in the process
     int (*GetUniqueId)(void*) = nullptr;
     int (*CommInitRank)(void**, int, Id128 /*ncclUniqueId by value*/, int) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
+    int (*CommUserRank)(void*, int*) = nullptr;
 };
 Rccl g_rccl;
 
 int rccl_load() {
     if (g_rccl.lib) return TG_OK;
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    bool mapped = true;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    if (!h) { mapped = false; h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL); }
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!h) return fail(TG_ERR_STATE, std::string("cannot load librccl: ") + dlerror());
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
@@ -65,9 +77,13 @@ int rccl_load() {
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    g_rccl.GetVersion = (decltype(g_rccl.GetVersion))dlsym(h, "ncclGetVersion");
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(h, "ncclCommCount");
+    g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))dlsym(h, "ncclCommUserRank");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
         return fail(TG_ERR_STATE, "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce");
     g_rccl.lib = h;
+    g_rccl.was_mapped = mapped;
     return TG_OK;
 }
 constexpr int NCCL_FLOAT32 = 7, NCCL_SUM = 0;  // ncclDataType_t / ncclRedOp_t values of rccl.h
@@ -105,13 +121,21 @@ struct Trainer {
     int world = 1, rank = 0;
     TgAllReduceFn hook = nullptr;
     void* hook_ctx = nullptr;
-    // gradient all-reduces timed with HIP events on the engine stream (tg_train_comm_stats): pairs not yet read back
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ar_events;
+    // gradient all-reduces timed with HIP events on the engine stream (tg_train_comm_stats): ONE event pair, created at the first
+    // reduction and re-recorded by every step; the previous step's elapsed time is folded into ar_ms before the pair is reused
+    hipEvent_t ar_ev[2] = {nullptr, nullptr};
+    bool ar_pending = false;
     double ar_ms = 0.0;
     int64_t ar_count = 0;
+    void ar_fold() {
+        if (!ar_pending) return;
+        float ms = 0.0f;
+        if (hipEventSynchronize(ar_ev[1]) == hipSuccess && hipEventElapsedTime(&ms, ar_ev[0], ar_ev[1]) == hipSuccess) { ar_ms += ms; ar_count++; }
+        ar_pending = false;
+    }
     DevBuf err_flag;  // one float: the ranks agree on an argument error before the first chunk of tg_train
     ~Trainer() {
-        for (auto& p : ar_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+        for (hipEvent_t ev : ar_ev) if (ev) (void)hipEventDestroy(ev);
         if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
     }
 };
@@ -297,17 +321,16 @@ int optimizer_step(TgEngine* e) {
     {
         bool reduced;
         const bool timed = t->hook || t->comm;
-        hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (timed) {
-            TG_HIP(hipEventCreate(&ev0));
-            TG_HIP(hipEventCreate(&ev1));
-            TG_HIP(hipEventRecord(ev0, st));
+            t->ar_fold();  // the previous step's pair (long complete: a whole step of chunks lies between)
+            if (!t->ar_ev[0]) {
+                TG_HIP(hipEventCreate(&t->ar_ev[0]));
+                TG_HIP(hipEventCreate(&t->ar_ev[1]));
+            }
+            TG_HIP(hipEventRecord(t->ar_ev[0], st));
         }
         int rc = all_reduce_sum(e, t->grads.as<float>(), t->n_params, "gradients", &reduced);
-        if (timed) {
-            (void)hipEventRecord(ev1, st);
-            t->ar_events.emplace_back(ev0, ev1);
-        }
+        if (timed) t->ar_pending = hipEventRecord(t->ar_ev[1], st) == hipSuccess;
         if (rc) return rc;
         if (reduced) gscale = 1.0f / (float)t->world;
     }
@@ -728,15 +751,34 @@ int tg_train_comm_stats(TgEngine* e, double* ms_total, int64_t* reductions) {
     if (rc) return rc;
     Trainer* t = e->trainer;
     TG_HIP(hipStreamSynchronize(e->stream));
-    for (auto& p : t->ar_events) {
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { t->ar_ms += ms; t->ar_count++; }
-        (void)hipEventDestroy(p.first);
-        (void)hipEventDestroy(p.second);
-    }
-    t->ar_events.clear();
+    t->ar_fold();
     if (ms_total) *ms_total = t->ar_ms;
     if (reductions) *reductions = t->ar_count;
+    return TG_OK;
+}
+
+int tg_train_comm_info(TgEngine* e, TgCommInfo* out) {
+    int rc = need_trainer(e);
+    if (rc) return rc;
+    if (!out) return fail(TG_ERR_INVALID_ARG, "null argument");
+    Trainer* t = e->trainer;
+    std::memset(out, 0, sizeof(*out));
+    out->attached = t->comm ? 1 : t->hook ? 2 : 0;
+    out->world_size = t->world;
+    out->rank = t->rank;
+    out->nccl_count = out->nccl_rank = out->nccl_version = -1;
+    if (g_rccl.lib) {
+        out->lib_was_mapped = g_rccl.was_mapped ? 1 : 0;
+        if (g_rccl.GetVersion) { int v = -1; if (g_rccl.GetVersion(&v) == 0) out->nccl_version = v; }
+        Dl_info di;
+        if (dladdr((void*)g_rccl.AllReduce, &di) && di.dli_fname) std::snprintf(out->lib_path, sizeof(out->lib_path), "%s", di.dli_fname);
+    }
+    if (t->comm) {
+        int v = -1;
+        if (g_rccl.CommCount && g_rccl.CommCount(t->comm, &v) == 0) out->nccl_count = v;
+        v = -1;
+        if (g_rccl.CommUserRank && g_rccl.CommUserRank(t->comm, &v) == 0) out->nccl_rank = v;
+    }
     return TG_OK;
 }
 

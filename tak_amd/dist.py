@@ -51,6 +51,31 @@ def reduce_min(dist, value, device="cpu"):
     return t.item()
 
 
+class Stages:
+    """Rank-local pieces of work in front of a collective.  `run(name, fn)` executes fn on this rank, then all ranks agree
+    (one MIN all-reduce of an ok flag — which is also the barrier in front of the next piece): the rank that failed re-raises its
+    own error, every other rank raises "another rank failed" — so nobody enters the next collective (a communicator rendezvous,
+    tg_train's gradient all-reduce) to wait there for a rank that will never arrive."""
+
+    def __init__(self, dist, rank, device="cpu"):
+        self.dist, self.rank, self.device = dist, rank, device
+
+    def agree(self, name, error=None):
+        ok = reduce_min(self.dist, 0.0 if error else 1.0, device=self.device)
+        if error:
+            raise error
+        if ok < 1.0:
+            raise RuntimeError(f"rank {self.rank}: another rank failed during {name}; leaving before the next collective")
+
+    def run(self, name, fn):
+        try:
+            result, failure = fn(), None
+        except Exception as ex:  # noqa: BLE001 — re-raised by agree() on this rank, reported to the others
+            result, failure = None, ex
+        self.agree(name, failure)
+        return result
+
+
 def training_shard(n_examples, rank, world, chunk_size):
     """[begin, end) of a rank's examples for data-parallel training: every rank gets the same number of WHOLE chunks
     (the gradient all-reduce inside tg_train_chunk's optimiser step must be entered equally often on every rank);

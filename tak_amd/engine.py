@@ -82,6 +82,17 @@ class TgPitResult(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
 
 
+class TgCommInfo(C.Structure):
+    _fields_ = [("attached", C.c_int32), ("world_size", C.c_int32), ("rank", C.c_int32), ("nccl_count", C.c_int32),
+                ("nccl_rank", C.c_int32), ("nccl_version", C.c_int32), ("lib_was_mapped", C.c_int32), ("reserved", C.c_int32),
+                ("lib_path", C.c_char * 256)]
+
+    def as_dict(self):
+        d = {k: int(getattr(self, k)) for k, _ in self._fields_ if k not in ("reserved", "lib_path")}
+        d["lib_path"] = self.lib_path.decode(errors="replace")
+        return d
+
+
 # every symbol include/takgpu.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "tg_state_bytes", "tg_engine_create", "tg_engine_destroy", "tg_last_error", "tg_sync", "tg_stream",
@@ -94,7 +105,7 @@ ABI_SYMBOLS = [
     "tg_augment_examples",
     "tg_train_create", "tg_train_chunk", "tg_train", "tg_train_step", "tg_train_forward", "tg_train_get_tensor",
     "tg_train_get_grad", "tg_train_commit", "tg_comm_unique_id", "tg_train_comm_init", "tg_train_set_allreduce",
-    "tg_train_grad_buffer", "tg_train_comm_stats", "tg_pit",
+    "tg_train_grad_buffer", "tg_train_comm_stats", "tg_train_comm_info", "tg_pit",
     "tg_format_move", "tg_parse_move", "tg_format_tps", "tg_parse_tps", "tg_format_example", "tg_parse_example",
 ]
 
@@ -469,6 +480,13 @@ class Engine:
         ms, cnt = C.c_double(0), C.c_int64(0)
         self._check(self.lib.tg_train_comm_stats(self.h, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+    def train_comm_info(self):
+        """what is attached to the optimiser step's reduction, as the library sees it: ncclCommCount / ncclCommUserRank of the
+        communicator, ncclGetVersion, the file ncclAllReduce was bound from, whether that copy was already mapped"""
+        info = TgCommInfo()
+        self._check(self.lib.tg_train_comm_info(self.h, C.byref(info)))
+        return info.as_dict()
 
     def train_comm_init(self, rank, world, unique_id):
         uid = np.frombuffer(bytes(unique_id), np.uint8).copy()

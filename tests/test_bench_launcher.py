@@ -58,3 +58,54 @@ def test_world_size_mismatch_is_refused():
     env = dict(_clean_env(), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rehearse-launch"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert p.returncode == 2 and "WORLD_SIZE=1" in p.stderr.decode()
+
+
+def _launch(*extra, timeout=300):
+    p = subprocess.run([sys.executable, BENCH, "--rehearse-launch", *extra], env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=timeout)
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    return p.returncode, lines, p.stderr.decode()
+
+
+def test_eight_ranks_at_the_real_fan_out():
+    """the 8-GPU node's launch shape on the CPU: free port, eight child processes, OMP split, ONE line relayed from rank 0"""
+    rc, lines, err = _launch("--gpus", "8")
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["max_over_ranks"] == 8.0 and out["sum_over_ranks"] == 36
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_a_hung_collective_ends_non_zero_with_the_headline_printed(world):
+    """config C5's watchdog, acted out without a GPU: one rank never joins the collective → after --train-timeout rank 0 prints
+    the line it has, marked train_c5_failed, and the launch ends with EXIT_C5_FAILED instead of hanging or looking green"""
+    import time
+
+    from bench import EXIT_C5_FAILED
+
+    t0 = time.time()
+    rc, lines, err = _launch("--gpus", str(world), "--train-timeout", "8", "--rehearse-hang-rank", str(world - 1), timeout=240)
+    assert rc == EXIT_C5_FAILED, (rc, err[-2000:])
+    assert time.time() - t0 < 120
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["train_c5_failed"] is True and "timed out" in out["extra"]["train_c5"]["error"] and out["n_gpus"] == world
+    assert "did not finish within 8 s" in err
+
+
+def test_a_rank_that_fails_before_the_collective_releases_the_others():
+    """one rank raises in its local stage: every other rank learns it from the agreement all-reduce and leaves too — nobody waits
+    in the collective for the watchdog (which is set far away here)"""
+    import time
+
+    from bench import EXIT_C5_FAILED
+
+    t0 = time.time()
+    rc, lines, err = _launch("--gpus", "4", "--train-timeout", "600", "--rehearse-fail-rank", "2", timeout=240)
+    assert rc == EXIT_C5_FAILED, (rc, err[-2000:])
+    assert time.time() - t0 < 120, "the ranks waited for the watchdog"
+    out = json.loads(lines[0])
+    assert out["train_c5_failed"] is True and "rehearsed local failure" not in out["extra"]["train_c5"]["error"]  # rank 0 saw "another rank failed"
+    assert "another rank failed" in out["extra"]["train_c5"]["error"]
+    assert "rehearsed local failure" in err

@@ -158,3 +158,81 @@ def test_bench_gpus_2_runs_unaided_on_one_card():
     assert c5["n_gpus"] == 2 and c5["optimizer_steps"] == 2 and c5["parameters_identical_on_all_ranks"] is True
     assert c5["gradient_allreduce"]["count"] == 2 and c5["gradient_allreduce"]["ms_per_step_rank0"] > 0
     assert c5["value"] > 0 and c5["selfplay_c5net"]["value"] > 0
+
+
+def test_bench_gpus_4_runs_unaided_on_one_card():
+    """the same at a wider fan-out: four ranks (four child processes) on the one card.  The 8-GPU node's fan-out itself — port,
+    eight children, OMP split, stdout relay, failure propagation, watchdog — is rehearsed without a GPU in
+    tests/test_bench_launcher.py; on a one-GPU box at most 6 processes may use the card at once (pool rule), and this test's
+    own process is one of them, so four ranks is what fits."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(TAK_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1", "--games", "128", "--rollouts", "16",
+           "--blocks", "2", "--filters", "64", "--train-games", "128", "--train-blocks", "2", "--train-filters", "64", "--train-steps", "2",
+           "--train-chunk", "24", "--train-chunks-in-step", "2", "--train-example-rollouts", "8", "--profile-every", "0"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["value"] > 0 and "train_c5_failed" not in out
+    assert out["config"]["expansions_timed"] == 4 * 128 * 17
+    c5 = out["extra"]["train_c5"]
+    assert "error" not in c5, c5
+    assert c5["n_gpus"] == 4 and c5["optimizer_steps"] == 2 and c5["parameters_identical_on_all_ranks"] is True
+    assert c5["gradient_allreduce"]["count"] == 2
+    assert c5["gradient_allreduce"]["rccl"]["attached"] == 2 and c5["gradient_allreduce"]["rccl"]["world_size"] == 4  # the host hook
+
+
+COMM_INFO = r"""
+import json, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+{preload}
+import tak_amd
+from oracle import oracle as orc
+e = tak_amd.Engine(5, res_blocks=1, filters=32, evaluator=tak_amd.EVAL_RESNET, max_batch=64)
+e.init_random(seed=1)
+e.train_create(learning_rate=1e-3, chunk_size=8, chunks_in_step=1)
+before = e.train_comm_info()
+e.train_comm_init(0, 1, tak_amd.comm_unique_id())
+info = e.train_comm_info()
+sts = orc.random_positions(5, 64, seed=2, max_plies=40, half_komi=4)
+sts = sts[orc.result(5, sts) == 0][:8]
+mv, cnt = orc.movegen(5, sts)
+visits = np.zeros((8, 512), np.uint32)
+for i in range(8):
+    visits[i, : cnt[i]] = 1
+lp, lz, stepped = e.train_chunk(sts, cnt.astype(np.int32), mv, visits, np.zeros(8, np.float32))   # one all-reduced optimiser step
+ms, count = e.train_comm_stats()
+e.close()
+print("INFO", json.dumps(dict(before=before, info=info, stepped=bool(stepped), reductions=int(count), torch="torch" in sys.modules)))
+"""
+
+
+@pytest.mark.parametrize("with_torch", [True, False])
+def test_comm_info_names_the_rccl_that_is_bound(with_torch):
+    """ONE copy of RCCL per process, chosen on purpose (train.hip, rccl_load): in a process that has imported torch — bench.py's
+    ranks, whose torch.distributed backend is RCCL too — libtakgpu binds the librccl.so.1 torch already mapped
+    (torch/lib/librccl.so) instead of loading a second one; a process without one (the Rust host) loads /opt/rocm's.  World size 1
+    on the one card: ncclCommCount = 1, and an optimiser step goes through ncclAllReduce of that library."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TG_")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    code = COMM_INFO.format(root=ROOT, preload="import torch" if with_torch else "")
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    r = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("INFO")][-1][5:])
+    assert r["torch"] == with_torch
+    assert r["before"]["attached"] == 0 and r["before"]["nccl_count"] == -1 and r["before"]["world_size"] == 1
+    info = r["info"]
+    assert info["attached"] == 1 and info["world_size"] == 1 and info["rank"] == 0
+    assert info["nccl_count"] == 1 and info["nccl_rank"] == 0 and info["nccl_version"] > 20000
+    assert r["stepped"] and r["reductions"] == 1
+    if with_torch:
+        assert info["lib_was_mapped"] == 1 and info["lib_path"].endswith(os.path.join("torch", "lib", "librccl.so")), info
+    else:
+        assert info["lib_was_mapped"] == 0 and "torch" not in info["lib_path"] and "librccl.so" in info["lib_path"], info

@@ -49,6 +49,48 @@ def test_policy_eval_full_batch_properties(c2, orc):
     assert worst_p <= 1e-4 and worst_v <= 1e-4, (worst_p, worst_v)
 
 
+def _all_rows_against_pytorch(orc, n, blocks, filters, head, precision, rows, seed, chunk=512):
+    """policy_eval on a FULL batch of 4096 positions (the kernel instantiations the benchmarks run) against PyTorch fp32 on
+    `rows` (all 4096, or every 4th): worst |Δ| of policy and eval (north_star: ≤ 1e-4)."""
+    import tak_amd
+
+    net = torch_ref.make_net(n, blocks, filters, head, seed=seed, randomize_bn=False)
+    e = tak_amd.Engine(n, res_blocks=blocks, filters=filters, evaluator=tak_amd.EVAL_RESNET, max_batch=G)
+    if precision != "f32":
+        e.set_precision(precision)
+    e.load_state_dict(torch_ref.abi_tensors(net))
+    base = orc.random_positions(n, 3000, seed=seed + 40, max_plies=70, half_komi=4)
+    base = base[orc.result(n, base) == 0]
+    sts = np.tile(base, (G // len(base) + 1, 1))[:G]
+    p, v = e.policy_eval(sts)
+    e.close()
+    assert np.abs(p.sum(1) - 1).max() < 2e-5 and (p > 0).all() and (np.abs(v) <= 1).all()
+    idx = np.arange(0, G, G // rows)
+    worst_p = worst_v = 0.0
+    for lo in range(0, len(idx), chunk):
+        sel = idx[lo : lo + chunk]
+        p_ref, v_ref = torch_ref.forward(net, orc.encode(n, sts[sel]))
+        worst_p = max(worst_p, float(np.abs(p[sel] - p_ref).max()))
+        worst_v = max(worst_v, float(np.abs(v[sel] - v_ref).max()))
+    return worst_p, worst_v
+
+
+@pytest.mark.parametrize("name,n,blocks,filters,head,precision,rows", [
+    # the C5 network's full-batch tower k_tower_halo<…,37> and its ring FC, exact f32: ALL 4096 rows
+    ("c5net_f32", 5, 10, 128, "fc5", "f32", 4096),
+    # the split-bf16 towers k_tower_s3_halo and k_fc_s3b on the C2 network: ALL 4096 rows
+    ("c2_bf16x3", 5, 6, 64, "fc5", "bf16x3", 4096),
+    # the C5 network on the split-bf16 path (the 8-wave k_tower_s3_halo instantiation): every 4th row
+    ("c5net_bf16x3", 5, 10, 128, "fc5", "bf16x3", 1024),
+    # C3 (6×6, 10×128, conv-251 head inside the split tower): 1024 rows of the full batch
+    ("c3_bf16x3", 6, 10, 128, "conv", "bf16x3", 1024),
+])
+def test_full_batch_rows_against_pytorch(orc, name, n, blocks, filters, head, precision, rows):
+    worst_p, worst_v = _all_rows_against_pytorch(orc, n, blocks, filters, head, precision, rows, seed=3, chunk=512 if n == 5 else 128)
+    print(f"{name}: worst |dp| {worst_p:.3e}, worst |dv| {worst_v:.3e} over {rows} rows of a 4096-position batch")
+    assert worst_p <= 1e-4 and worst_v <= 1e-4, (name, worst_p, worst_v)
+
+
 def test_search_full_size_invariants_and_slice_parity(c2, orc):
     import tak_amd
 

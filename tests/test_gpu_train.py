@@ -482,3 +482,99 @@ def test_full_batch_training_kernels_return_identical_bits(cfg):
     assert digest(TG_NO_CONV_STATS="1", TG_NO_HALO_CONV="1") == base
     assert digest(TG_NO_CONV_STATS="1", TG_NO_HALO_WGRAD="1") == base
     assert digest(TG_NO_CONV_STATS="1", TG_NO_HALO_CONV="1", TG_NO_HALO_WGRAD="1") == base
+
+
+BN_STATS_DUMP = r"""
+import sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+import numpy as np
+import tak_amd, torch_ref
+from oracle import oracle as orc
+import test_gpu_train as T
+n, blocks, filters, head, count = {cfg!r}
+net = T._net_with_shifted_layers(n, blocks, filters, head)
+e = T._engine(n, blocks, filters, head)
+tensors = torch_ref.abi_tensors(net)
+e.load_state_dict(tensors)
+e.train_create(chunk_size=count, chunks_in_step=1000, bn_momentum=1.0)   # running statistics := this chunk's statistics
+ex = T._examples(orc, n, count, seed=7)
+lp, lz, _ = e.train_chunk(*ex)
+out = dict(loss=np.float32([lp, lz]))
+for name, shape in T._shapes(net).items():
+    out["grad/" + name] = e.train_get_grad(name, shape)
+for name, a in tensors.items():
+    if "running_" in name:
+        out["stat/" + name] = e.train_get_tensor(name, a.shape)
+np.savez({out!r}, **out)
+"""
+
+
+def _net_with_shifted_layers(n, blocks, filters, head):
+    """a network whose res0.conv1 / res0.conv2 outputs sit far from zero (conv bias ±25 and ∓40 on alternating channels):
+    |mean| ≥ 10σ in front of their BatchNorms, where var = E[z²] − E[z]² cancels worst"""
+    import torch
+
+    net = torch_ref.make_net(n, blocks, filters, head, seed=3)
+    with torch.no_grad():
+        sign = torch.where(torch.arange(filters) % 2 == 0, 1.0, -1.0)
+        net.res[0].conv1.bias.copy_(25.0 * sign)
+        net.res[0].conv2.bias.copy_(-40.0 * sign)
+    return net
+
+
+def test_batchnorm_statistics_from_the_conv_accumulators_by_value(orc, tmp_path):
+    """The default full-batch training forward takes BatchNorm's Σz, Σz² from k_conv_halo's accumulators (doubles from the first
+    add) and forms var = E[z²] − E[z]²; TG_NO_CONV_STATS=1 makes two passes over z (mean, then Σ(z − mean)²).  Both must give the
+    same statistics BY VALUE — mean to 2e-5 σ, variance to 1e-5 relative — also where |mean| ≥ 10 σ, and the same losses and
+    gradients (tensors behind a ReLU mask: up to the flip of a pre-activation that lies within 1e-7 of zero, which moves a tensor
+    by ≈ ‖g‖/√(M·F); the moments themselves are what this test pins)."""
+    import os
+    import subprocess
+    import sys
+
+    import torch
+
+    cfg = (5, 2, 128, "fc5", 128)
+    n, blocks, filters, head, count = cfg
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(tag, **env):
+        e = {k: v for k, v in os.environ.items() if not k.startswith("TG_")}
+        e.update(env)
+        path = str(tmp_path / f"{tag}.npz")
+        subprocess.run([sys.executable, "-c", BN_STATS_DUMP.format(root=root, cfg=cfg, out=path)], env=e, check=True, timeout=600)
+        return dict(np.load(path))
+
+    a, b = run("default"), run("two_pass", TG_NO_CONV_STATS="1")
+    # the batch statistics PyTorch (fp64) sees, for the scale of each layer and as a third opinion
+    net = _net_with_shifted_layers(n, blocks, filters, head).double().train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = 1.0
+    planes, pi, z, _ = _targets(orc, n, head, _examples(orc, n, count, seed=7))
+    net.forward_training(torch.from_numpy(planes.astype(np.float64)))
+    ref = {torch_ref.abi_name(k): v.numpy() for k, v in net.state_dict().items() if "running_" in k}
+    ratios = {}
+    for name in sorted(k[5:] for k in a if k.startswith("stat/") and k.endswith("running_mean")):
+        vname = name.replace("running_mean", "running_var")
+        mean_a, mean_b, var_a, var_b = a["stat/" + name], b["stat/" + name], a["stat/" + vname], b["stat/" + vname]
+        sigma = np.sqrt(ref[vname])
+        ratios[name] = float(np.abs(ref[name] / sigma).min())
+        assert (np.abs(mean_a - mean_b) <= 2e-5 * sigma + 2e-7 * np.abs(ref[name])).all(), name
+        assert (np.abs(var_a - var_b) <= 1e-5 * ref[vname]).all(), (name, float(np.abs(var_a / var_b - 1).max()))
+        # against PyTorch fp64 on its own conv outputs (which differ from ours by f32 rounding of z: at |mean| = 25 an ulp of z
+        # is 4e-6 σ): looser, but a 1e-4 error of the variance — what f32 partial sums left here — does not pass
+        assert (np.abs(mean_a - ref[name]) <= 2e-5 * sigma + 2e-7 * np.abs(ref[name])).all(), name
+        assert (np.abs(var_a - ref[vname]) <= 3e-5 * ref[vname]).all(), (name, float(np.abs(var_a / ref[vname] - 1).max()))
+    assert ratios["res0.bn1.running_mean"] >= 10.0 and ratios["res0.bn2.running_mean"] >= 10.0, ratios
+    assert np.abs(a["loss"] - b["loss"]).max() <= 1e-5 * np.abs(b["loss"]).max()
+    for k in a:
+        if not k.startswith("grad/"):
+            continue
+        name = k[5:]
+        if name.endswith(".bias") and "conv" in name and not name.startswith("policy"):
+            continue  # zero true gradient: rounding noise on both sides
+        nrm = np.linalg.norm(b[k].astype(np.float64))
+        err = np.linalg.norm(a[k].astype(np.float64) - b[k].astype(np.float64))
+        tight = name.startswith("policy.") or name.startswith("value.")   # no ReLU mask between them and the loss
+        assert err <= (1e-5 if tight else 2e-3) * nrm, (name, err / nrm)

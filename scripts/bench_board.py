@@ -60,11 +60,21 @@ ms, out_states, res, counts = eng.board_pass_bench(states, moves_all, reps=args.
 planes_bytes = tak_amd.input_channels(n) * n * n * 4
 alg = 2 * sb + planes_bytes
 gbs = args.positions * alg / (ms * 1e-3) / 1e9
+# HBM bytes per launch by the memory-side counters: a separate `rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_WRREQ` pass over this script,
+# summarised by scripts/pmc_traffic.py (scripts/collect_evidence.sh) and committed under profiles/; null if that file is absent
+traffic = None
+pmc = os.path.join(ROOT, "profiles", f"pmc_board_pass_{n}x{n}.json")
+if os.path.exists(pmc) and args.positions == 1 << 20:
+    try:
+        traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+    except Exception:
+        traffic = None
 print(json.dumps({
     "bench": "board_pass", "board": n, "positions": args.positions, "distinct_positions": int(len(base)), "avg_ms": ms,
     "algorithmic_bytes_per_position": alg, "positions_per_s": args.positions / (ms * 1e-3),
     "mean_legal_moves": float(cnt.mean()),
-    "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+    "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": traffic,
+                 "traffic_gbs": None if traffic is None else traffic / (ms * 1e-3) / 1e9,
                  "note": "planes are written as the reference tensor has them, C_in f32 channels per square (no padding): the store "
                          "bytes are the algorithmic ones; achievable HBM is ~6.3 TB/s"},
 }))

@@ -12,7 +12,7 @@ FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-
 OBJS=$(ls $R/tak_amd/csrc/_obj/*.o | grep -v net_kernels.o)
 cd /tmp && export TMPDIR=/tmp
 for m in ${1:-0 64 128 192}; do
-    /opt/rocm/bin/hipcc $FLAGS -DTG_RING_PROBE=$m -c $R/tak_amd/csrc/net_kernels.hip -o $B/net_kernels_p$m.o || exit 1
+    /opt/rocm/bin/hipcc $FLAGS -D${PROBE_MACRO:-TG_RING_PROBE}=$m -c $R/tak_amd/csrc/net_kernels.hip -o $B/net_kernels_p$m.o || exit 1
     /opt/rocm/bin/hipcc $FLAGS -shared -o $B/libtakgpu_fc_p$m.so $OBJS $B/net_kernels_p$m.o -ldl || exit 1
     export TAKGPU_LIB=$B/libtakgpu_fc_p$m.so
     rm -rf $O/kt_$m
@@ -20,8 +20,8 @@ for m in ${1:-0 64 128 192}; do
     f=$(find $O/kt_$m -name '*kernel_stats.csv' | head -1)
     python3 - "$m" "$f" <<'PY' | tee -a $O/summary.txt
 import csv, sys
-rows = {r["Name"].split("(")[0].replace("void tg::", "")[:28]: r for r in csv.DictReader(open(sys.argv[2]))}
-print("mask", sys.argv[1], " | ".join(f"{k}: {float(r['AverageNs']) / 1e3:.1f} us x{r['Calls']}" for k, r in rows.items() if k.startswith(("k_fc_ring", "k_tower_halo", "k_softmax"))))
+rows = {r["Name"].split("(")[0].replace("void ", "").replace("tg::", "")[:28]: r for r in csv.DictReader(open(sys.argv[2]))}
+print("mask", sys.argv[1], " | ".join(f"{k}: {float(r['AverageNs']) / 1e3:.1f} us x{r['Calls']}" for k, r in rows.items() if k.startswith(("k_fc", "k_tower_halo", "k_softmax"))))
 PY
     rm -rf $O/kt_$m
 done

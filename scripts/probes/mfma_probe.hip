@@ -107,7 +107,72 @@ void run(const char* name, int threads) {
     printf("%-40s threads %d NT %d: %.3f ms  %.1f TFLOP/s (%.1f%% of 157.3)\n", name, threads, NT, ms, flops / ms / 1e9, flops / ms / 1e9 / 157.3 * 100);
     hipFree(d);
 }
+// register tile of k_fc_reg: 4 activation fragments × 3 weight fragments → 12 accumulators, operands in registers only.
+// ORDER 0: for t, for i, for j (B operand fixed for 3 MFMAs); 1: for t, for j, for i (A operand fixed for 4); 2: for i, for j, for t
+// (the 4 k-slices of one accumulator back to back: a dependent chain of 4)
+template <int ORDER>
+__global__ __launch_bounds__(512) void probe3(float* out, const f32x4* __restrict__ src, int iters) {
+    const int tid = threadIdx.x;
+    f32x4 a[4], w[3], acc[4][3];
+    for (int i = 0; i < 4; i++) a[i] = src[tid + 512 * i];
+    for (int j = 0; j < 3; j++) w[j] = src[tid + 512 * (4 + j)];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 3; j++) acc[i][j] = f32x4{0, 0, 0, 0};
+    for (int it = 0; it < iters; it++) {
+        if (ORDER == 0) {
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j][t], a[i][t], acc[i][j], 0, 0, 0);
+        } else if (ORDER == 1) {
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j][t], a[i][t], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j][t], a[i][t], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("" : "+v"(a[0]), "+v"(w[0]));  // (keeps the loop a loop)
+    }
+    f32x4 s = f32x4{0, 0, 0, 0};
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 3; j++) s += acc[i][j];
+    out[blockIdx.x * 512 + tid] = s[0] + s[1] + s[2] + s[3];
+}
+template <int ORDER>
+void run3(const char* name, int threads, bool random) {
+    float* d; hipMalloc(&d, 256 * 512 * 4);
+    f32x4* src; hipMalloc(&src, 512 * 7 * 16);
+    float* h = (float*)malloc(512 * 7 * 16);
+    for (int i = 0; i < 512 * 7 * 4; i++) h[i] = random ? ((float)rand() / (float)RAND_MAX - 0.5f) * ((i & 1) ? 0.05f : 1.7f) : 0.0f;  // full-mantissa randomness
+    hipMemcpy(src, h, 512 * 7 * 16, hipMemcpyHostToDevice);
+    int iters = 4000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    probe3<ORDER><<<256, threads>>>(d, src, 10);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    probe3<ORDER><<<256, threads>>>(d, src, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double flops = 256.0 * (threads / 64) * iters * 48 * 2048.0;
+    printf("%-44s threads %d %s: %.3f ms  %.1f TFLOP/s (%.1f%% of 157.3)\n", name, threads, random ? "random" : "zeros ", ms, flops / ms / 1e9, flops / ms / 1e9 / 157.3 * 100);
+    hipFree(d); hipFree(src); free(h);
+}
 int main() {
+    run3<0>("4x3 register tile, order t,i,j", 512, true);
+    run3<0>("4x3 register tile, order t,i,j", 512, false);
+    run3<1>("4x3 register tile, order t,j,i", 512, true);
+    run3<2>("4x3 register tile, order i,j,t (chains of 4)", 512, true);
+    run3<0>("4x3 register tile, order t,i,j", 256, true);
     run<0, 13>("regs only", 512);
     run<0, 13>("regs only", 256);
     run<0, 4>("regs only", 512);

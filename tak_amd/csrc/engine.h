@@ -93,7 +93,10 @@ int net_forward_dev(TgEngine* e, int n, const float* d_planes_nhwc, float* d_pol
 // same from packed states (device); encodes inside the fused tower when the topology allows, else via k_encode
 int net_forward_states_dev(TgEngine* e, int n, const uint8_t* d_states, float* d_policy, float* d_eval);
 bool net_takes_states(const TgEngine* e);  // true when the fused tower encodes in-kernel
-const float* net_fc_stats(const TgEngine* e, int* blocks);  // block-wise softmax statistics that go with net_fc_logits' buffer, or nullptr
+struct FcGatherArgs;  // kernels.h
+const float* net_fc_stats(const TgEngine* e, int* blocks, int* stride);  // block-wise softmax statistics that go with net_fc_logits' buffer ([batch][stride][2]), or nullptr
+bool net_gather_ok(const TgEngine* e, int leaves);          // will a logits-only forward of `leaves` rows write the children's logits (net_set_gather)?
+void net_set_gather(TgEngine* e, const FcGatherArgs* g);    // the search's child_pidx / leaf_rec / child_logit buffers, or nullptr
 const float* net_fc_logits(const TgEngine* e, int* ld);  // FC head: logits buffer for logits-only forwards (d_policy = nullptr), else nullptr
 int net_forward_states_at(TgEngine* e, int n, const uint8_t* d_states, float* d_policy, float* d_eval, hipStream_t st, int pos0);
 bool net_profile_due(const TgEngine* e);

@@ -120,13 +120,24 @@ hipError_t launch_fc_s3(hipStream_t st, const float* act_split, const void* Wp, 
 hipError_t launch_value_head_s3(hipStream_t st, const float* act_split, const float* wv, float bv, int B, int len, float* eval);
 // a_frag: A is in the fragment-major order of TowerParams.frag_out (needs fc_frag_supported(K, NP))
 // stats (optional, needs fc_stats_supported): the block-wise softmax statistics of softmax.cuh over columns < n_soft,
-// [M][NP/208][2] floats — emitted by the FC's epilogue (full batches) or by a small kernel behind it (≤ 512 rows): same bits
+// [M][FC_STAT_STRIDE][2] floats (11 block pairs, then {value pre-activation = column n_soft, 0}) — emitted by the FC's epilogue
+// (full batches) or by a small kernel behind it (≤ 512 rows): same bits
+// gather (optional, needs stats and fc_gather_supported): no logits row is written; for every row the logits of the children
+// of that row's leaf go to child_logit[row][child] (search iterations: the tree backup needs nothing else)
+struct FcGatherArgs {
+    const uint16_t* child_pidx;  // [M][stride] policy index per child, 0xFFFF = unmapped
+    const uint32_t* leaf_rec;    // [M][2] {children block, child count}
+    float* child_logit;          // [M][stride]
+    int stride;
+};
 hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp, const float* bias, float* out, int M, int K,
-                       int NP, int out_stride, int n_valid, bool a_frag = false, float* stats = nullptr, int n_soft = 0);
+                       int NP, int out_stride, int n_valid, bool a_frag = false, float* stats = nullptr, int n_soft = 0,
+                       const FcGatherArgs* gather = nullptr);
 bool fc_frag_supported(int K, int NP);
 bool fc_stats_supported(int K, int NP, int out_stride);
-hipError_t launch_softmax_stats(hipStream_t st, const float* logits, int row_stride, const float* stats, int blocks, int P, int B,
-                                float* policy, float* eval);
+bool fc_gather_supported(int M, int K, int NP);
+hipError_t launch_softmax_stats(hipStream_t st, const float* logits, int row_stride, const float* stats, int blocks, int stat_stride, int P,
+                                int B, float* policy, float* eval);
 hipError_t launch_value_head(hipStream_t st, const float* act, const float* wv, float bv, int B, int len, float* eval);
 hipError_t launch_softmax(hipStream_t st, const float* logits, int row_stride, bool conv_head, int nsq, int ch_stride, int P,
                           int B, float* policy, float* eval = nullptr);

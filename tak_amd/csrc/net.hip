@@ -8,6 +8,7 @@
 
 #include "engine.h"
 #include "kernels.h"
+#include "softmax.cuh"
 #include "rng.cuh"
 
 namespace tg {
@@ -34,7 +35,10 @@ struct Net {
     DevBuf x, y, logits, planes_nhwc, planes_nchw;
     DevBuf fc_stats;                  // [max_batch][fc_stat_blocks][2]: block-wise softmax statistics of the policy FC (softmax.cuh)
     bool fc_stats_on = false;
-    int fc_stat_blocks = 0;           // policy_np / 208 on the exact path, s3_np / 112 on the split-bf16 FC
+    int fc_stat_blocks = 0;           // FC_STAT_BLOCKS (11) on the exact path, s3_np / 112 on the split-bf16 FC
+    int fc_stat_stride = 0;           // pairs per row of fc_stats: the exact path appends {value pre-activation, 0}
+    FcGatherArgs gather{};            // set by the search (net_set_gather): logits-only forwards of the exact FC write the
+    bool gather_on = false;           // children's logits of every leaf instead of the logits rows
     bool fused = false;  // whole tower in one launch (k_tower)
     TowerParams tower;
     ConvLayer conv0_tower;             // conv0 with the last input chunk permuted (layer 0 of the fused towers)
@@ -249,8 +253,8 @@ int net_finalize(TgEngine* e) {
         auto w = find(n, "policy.weight", (size_t)P * K, err);
         auto b = w ? find(n, "policy.bias", P, err) : nullptr;
         if (!b) return fail(TG_ERR_WEIGHTS, err);
-        // 13 output tiles of 16 per workgroup column (k_fc_lds): 1575 → 1664 = 8·208; 208 is also a multiple of
-        // nothing the generic k_gemm needs, so shapes with K % 64 != 0 keep the 64-wide padding
+        // padded to 1664 columns (the FC kernels use the first 99 tiles = 1584 of them, softmax.cuh; the generic k_gemm and
+        // k_fc_small want multiples of 64 / 32); shapes with K % 64 != 0 go through k_gemm
         int NP = (K % 64 == 0) ? round_up(P, 208) : round_up(P, 64);
         std::vector<float> wp(K * NP, 0.0f), bp(NP, 0.0f);
         for (int o = 0; o < P; o++) {
@@ -473,8 +477,9 @@ int net_finalize(TgEngine* e) {
     const bool s3fc = n->s3 && n->s3_fc_on;
     n->fc_stats_on = e->cfg.policy_head == TG_HEAD_FC5 && n->value_in_fc && !getenv("TG_NO_FC_STATS") &&
                      (s3fc ? (n->s3_np % 112 == 0 && n->s3_np / 112 <= 64) : fc_stats_supported(nsq * F, n->policy_np, n->policy_np));
-    n->fc_stat_blocks = n->fc_stats_on ? (s3fc ? n->s3_np / 112 : n->policy_np / 208) : 0;
-    if (n->fc_stats_on) TG_HIP(n->fc_stats.ensure(mb * (size_t)n->fc_stat_blocks * 2 * 4));
+    n->fc_stat_blocks = n->fc_stats_on ? (s3fc ? n->s3_np / 112 : FC_STAT_BLOCKS) : 0;
+    n->fc_stat_stride = n->fc_stats_on ? (s3fc ? n->fc_stat_blocks : FC_STAT_STRIDE) : 0;
+    if (n->fc_stats_on) TG_HIP(n->fc_stats.ensure(mb * (size_t)n->fc_stat_stride * 2 * 4));
     n->ready = true;
     return TG_OK;
 }
@@ -502,11 +507,29 @@ const float* net_fc_logits(const TgEngine* e, int* ld) {
 
 // the block statistics that go with net_fc_logits' buffer ([max_batch][*blocks][2]), or nullptr: the consumer then takes max and
 // Σexp over the whole row itself (softmax_stats_wave)
-const float* net_fc_stats(const TgEngine* e, int* blocks) {
+const float* net_fc_stats(const TgEngine* e, int* blocks, int* stride) {
     if (!net_ready(e) || !e->net->fc_stats_on) return nullptr;
     if (e->net->s3 && !e->net->s3_fc_on) return nullptr;  // split tower with the f32 FC: net_fc_logits declines too
     *blocks = e->net->fc_stat_blocks;
+    *stride = e->net->fc_stat_stride;
     return e->net->fc_stats.as<float>();
+}
+
+// Search iterations on the exact-f32 FC head need, of the FC's output, only the logits of every leaf's children: with a gather
+// target set (and a batch the ring kernel serves), a logits-only forward (d_policy = nullptr) of `leaves` rows writes
+// child_logit[row][child] and the statistics record (with the value pre-activation) — no logits rows.  net_gather_ok tells
+// the search whether the next such forward will do so (then its backup reads child_logit, else the logits buffer).
+bool net_gather_ok(const TgEngine* e, int leaves) {
+    if (!net_ready(e)) return false;
+    const Net* n = e->net;
+    static const bool off = getenv("TG_NO_FC_GATHER") != nullptr;  // A/B: logits rows + the backup's own gather (same bits)
+    return !off && e->cfg.policy_head == TG_HEAD_FC5 && !n->s3 && n->fc_stats_on && n->value_in_fc &&
+           fc_gather_supported(leaves, e->g.nsq * n->F, n->policy_np);
+}
+void net_set_gather(TgEngine* e, const FcGatherArgs* g) {
+    if (!e || !e->net) return;
+    e->net->gather_on = g != nullptr;
+    if (g) e->net->gather = *g;
 }
 
 // half batch on its own stream (only when the tower encodes from states); see search.hip
@@ -593,17 +616,18 @@ static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const ui
             TG_HIP(launch_conv3x3(st, x, L.w.as<float>(), L.b.as<float>(), nullptr, logits, M, N, F, L.cout_pad, L.cout_pad, L.cout, false));
         TG_HIP(launch_softmax(st, logits, nsq * L.cout_pad, true, nsq, L.cout_pad, e->policy_size, nb, d_policy));
     } else if (n->s3 && n->s3_fc_on) {
-        float* stats = n->fc_stats_on ? n->fc_stats.as<float>() + (size_t)pos0 * n->fc_stat_blocks * 2 : nullptr;
+        float* stats = n->fc_stats_on ? n->fc_stats.as<float>() + (size_t)pos0 * n->fc_stat_stride * 2 : nullptr;
         TG_HIP(launch_fc_s3(st, x, n->s3_fc.p, n->s3_fc_b.as<float>(), logits, nb, nsq * F, n->s3_np, n->s3_np, e->policy_size + (n->value_in_fc ? 1 : 0),
                             stats, e->policy_size));
-        if (d_policy && stats) TG_HIP(launch_softmax_stats(st, logits, n->s3_np, stats, n->fc_stat_blocks, e->policy_size, nb, d_policy, d_eval));
+        if (d_policy && stats) TG_HIP(launch_softmax_stats(st, logits, n->s3_np, stats, n->fc_stat_blocks, n->fc_stat_stride, e->policy_size, nb, d_policy, d_eval));
         else if (d_policy) TG_HIP(launch_softmax(st, logits, n->s3_np, false, nsq, 0, e->policy_size, nb, d_policy, n->value_in_fc ? d_eval : nullptr));
     } else {
-        float* stats = n->fc_stats_on ? n->fc_stats.as<float>() + (size_t)pos0 * n->fc_stat_blocks * 2 : nullptr;
+        float* stats = n->fc_stats_on ? n->fc_stats.as<float>() + (size_t)pos0 * n->fc_stat_stride * 2 : nullptr;
+        const bool gather = !d_policy && pos0 == 0 && n->gather_on && net_gather_ok(e, nb);
         TG_HIP(launch_gemm(st, x, nsq * F, n->policy_w.as<float>(), n->policy_b.as<float>(), logits, nb, nsq * F, n->policy_np,
                            n->policy_np, e->policy_size + (n->value_in_fc ? 1 : 0), !n->s3 && n->fused && n->tower.frag_out,
-                           stats, e->policy_size));
-        if (d_policy && stats) TG_HIP(launch_softmax_stats(st, logits, n->policy_np, stats, n->fc_stat_blocks, e->policy_size, nb, d_policy, d_eval));
+                           stats, e->policy_size, gather ? &n->gather : nullptr));
+        if (d_policy && stats) TG_HIP(launch_softmax_stats(st, logits, n->policy_np, stats, n->fc_stat_blocks, n->fc_stat_stride, e->policy_size, nb, d_policy, d_eval));
         else if (d_policy) TG_HIP(launch_softmax(st, logits, n->policy_np, false, nsq, 0, e->policy_size, nb, d_policy, n->value_in_fc ? d_eval : nullptr));
     }
     if (!d_policy && !(e->cfg.policy_head == TG_HEAD_FC5 && n->value_in_fc)) return fail(TG_ERR_STATE, "logits-only forward needs the FC head with the value column");

@@ -16,7 +16,7 @@
 //                           off-board taps, per-tap masks): batches below 2048 / 1024 / 512 positions
 //   k_tower_halo            the same tower on the HALO image (zero cells between board rows and positions, taps as
 //                           ds_read immediates, conflict-free slot table): full batches, 89 – 94 % of the MFMA peak
-//   k_gemm, k_fc_lds        generic GEMM; policy FC with a workgroup barrier per K-step (A/B reference)
+//   k_gemm                  generic GEMM
 //   k_fc_ring               policy FC for full batches: LDS-DMA ring of three K-steps, flag counters instead of barriers
 //   k_fc_small              policy FC for ≤ 512 rows (no LDS, no barrier)
 //   k_softmax(_conv), k_value_head
@@ -917,147 +917,55 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
 }
 
 
-// Policy FC (net5.rs:56-61,108) for the BASELINE shape M = 4096, K = 1600, N = 1575: workgroup tile
-// 128 rows × 208 outputs (13 MFMA tiles) → 32 × 8 = 256 workgroups, one per CU.  Wave w owns row tile w
-// (16 positions) and all 13 output tiles.  The weights (shared by the 8 waves) are staged global → LDS
-// in K-steps of 64, double buffered, in four 16-byte-slot planes (one per k-quarter) so that a wave's 16
-// lanes of one plane hit 16 different bank groups: conflict-free ds_read_b128.  The wave's own 16
-// activation rows are the MFMA B operand, read straight from global one chunk ahead.
-constexpr int FC_CT = 13;            // output tiles per workgroup
-constexpr int FC_COLS = FC_CT * 16;  // 208
-constexpr int FC_KSTEP = 64;         // 4 chunks of 16
-constexpr int FC_PLANE = (FC_KSTEP / 16) * FC_COLS;  // 832 slots per k-quarter plane (≡ 0 mod 16)
+// Policy FC (net5.rs:56-61,108) for the BASELINE shape M = 4096, K = 1600, N = 1575 (+ the value head in column 1575): 1576
+// useful columns are 98.5 MFMA tiles of 16 → FC_TILES = 99.  A workgroup covers 128 rows (8 row tiles, one per wave) × 12 MAIN
+// tiles (column block cb: tiles 12 cb … 12 cb + 11 = 192 columns) → 32 × 8 = 256 workgroups, one per CU — and ONE of the three
+// leftover tiles (96, 97, 98) for some of its row tiles: the 8 row tiles × 3 leftover tiles of a row block are 24 (row tile,
+// tile) pairs, dealt 3 / 3 / 2 / 3 / 3 / 2 / 4 / 4 to the 8 workgroups of the row block (fc_extra): workgroup cb computes
+// leftover tile 96 + l for the row tiles s … s + ne − 1, in its waves 0 … ne − 1 — different SIMDs (waves w and w + 4 share
+// one), so a SIMD carries 12 + 12 or 12 + 13 tile chains where round 3's 8 × 13-tile blocks (104 tiles, 5 of them padding)
+// made it 26.  Wave w owns row tile (w + s) mod 8: the rotation puts the rows that need the leftover tile into waves 0 … ne − 1.
+// The weights (shared by the 8 waves) go global → LDS in K-steps of 64, in four 16-byte-slot planes (one per k-quarter) so that
+// a wave's 16 lanes of one plane hit 16 different bank groups: conflict-free ds_read_b128; slot 12 of a chunk's 13 tile slots
+// holds the workgroup's leftover tile.  The wave's own 16 activation rows are the MFMA B operand, read straight from global.
+constexpr int FC_CT = FC_MAIN_TILES + 1;  // tile slots per workgroup: 12 main + its leftover tile
+constexpr int FC_KSTEP = 64;              // 4 chunks of 16
+constexpr int FC_PLANE = (FC_KSTEP / 16) * FC_CT * 16;  // 832 slots per k-quarter plane (≡ 0 mod 16)
 
-static_assert(FC_COLS == FC_STAT_COLS && FC_CT == FC_STAT_TILES, "the statistics blocks of softmax.cuh are the FC's column blocks");
-// Epilogue of k_fc_lds / k_fc_ring: bias, the logits to `out`, and — stats != nullptr — the softmax statistics of this
-// workgroup's column block for every row (softmax.cuh: fc_block_stats), stats[(row·blocks + block)·2] = {m_b, s_b}.
-// bias holds NP entries, so it is read unguarded.
-__device__ __forceinline__ void fc_epilogue(const f32x4 (&acc)[FC_CT], const float* __restrict__ bias, float* __restrict__ out,
-                                            float* __restrict__ stats, int row, bool row_ok, int n0, int q, int out_stride,
-                                            int n_valid, int n_soft, int blocks) {
-    f32x4 v[FC_CT];
-#pragma unroll
-    for (int j = 0; j < FC_CT; j++) v[j] = acc[j] + *(const f32x4*)&bias[n0 + j * 16 + 4 * q];
-    if (row_ok) {
-#pragma unroll
-        for (int j = 0; j < FC_CT; j++) {
-            const int nn = n0 + j * 16 + 4 * q;
-            if (nn < n_valid) {
-                float* o = out + (size_t)row * out_stride + nn;
-                if (nn + 3 < n_valid) *(f32x4*)o = v[j];
-                else for (int t = 0; t < 4; t++) if (nn + t < n_valid) o[t] = v[j][t];
-            }
-        }
-    }
-    if (stats) {
-        float m, sm;
-        fc_block_stats<FC_CT>(v, n0 + 4 * q, n_soft, m, sm);
-        if (row_ok && q == 0) *(float2*)&stats[((size_t)row * blocks + (n0 / FC_COLS)) * 2] = make_float2(m, sm);
-    }
+// which leftover tile (l), from which row tile on (s), for how many row tiles (ne) workgroup column cb computes it
+struct FcExtra { int l, s, ne; };
+__host__ __device__ inline FcExtra fc_extra(int cb) {
+    if (cb < 6) { const int g = cb % 3; return FcExtra{cb / 3, 3 * g, g < 2 ? 3 : 2}; }
+    return FcExtra{2, 4 * (cb - 6), 4};
 }
 
-__global__ __launch_bounds__(512) void k_fc_lds(const float* __restrict__ A, int lda, const float* __restrict__ Wp,
-                                                const float* __restrict__ bias, float* __restrict__ out, int M, int K, int NP,
-                                                int out_stride, int n_valid, int a_frag, float* __restrict__ stats, int n_soft) {
-    __shared__ f32x4 wl[2][4][FC_PLANE];  // [buffer][k-quarter][chunk*208 + col]  = 106.5 KB
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int r16 = lane & 15, q = lane >> 4;
-    const int row = blockIdx.x * 128 + wave * 16 + r16;
-    const bool row_ok = row < M;
-    const int n0 = blockIdx.y * FC_COLS;
-    // loads are unconditional (rows past the end read a valid row and are never stored; the idle tail of the staging
-    // round reads a clamped slot): hipcc puts s_waitcnt vmcnt(0) right behind an exec-masked global load
-    // activations: row-major (one 16-B slot of its row per lane and chunk), or fragment-major (TowerParams.frag_out: the
-    // wave's 16 rows × 16 k of a chunk are one contiguous KB)
-    const int last_tile = (M - 1) >> 4;
-    const int my_tile = min(blockIdx.x * 8 + wave, last_tile);
-    const f32x4* ap = a_frag ? (const f32x4*)A + (size_t)my_tile * (K >> 4) * 64 + r16 * 4 + q
-                             : (const f32x4*)(A + (size_t)(row_ok ? row : M - 1) * lda) + q;
-    const size_t achunk = a_frag ? 64 : 4;  // f32x4 slots from one chunk to the next
-    const f32x4* wg = (const f32x4*)Wp;  // slot (chunk, col, q) at (chunk*NP + col)*4 + q
-    const int nsteps = K / FC_KSTEP;
+// What a search iteration needs of the FC's output is not the 1576 logits of a leaf but the ≈ 45 of its children: with
+// `gather` set the epilogue writes NO logits row; every wave parks its 16 rows × 13 tiles in LDS and copies, for each of its
+// rows, the logits of that leaf's children (child_pidx: the policy index of child c, recorded by the select kernel) that fall
+// into its columns to child_logit[row][c] — 0.7 MB per iteration instead of a 27 MB logits burst that the tree backup then
+// gathers 45 of 1664 floats from.  The statistics record carries the value pre-activation (pair FC_STAT_BLOCKS).
+struct FcGather {
+    const uint16_t* child_pidx;  // [M][stride] policy index per child of row's leaf, 0xFFFF = unmapped
+    const uint32_t* leaf_rec;    // [M][2]: {children block, child count}
+    float* child_logit;          // [M][stride]
+    int stride;                  // EX_MOVES
+};
 
-    // staging assignment: 4 planes × 832 slots = 3328 slots per step, 7 per thread (the last partly idle)
-    auto stage_load = [&](int step, f32x4 (&r)[7]) {
-#pragma unroll
-        for (int u = 0; u < 7; u++) {
-            int idx = u * 512 + tid;
-            idx = idx < 4 * FC_PLANE ? idx : 4 * FC_PLANE - 1;
-            int qq = idx / FC_PLANE, rem = idx - qq * FC_PLANE;
-            int c = rem / FC_COLS, col = rem - c * FC_COLS;
-            r[u] = wg[((size_t)(step * 4 + c) * NP + n0 + col) * 4 + qq];
-        }
-    };
-    auto stage_store = [&](int buf, const f32x4 (&r)[7]) {
-#pragma unroll
-        for (int u = 0; u < 7; u++) {
-            int idx = u * 512 + tid;
-            if (idx < 4 * FC_PLANE) (&wl[buf][0][0])[idx] = r[u];
-        }
-    };
-
-    f32x4 acc[FC_CT];
-#pragma unroll
-    for (int j = 0; j < FC_CT; j++) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    f32x4 stg[7];
-    stage_load(0, stg);
-    stage_store(0, stg);
-    f32x4 a_cur = ap[0];
-    __syncthreads();
-    // (measured and discarded, scripts/probes/fc_stamps.hip + in-product A/B: a half-tile software pipeline as in the tower,
-    // activations one K-step or two chunks ahead, staging loads behind the first chunk, s_setprio turns — none faster.
-    // Per K-step the slower wave of a SIMD computes for 15.3 k cycles against 13.3 k of MFMA issue, then 1.8 k go to the
-    // staging stores, the barrier and the restart; without any global traffic the loop runs at 86 % of the peak.)
-    for (int step = 0; step < nsteps; step++) {
-        const int buf = step & 1;
-        TG_STAMP(step, 0);
-#ifndef TG_FC_PROBE
-#define TG_FC_PROBE 0  // scripts/probes/fc_stamps.hip: bit 0 = no weight staging, bit 1 = no activation stream (wrong results)
-#endif
-        if (!(TG_FC_PROBE & 1)) stage_load(step + 1 < nsteps ? step + 1 : step, stg);  // the last step reloads itself (unused)
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const int kc = step * 4 + c;
-            const int kn = kc + 1 < nsteps * 4 ? kc + 1 : kc;
-            const f32x4 a_nxt = (TG_FC_PROBE & 2) ? a_cur : ap[(size_t)kn * achunk];
-            f32x4 w[FC_CT];
-#pragma unroll
-            for (int j = 0; j < FC_CT; j++) w[j] = wl[buf][q][c * FC_COLS + j * 16 + r16];
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-#pragma unroll
-                for (int j = 0; j < FC_CT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j][t], a_cur[t], acc[j], 0, 0, 0);
-            a_cur = a_nxt;
-        }
-        TG_STAMP(step, 1);
-        if (!(TG_FC_PROBE & 1)) stage_store(buf ^ 1, stg);
-        TG_STAMP(step, 2);
-        __syncthreads();
-        TG_STAMP(step, 3);
-    }
-    fc_epilogue(acc, bias, out, stats, row, row_ok, n0, q, out_stride, n_valid, n_soft, (int)gridDim.y);
-}
-
-
-// k_fc_lds without workgroup barriers in the loop (the default for full batches; TG_FC_BARRIER=1 selects k_fc_lds for A/B).
-// Three weight buffers of one K-step form a ring filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, no
-// ds_write phase, 16 cache lines per instruction); the eight waves synchronise through two sets of monotonic counters
-// in LDS instead of s_barrier:
+// Barrier-free ring: three weight buffers of one K-step filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, no
+// ds_write phase, 16 cache lines per instruction); the eight waves synchronise through two sets of monotonic counters in LDS
+// instead of s_barrier:
 //   ready[b] += 1 by every wave once its share of the K-step now in buffer b has landed (s_waitcnt vmcnt),
 //   done[b]  += 1 by every wave once it has read the last fragment of the K-step in buffer b.
 // A wave reads step s after ready[s % 3] = 8·(s/3 + 1) and refills buffer (s + 2) % 3 — in the MIDDLE of step s, half a
 // step after it finished reading it itself — after done[(s + 2) % 3] = 8·⌊(s + 2)/3⌋.  Both flags are read half a chunk
 // before they are needed and normally hold by then, so no wave waits out a round trip and the waves may drift half a step
-// apart instead of draining the MFMA pipe at a barrier every 17 k cycles.  Same products in the same order as k_fc_lds →
-// identical bits.  Measured (C2, 4096 rows): 173 – 175 µs against 178 – 180 µs; with neither refills nor flags the loop
-// takes 159 µs (of which ≈ 10 µs are the first fill and the 27 MB output burst), the flags alone cost 10 µs (waves held
-// back for a slower one run their SIMD alone), the refills alone 12 µs.  Fair-priority and operand-order variants: no change.
-// Round 3, measured and discarded: a ninth wave that does nothing but fill the ring (waits for done[], issues the 52 LDS-DMA
-// instructions of a K-step, publishes ready[]) so that the eight MFMA waves never issue an LDS-DMA, never wait vmcnt(0) and
-// never poll done[] — identical bits, 139 registers, and 8 – 10 µs SLOWER per launch (with the poll slowed to s_sleep 16:
-// 3 µs slower; with the fill paced in four groups: 12 µs slower).  What the refills cost is the LDS-DMA traffic beside the
-// fragment reads, not the instructions that start it; spread over eight waves in mid-step it disturbs least.
+// apart instead of draining the MFMA pipe at a barrier every 17 k cycles.  Every output element is accumulated over k in the
+// same order by the same MFMA as in k_fc_small → identical logits bits (tests/test_gpu_net.py, batch independence).
+// What bounds it (TG_RING_PROBE, profiles/r04_b_fc_candidates.txt): with neither refills nor flags the loop is 17 µs shorter —
+// the LDS-DMA pieces' issue slots beside the fragment reads and waves held back for a slower one; the MFMAs of the 88 padded
+// columns were 3.2 µs, the logits burst 3.7 µs.  Measured and discarded: a ninth wave that only fills the ring (8 – 10 µs
+// slower), non-temporal logits stores, the barrier version k_fc_lds (rounds 1 – 3: + 6 µs), a register-tiled FC without LDS
+// (k_fc_reg, scripts/probes/fc_reg.cuh: 227 µs — 2.7 × the operand bytes through the vector-memory path).
 constexpr int FC_RING = 3;
 constexpr int FC_RING_SLOTS = 4 * FC_PLANE;                                        // f32x4 slots per buffer (3328)
 constexpr size_t FC_RING_LDS = (size_t)FC_RING * FC_RING_SLOTS * 16 + 2 * FC_RING * sizeof(uint32_t);
@@ -1076,20 +984,29 @@ __device__ __forceinline__ void fc_ring_signal(uint32_t flag_addr) {
 }
 __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, int lda, const float* __restrict__ Wp,
                                                  const float* __restrict__ bias, float* __restrict__ out, int M, int K, int NP,
-                                                 int out_stride, int n_valid, int a_frag, float* __restrict__ stats, int n_soft) {
+                                                 int out_stride, int n_valid, int a_frag, float* __restrict__ stats, int n_soft,
+                                                 const FcGather gather) {
     extern __shared__ __attribute__((aligned(16))) float fc_ring_lds[];
-    f32x4* wl = (f32x4*)fc_ring_lds;                                // [FC_RING][chunk][output tile][q][r16]
+    f32x4* wl = (f32x4*)fc_ring_lds;                                // [FC_RING][chunk][tile slot][q][r16]
     uint32_t* flags = (uint32_t*)(wl + FC_RING * FC_RING_SLOTS);    // ready[FC_RING], done[FC_RING]
     const uint32_t ready0 = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)flags;  // LDS byte addresses
     const uint32_t done0 = ready0 + FC_RING * 4;
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r16 = lane & 15, q = lane >> 4;
-    const int row = blockIdx.x * 128 + wave * 16 + r16;
+    const int cb = blockIdx.y;
+    const FcExtra X = fc_extra(cb);
+    const bool has13 = wave < X.ne;                    // this wave also computes the leftover tile for its rows (wave-uniform)
+    const int rt = (wave + X.s) & 7;                   // row tile of the row block owned by this wave
+    const int row = blockIdx.x * 128 + rt * 16 + r16;
     const bool row_ok = row < M;
-    const int n0 = blockIdx.y * FC_COLS;
+    const int n0 = cb * (FC_MAIN_TILES * 16);          // first column of the main tiles
+    const int nx = (FC_MAIN_TILES * FC_MAIN_BLOCKS + X.l) * 16;  // first column of the leftover tile
+    // loads are unconditional (rows past the end read a valid row and are never stored): hipcc puts s_waitcnt vmcnt(0)
+    // right behind an exec-masked global load.  Activations: row-major (one 16-B slot of its row per lane and chunk), or
+    // fragment-major (TowerParams.frag_out: the wave's 16 rows × 16 k of a chunk are one contiguous KB)
     const int last_tile = (M - 1) >> 4;
-    const int my_tile = min(blockIdx.x * 8 + wave, last_tile);
+    const int my_tile = min(blockIdx.x * 8 + rt, last_tile);
     const f32x4* ap = a_frag ? (const f32x4*)A + (size_t)my_tile * (K >> 4) * 64 + r16 * 4 + q
                              : (const f32x4*)(A + (size_t)(row_ok ? row : M - 1) * lda) + q;
     const size_t achunk = a_frag ? 64 : 4;
@@ -1097,7 +1014,7 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
     const int nsteps = K / FC_KSTEP;
     const int nchunks = nsteps * 4;
 
-    // LDS-DMA: one wave-instruction fills 64 consecutive slots of a buffer (1 KB) = one (chunk, output tile) block, slot
+    // LDS-DMA: one wave-instruction fills 64 consecutive slots of a buffer (1 KB) = one (chunk, tile slot) block, slot
     // q·16 + r16 inside it — the lane number of its reader, so the fragment reads are contiguous and conflict free — from
     // the block's 1 KB of the weight matrix (slot r16·4 + q: the permutation is on the source side, 16 cache lines per
     // instruction).  52 blocks per K-step, block i = wave + 8u by this wave (7 for waves 0-3, 6 for waves 4-7).
@@ -1107,7 +1024,8 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
         int blk = wave + 8 * u;
         blk = blk < FC_RING_SLOTS / 64 ? blk : FC_RING_SLOTS / 64 - 1;
         const int c = blk / FC_CT, j = blk - c * FC_CT;
-        src0[u] = (uint32_t)(((size_t)c * NP + n0 + j * 16 + r16) * 4 + q);
+        const int col = (j < FC_MAIN_TILES ? n0 + j * 16 : nx) + r16;
+        src0[u] = (uint32_t)(((size_t)c * NP + col) * 4 + q);
     }
     const uint32_t step_slots = (uint32_t)(4 * NP * 4);  // f32x4 slots of the weights per K-step
     auto fill = [&](int step, int buf) {
@@ -1118,7 +1036,7 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
                                                  (__attribute__((address_space(3))) void*)(wl + buf * FC_RING_SLOTS + (wave + 8 * u) * 64), 16, 0, 0);
     };
 #ifndef TG_RING_PROBE
-#define TG_RING_PROBE 0  // timing probes (wrong results): 1 = no refills and no flags, 2 = no activation stream, 8 = MFMA operands swapped, 16 = flags only, 32 = refills only, 64 = 25 instead of 26 output tiles per SIMD, 128 = no logits store
+#define TG_RING_PROBE 0  // timing probes (wrong results): 1 = no refills and no flags, 2 = no activation stream, 16 = flags only, 32 = refills only
 #endif
     auto aload = [&](int kc) { return ap[(size_t)((TG_RING_PROBE & 2) ? 0 : (kc < nchunks ? kc : nchunks - 1)) * achunk]; };
     if (tid < 2 * FC_RING) flags[tid] = 0u;
@@ -1136,16 +1054,16 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     fc_ring_signal(ready0);
     if (nsteps > 1) fc_ring_signal(ready0 + 4);
-    // One chunk: the 13 weight fragments in two halves (7 + 6 output tiles); each half is requested while the other half's
-    // MFMAs run, across chunk boundaries inside a step (the tower's half-tile pipeline, conv_mainloop.cuh).
+    // One chunk: the 13 weight fragments in two halves (7 + 6 tile slots; the 13th only feeds MFMAs in the waves that own a
+    // leftover tile); each half is requested while the other half's MFMAs run, across chunk boundaries inside a step (the
+    // tower's half-tile pipeline, conv_mainloop.cuh).
     constexpr int FC_H1 = 7;
     f32x4 w[FC_CT];
 #define TG_FC_LOAD(C, J0, J1) _Pragma("unroll") for (int j = J0; j < J1; j++) w[j] = wb[((C) * FC_CT + j) * 64 + lane];
 #define TG_FC_MFMA(AV, J0, J1)                                                                                       \
     _Pragma("unroll") for (int t = 0; t < 4; t++)                                                                    \
         _Pragma("unroll") for (int j = J0; j < J1; j++)                                                              \
-            acc[j] = (TG_RING_PROBE & 8) ? __builtin_amdgcn_mfma_f32_16x16x4f32((AV)[t], w[j][t], acc[j], 0, 0, 0)        \
-                                         : __builtin_amdgcn_mfma_f32_16x16x4f32(w[j][t], (AV)[t], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j][t], (AV)[t], acc[j], 0, 0, 0);
 #define TG_FC_CHUNK(C, AV, NEXT, EARLY)                                                                              \
     TG_FC_LOAD(C, FC_H1, FC_CT)                                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
@@ -1154,16 +1072,16 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
     if (NEXT) { TG_FC_LOAD((C) + 1, 0, FC_H1) }                                                                      \
     EARLY;                                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
-    if (TG_RING_PROBE & 64) {                                                                                        \
-        TG_FC_MFMA(AV, FC_H1, FC_CT - 1)                                                                             \
-        if (probe_13th) { TG_FC_MFMA(AV, FC_CT - 1, FC_CT) }                                                         \
-    } else {                                                                                                         \
-        TG_FC_MFMA(AV, FC_H1, FC_CT)                                                                                 \
-    }                                                                                                                \
+    TG_FC_MFMA(AV, FC_H1, FC_MAIN_TILES)                                                                             \
+    if (has13) { TG_FC_MFMA(AV, FC_MAIN_TILES, FC_CT) }                                                              \
     __builtin_amdgcn_sched_barrier(0);
-    const bool probe_13th = __builtin_amdgcn_readfirstlane(wave) < 4;  // TG_RING_PROBE & 64: waves 4-7 skip their 13th output tile
     const volatile __attribute__((address_space(3))) uint32_t* flag_lds = (const volatile __attribute__((address_space(3))) uint32_t*)flags;
     uint32_t early_ready = 0u, early_done = 0u;
+    // gather mode: what the epilogue needs of this wave's rows is requested under the last K-steps' MFMAs — row r16's child
+    // count in lane r16, and per row the first 128 child indices, two 16-bit indices per lane
+    uint32_t g_cnt = 0u, g_pidx[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) g_pidx[r] = 0u;
     for (int step = 0; step < nsteps; step++) {
         const int buf = step % FC_RING;
         const f32x4* wb = wl + buf * FC_RING_SLOTS;
@@ -1176,6 +1094,13 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
         a3 = aload(step * 4 + 3);
         b0 = aload(step * 4 + 4);
         b1 = aload(step * 4 + 5);
+        if (gather.child_logit && step == nsteps - 1) {  // (no refill follows in the last step: these loads wait for nobody)
+            const int tile_row0 = blockIdx.x * 128 + rt * 16;
+            g_cnt = gather.leaf_rec[2 * (size_t)min(tile_row0 + r16, M - 1) + 1];
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                g_pidx[r] = ((const uint32_t*)(gather.child_pidx + (size_t)min(tile_row0 + r, M - 1) * gather.stride))[lane];
+        }
         __builtin_amdgcn_sched_barrier(0);
         TG_FC_CHUNK(0, a0, true, (void)0)
         TG_FC_CHUNK(1, a1, true, early_done = flag_lds[FC_RING + (step + 2) % FC_RING])
@@ -1198,16 +1123,83 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
 #undef TG_FC_LOAD
 #undef TG_FC_MFMA
 #undef TG_FC_CHUNK
-    fc_epilogue(acc, bias, out, stats, row, row_ok && !(TG_RING_PROBE & 128), n0, q, out_stride, n_valid, n_soft, (int)gridDim.y);
+    // ---- epilogue: bias; logits or the children's logits; the statistics of this wave's blocks of its rows ----
+    f32x4 v[FC_CT];
+#pragma unroll
+    for (int j = 0; j < FC_MAIN_TILES; j++) v[j] = acc[j] + *(const f32x4*)&bias[n0 + j * 16 + 4 * q];
+    v[FC_MAIN_TILES] = acc[FC_MAIN_TILES] + *(const f32x4*)&bias[nx + 4 * q];
+    if (stats) {
+        float m, sm;
+        float* srow = stats + (size_t)(row_ok ? row : 0) * (FC_STAT_STRIDE * 2);
+        fc_block_stats<FC_MAIN_TILES>(*reinterpret_cast<const f32x4(*)[FC_MAIN_TILES]>(&v[0]), n0 + 4 * q, min(n_soft, n0 + FC_MAIN_TILES * 16), m, sm);
+        if (row_ok && q == 0) *(float2*)&srow[cb * 2] = make_float2(m, sm);
+        if (has13) {
+            fc_block_stats<1>(*reinterpret_cast<const f32x4(*)[1]>(&v[FC_MAIN_TILES]), nx + 4 * q, min(n_soft, nx + 16), m, sm);
+            if (row_ok && q == 0) *(float2*)&srow[(FC_MAIN_BLOCKS + X.l) * 2] = make_float2(m, sm);
+            // column n_soft (= P) is the value head's pre-activation: pair FC_STAT_BLOCKS of the record
+            const int dv = n_soft - (nx + 4 * q);
+            if (row_ok && dv >= 0 && dv < 4) *(float2*)&srow[FC_STAT_BLOCKS * 2] = make_float2(dv == 0 ? v[FC_MAIN_TILES][0] : dv == 1 ? v[FC_MAIN_TILES][1] : dv == 2 ? v[FC_MAIN_TILES][2] : v[FC_MAIN_TILES][3], 0.0f);
+        }
+    }
+    if (out && row_ok) {
+#pragma unroll
+        for (int j = 0; j < FC_CT; j++) {
+            const int nn = (j < FC_MAIN_TILES ? n0 + j * 16 : nx) + 4 * q;
+            if (nn < n_valid && (j < FC_MAIN_TILES || has13)) {
+                float* o = out + (size_t)row * out_stride + nn;
+                if (nn + 3 < n_valid) *(f32x4*)o = v[j];
+                else for (int t = 0; t < 4; t++) if (nn + t < n_valid) o[t] = v[j][t];
+            }
+        }
+    }
+    if (gather.child_logit) {
+        // This wave's 16 rows × 13 tile slots (13 312 B) go into its eighth of the two ring buffers that hold no data of the last
+        // K-step, once every wave has read the steps that lived there (done[] — normally long true: a wave is at most half a
+        // step behind); every LDS-DMA into them landed steps ago.  The laggard of the workgroup never waits here.
+        const int bA = nsteps % FC_RING, bB = (nsteps + 1) % FC_RING;
+        auto uses = [&](int b) { return b < nsteps ? (nsteps - b + FC_RING - 1) / FC_RING : 0; };
+        if (!(TG_RING_PROBE & (1 | 32))) {
+            fc_ring_wait(done0 + 4 * bA, 8u * (uint32_t)uses(bA));
+            fc_ring_wait(done0 + 4 * bB, 8u * (uint32_t)uses(bB));
+        }
+        constexpr int RP = FC_CT * 16;  // floats per parked row (208)
+        float* park[2] = {(float*)(wl + bA * FC_RING_SLOTS) + wave * (8 * RP), (float*)(wl + bB * FC_RING_SLOTS) + wave * (8 * RP)};
+        {
+            float* dst = park[r16 >> 3] + (r16 & 7) * RP + 4 * q;
+#pragma unroll
+            for (int j = 0; j < FC_CT; j++) *(f32x4*)&dst[j * 16] = v[j];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own parked rows, now read by other lanes of the same wave
+        const int tile_row0 = blockIdx.x * 128 + rt * 16;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int grow = min(tile_row0 + r, M - 1);
+            const uint32_t cnt = tile_row0 + r < M ? min((uint32_t)__builtin_amdgcn_readlane((int)g_cnt, r), (uint32_t)gather.stride) : 0u;
+            const float* prow = park[r >> 3] + (r & 7) * RP;
+            float* crow = gather.child_logit + (size_t)grow * gather.stride;
+            const uint16_t* irow = gather.child_pidx + (size_t)grow * gather.stride;
+            for (uint32_t c0 = 0; c0 < cnt; c0 += 128) {
+                const uint32_t pair = c0 == 0 ? g_pidx[r] : ((const uint32_t*)(irow + c0))[lane];
+#pragma unroll
+                for (int hlf = 0; hlf < 2; hlf++) {
+                    const uint32_t c = c0 + 2 * lane + hlf;
+                    const uint32_t p = hlf ? pair >> 16 : pair & 0xFFFFu;
+                    const uint32_t dm = p - (uint32_t)n0, dx = p - (uint32_t)nx;
+                    const bool in_main = dm < (uint32_t)(FC_MAIN_TILES * 16), in_x = has13 && dx < 16u;
+                    if (c < cnt && (in_main || in_x)) crow[c] = prow[in_main ? dm : FC_MAIN_TILES * 16 + dx];
+                }
+            }
+        }
+    }
 }
 
-// The same FC for SMALL batches (host-driven MCTS evaluates 16–32 leaves per call; Player, pit): k_fc_lds gives a row block
+// The same FC for SMALL batches (host-driven MCTS evaluates 16–32 leaves per call; Player, pit): k_fc_ring gives a row block
 // of 128 positions to one workgroup and needs ≥ 4096 rows to fill the chip, so a 32-row call took as long as a 4096-row
 // one.  Here a wave owns one 16-row tile × 2 output tiles and streams both operands straight from global (no LDS, no
 // barrier): M/16 × NP/32 waves.  Every output element is accumulated over k in the same order by the same MFMA as in
-// k_fc_lds, so the two kernels return identical bits and the choice between them is invisible.
+// k_fc_ring, so the two kernels return identical bits and the choice between them is invisible.
 constexpr int FCS_CT = 2;
-constexpr int FC_SMALL_ROWS = 512;  // up to here the small-batch kernel is the faster one (4 workgroups of k_fc_lds)
+constexpr int FC_SMALL_ROWS = 512;  // up to here the small-batch kernel is the faster one (4 workgroups of k_fc_ring)
 __global__ __launch_bounds__(256) void k_fc_small(const float* __restrict__ A, int lda, const float* __restrict__ Wp,
                                                   const float* __restrict__ bias, float* __restrict__ out, int M, int K, int NP,
                                                   int out_stride, int n_valid, int a_frag) {
@@ -1265,34 +1257,40 @@ __global__ __launch_bounds__(256) void k_fc_small(const float* __restrict__ A, i
 }
 
 // The softmax statistics of softmax.cuh from logits already in memory, for the producers that cannot emit them from their
-// accumulators (k_fc_small: a wave there owns 2 output tiles, not a block's 13).  A wave covers 16 (row, block) pairs with the
-// FC's own lane layout — lane = pair + 16·q holds columns 208·block + 16 j + 4 q + t — so fc_block_stats runs unchanged.
-__global__ __launch_bounds__(256) void k_fc_stats(const float* __restrict__ logits, int ld, int M, int blocks, int n_soft,
-                                                  float* __restrict__ stats) {
+// accumulators (k_fc_small: a wave there owns 2 output tiles, not a block's 12).  A wave covers 16 (row, block) pairs with the
+// FC's own lane layout — lane = pair + 16·q holds columns col0(block) + 16 j + 4 q + t — so fc_block_stats runs unchanged (a
+// single-tile block through the 12-tile template with its limit at the block's end: the same bits); the wave that handles a
+// row's block 0 also copies the value pre-activation (column n_soft) into pair FC_STAT_BLOCKS of the record.
+__global__ __launch_bounds__(256) void k_fc_stats(const float* __restrict__ logits, int ld, int M, int n_soft, float* __restrict__ stats) {
     const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
     const long pair0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
-    const long total = (long)M * blocks;
+    const long total = (long)M * FC_STAT_BLOCKS;
     if (pair0 >= total) return;
     const long pair = pair0 + r16 < total ? pair0 + r16 : total - 1;
-    const int row = (int)(pair / blocks), b = (int)(pair - (long)row * blocks);
-    const float* x = logits + (size_t)row * ld + b * FC_COLS + 4 * q;
-    f32x4 v[FC_CT];
+    const int row = (int)(pair / FC_STAT_BLOCKS), b = (int)(pair - (long)row * FC_STAT_BLOCKS);
+    const int col0 = fc_stat_col0(b), tiles = fc_stat_tiles(b);
+    const float* x = logits + (size_t)row * ld + col0 + 4 * q;
+    f32x4 v[FC_MAIN_TILES];
 #pragma unroll
-    for (int j = 0; j < FC_CT; j++) v[j] = *(const f32x4*)&x[16 * j];
+    for (int j = 0; j < FC_MAIN_TILES; j++) v[j] = j < tiles ? *(const f32x4*)&x[16 * j] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     float m, sm;
-    fc_block_stats<FC_CT>(v, b * FC_COLS + 4 * q, n_soft, m, sm);
-    if (q == 0 && pair0 + r16 < total) *(float2*)&stats[(size_t)pair * 2] = make_float2(m, sm);
+    fc_block_stats<FC_MAIN_TILES>(v, col0 + 4 * q, min(n_soft, col0 + 16 * tiles), m, sm);
+    if (q == 0 && pair0 + r16 < total) {
+        float* srow = stats + (size_t)row * (FC_STAT_STRIDE * 2);
+        *(float2*)&srow[b * 2] = make_float2(m, sm);
+        if (b == 0) *(float2*)&srow[FC_STAT_BLOCKS * 2] = make_float2(logits[(size_t)row * ld + n_soft], 0.0f);
+    }
 }
 
 // softmax of the FC head from the block statistics (tg_policy_eval; the search never materialises probabilities): the same
 // exp(x − M) · (1 / S) the tree backup evaluates for a leaf's children, so host-side trees built from these probabilities
 // and the engine's own agree bit for bit.  One block per position.
 __global__ __launch_bounds__(256) void k_softmax_stats(const float* __restrict__ logits, int row_stride, const float* __restrict__ stats,
-                                                       int blocks, int P, float* __restrict__ policy, float* __restrict__ eval) {
+                                                       int blocks, int stat_stride, int P, float* __restrict__ policy, float* __restrict__ eval) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* x = logits + (size_t)b * row_stride;
     float mx, inv;
-    fc_combine_stats(stats + (size_t)b * blocks * 2, blocks, mx, inv);
+    fc_combine_stats(stats + (size_t)b * stat_stride * 2, blocks, mx, inv);
     if (eval && tid == 0) eval[b] = tanhf(x[P]);
     float* o = policy + (size_t)b * P;
     for (int p = tid; p < P; p += 256) o[p] = stat_exp(x[p] - mx) * inv;
@@ -1740,36 +1738,34 @@ hipError_t launch_tower_states(hipStream_t st, const uint8_t* states, const Towe
     return hipErrorInvalidValue;
 }
 
-bool fc_frag_supported(int K, int NP) { return NP % FC_COLS == 0 && K % FC_KSTEP == 0 && NP % (FCS_CT * 16) == 0; }
-
-bool fc_stats_supported(int K, int NP, int out_stride) {
-    return NP % FC_COLS == 0 && K % FC_KSTEP == 0 && NP % (FCS_CT * 16) == 0 && out_stride == NP && NP / FC_COLS <= 64;
-}
+// the FC kernels of the 5×5 policy head: K-steps of 64, the 99 tiles of softmax.cuh's geometry inside NP columns
+static bool fc_shape_ok(int K, int NP) { return K % FC_KSTEP == 0 && NP >= FC_TILES * 16 && NP % (FCS_CT * 16) == 0; }
+bool fc_frag_supported(int K, int NP) { return fc_shape_ok(K, NP); }
+bool fc_stats_supported(int K, int NP, int out_stride) { return fc_shape_ok(K, NP) && out_stride == NP; }
+bool fc_gather_supported(int M, int K, int NP) { return fc_shape_ok(K, NP) && M > FC_SMALL_ROWS; }
 
 hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp, const float* bias, float* out, int M, int K,
-                       int NP, int out_stride, int n_valid, bool a_frag, float* stats, int n_soft) {
+                       int NP, int out_stride, int n_valid, bool a_frag, float* stats, int n_soft, const FcGatherArgs* gather) {
     if (a_frag && !fc_frag_supported(K, NP)) return hipErrorInvalidValue;
-    if (stats && !fc_stats_supported(K, NP, out_stride)) return hipErrorInvalidValue;
-    if (NP % FC_COLS == 0 && K % FC_KSTEP == 0 && M <= FC_SMALL_ROWS && NP % (FCS_CT * 16) == 0) {
+    if (stats && (!fc_stats_supported(K, NP, out_stride) || n_valid > FC_TILES * 16)) return hipErrorInvalidValue;
+    if (gather && (!stats || !fc_gather_supported(M, K, NP))) return hipErrorInvalidValue;
+    const bool fc = fc_shape_ok(K, NP) && n_valid <= FC_TILES * 16;
+    if (fc && M <= FC_SMALL_ROWS) {
         dim3 grid((M + 15) / 16, (NP / (FCS_CT * 16) + 3) / 4);
         hipLaunchKernelGGL(k_fc_small, grid, dim3(256), 0, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid, a_frag ? 1 : 0);
-        if (stats) {  // (columns ≥ n_valid of `out` are never written by any FC kernel and never enter the statistics: n_soft ≤ n_valid)
-            const int blocks = NP / FC_COLS;
-            const long pairs = (long)M * blocks;
-            hipLaunchKernelGGL(k_fc_stats, dim3((unsigned)((pairs + 63) / 64)), dim3(256), 0, st, out, out_stride, M, blocks, n_soft, stats);
+        if (stats) {  // (columns ≥ n_valid of `out` are never written by any FC kernel and never enter the statistics: n_soft < n_valid)
+            const long pairs = (long)M * FC_STAT_BLOCKS;
+            hipLaunchKernelGGL(k_fc_stats, dim3((unsigned)((pairs + 63) / 64)), dim3(256), 0, st, out, out_stride, M, n_soft, stats);
         }
         return hipGetLastError();
     }
-    if (NP % FC_COLS == 0 && K % FC_KSTEP == 0) {
-        dim3 grid((M + 127) / 128, NP / FC_COLS);
-        static const bool ring = getenv("TG_FC_BARRIER") == nullptr;  // A/B switch: the version with a workgroup barrier per K-step
-        if (ring) {
-            static LdsAttr lds_attr;
-            if (hipError_t e = lds_attr.ensure((const void*)k_fc_ring, FC_RING_LDS); e != hipSuccess) return e;
-            hipLaunchKernelGGL(k_fc_ring, grid, dim3(512), FC_RING_LDS, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid, a_frag ? 1 : 0, stats, n_soft);
-            return hipGetLastError();
-        }
-        hipLaunchKernelGGL(k_fc_lds, grid, dim3(512), 0, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid, a_frag ? 1 : 0, stats, n_soft);
+    if (fc) {
+        static LdsAttr lds_attr;
+        if (hipError_t e = lds_attr.ensure((const void*)k_fc_ring, FC_RING_LDS); e != hipSuccess) return e;
+        FcGather g{nullptr, nullptr, nullptr, 0};
+        if (gather) g = FcGather{gather->child_pidx, gather->leaf_rec, gather->child_logit, gather->stride};
+        hipLaunchKernelGGL(k_fc_ring, dim3((M + 127) / 128, FC_MAIN_BLOCKS), dim3(512), FC_RING_LDS, st, A, lda, Wp, bias, gather ? nullptr : out, M, K, NP,
+                           out_stride, n_valid, a_frag ? 1 : 0, stats, n_soft, g);
         return hipGetLastError();
     }
     dim3 grid((M + 127) / 128, NP / 64);
@@ -1792,9 +1788,9 @@ hipError_t launch_softmax(hipStream_t st, const float* logits, int row_stride, b
     return hipGetLastError();
 }
 
-hipError_t launch_softmax_stats(hipStream_t st, const float* logits, int row_stride, const float* stats, int blocks, int P, int B,
-                                float* policy, float* eval) {
-    hipLaunchKernelGGL(k_softmax_stats, dim3(B), dim3(256), 0, st, logits, row_stride, stats, blocks, P, policy, eval);
+hipError_t launch_softmax_stats(hipStream_t st, const float* logits, int row_stride, const float* stats, int blocks, int stat_stride, int P,
+                                int B, float* policy, float* eval) {
+    hipLaunchKernelGGL(k_softmax_stats, dim3(B), dim3(256), 0, st, logits, row_stride, stats, blocks, stat_stride, P, policy, eval);
     return hipGetLastError();
 }
 

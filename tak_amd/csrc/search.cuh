@@ -91,6 +91,10 @@ struct SearchDev {
     int logit_ld;
     const float* fc_stats; // with `logits`: per leaf and column block {max, Σexp(x − max)} emitted by the policy FC (softmax.cuh);
     int fc_blocks;         // null → the backup reduces the whole logits row itself
+    int fc_stride;         // pairs per leaf in fc_stats (the exact-f32 FC appends {value pre-activation, 0} behind the blocks)
+    const float* child_logit; // [G·batch][EX_MOVES] logit of every child of the expanded leaf, written by the policy FC's epilogue from
+                           // child_pidx (exact-f32 FC at full batches, round 4): then the FC writes no logits rows, the backup reads
+                           // this and the statistics record (value pre-activation = pair fc_blocks) and nothing of `logits`
     float* eval;         // [G]
     // constants
     const float* ctab;   // exploration_rate(n) for integer n (host logf, mcts.rs:10-12)

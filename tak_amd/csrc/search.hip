@@ -16,7 +16,7 @@ namespace tg {
 struct Search {
     TgSearchConfig cfg;
     SearchDev d;
-    DevBuf hot, cold, root, alloc, chunk_head, chunk_link, chunk_fwd, chunk_used, free_ring, pool_ctl, root_state, alive, generation, path_len, path, leaf_kind, leaf_rec, child_pidx, leaf_hash, planes, leaf_state, policy, eval,
+    DevBuf hot, cold, root, alloc, chunk_head, chunk_link, chunk_fwd, chunk_used, free_ring, pool_ctl, root_state, alive, generation, path_len, path, leaf_kind, leaf_rec, child_pidx, child_logit, leaf_hash, planes, leaf_state, policy, eval,
         ctab, err, counters, op, active, noise, abort;
     DevBuf r_moves, r_visits, r_prior, r_q, r_counts, r_rv, r_rq, s_moves;
     // self-play
@@ -108,6 +108,7 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     TG_HIP(hipSetDevice(e->cfg.device));
     if (e->search) {
         TG_HIP(hipStreamSynchronize(e->stream));
+        net_set_gather(e, nullptr);  // (its buffers go with the search)
         search_destroy(e->search);
         e->search = nullptr;
     }
@@ -160,6 +161,7 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     TG_HIP(s->leaf_kind.ensure(G * B));
     TG_HIP(s->leaf_rec.ensure(G * B * 8));
     TG_HIP(s->child_pidx.ensure(G * B * EX_MOVES * 2));
+    TG_HIP(s->child_logit.ensure(G * B * EX_MOVES * 4));
     TG_HIP(hipMemsetAsync(s->leaf_rec.p, 0, G * B * 8, e->stream));
     TG_HIP(s->leaf_hash.ensure(G * B * 8));
     TG_HIP(s->op.ensure(G * 4));
@@ -220,7 +222,7 @@ static int search_alloc(TgEngine* e, const TgSearchConfig* cfg) {
     d.legacy5 = e->legacy5 ? 1 : 0; d.evaluator = e->cfg.evaluator; d.slot_base = cfg->slot_base; d.seed = cfg->seed;
     d.batch = (int)B; d.pass = 0;
     d.retire = 0;  // tg_selfplay_create turns it on: only the self-play driver can restart a game on its own
-    d.logits = nullptr; d.logit_ld = 0; d.fc_stats = nullptr; d.fc_blocks = 0;  // refreshed before every iteration (bind_logits)
+    d.logits = nullptr; d.logit_ld = 0; d.fc_stats = nullptr; d.fc_blocks = 0; d.fc_stride = 0; d.child_logit = nullptr;  // refreshed before every iteration (bind_logits)
     e->search = sp.release();
     return TG_OK;
 }
@@ -246,15 +248,24 @@ static void bind_logits(TgEngine* e) {
     s->d.logit_ld = 0;
     s->d.fc_stats = nullptr;
     s->d.fc_blocks = 0;
+    s->d.fc_stride = 0;
+    s->d.child_logit = nullptr;
+    net_set_gather(e, nullptr);
     static const bool off = getenv("TG_DUAL_STREAM") != nullptr || getenv("TG_NO_FUSED_SOFTMAX") != nullptr;
     if (off || e->cfg.evaluator != TG_EVAL_RESNET) return;
     int ld = 0;
     const float* lg = net_fc_logits(e, &ld);
     if (lg) {
         s->d.logits = lg; s->d.logit_ld = ld;
-        int blocks = 0;
-        const float* fs = net_fc_stats(e, &blocks);
-        if (fs) { s->d.fc_stats = fs; s->d.fc_blocks = blocks; }
+        int blocks = 0, stride = 0;
+        const float* fs = net_fc_stats(e, &blocks, &stride);
+        if (fs) { s->d.fc_stats = fs; s->d.fc_blocks = blocks; s->d.fc_stride = stride; }
+        // exact-f32 FC at a batch its ring kernel serves: the FC's epilogue hands the backup the children's logits directly
+        if (fs && !s->d.planes && net_gather_ok(e, s->d.G * s->d.batch)) {
+            const FcGatherArgs g{s->d.child_pidx, s->d.leaf_rec, s->child_logit.as<float>(), EX_MOVES};
+            net_set_gather(e, &g);
+            s->d.child_logit = s->child_logit.as<float>();
+        }
     }
 }
 

@@ -419,7 +419,12 @@ __device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, con
     const uint32_t cb_v = S.leaf_rec[2 * slot], n_v = S.leaf_rec[2 * slot + 1];
     const uint32_t raw_idx = (uint32_t)pidx[lane], raw_idx2 = (uint32_t)pidx[lane + 64];  // (EX_MOVES ≥ 128 entries per slot)
     const uint32_t raw_nd = path[lane ? lane - 1 : 0];
-    const float vlogit_v = (S.evaluator == TG_EVAL_RESNET && lrow) ? lrow[S.P] : 0.0f;
+    // round 4: the policy FC's epilogue has already picked the children's logits out of its accumulators (child_logit, in child
+    // order): two coalesced loads in THIS round replace the dependent gather logits[pidx[child]] of round 2, and the value
+    // pre-activation comes with the statistics record
+    const float* clog = S.child_logit ? S.child_logit + slot * EX_MOVES : nullptr;
+    const float clog_v = clog ? clog[lane] : 0.0f, clog_v2 = clog ? clog[lane + 64] : 0.0f;
+    const float vlogit_v = (S.evaluator == TG_EVAL_RESNET && lrow && !clog) ? lrow[S.P] : 0.0f;
     // root_v = S.root[g] as the caller requested it, not yet waited for: it was the first request, so making it scalar here
     // waits for that one load alone, and the select's cold record of the root joins the requests above
     const uint32_t root = uni(root_v);
@@ -431,9 +436,9 @@ __device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, con
     uint64_t hsh = 0;
     float lmx = 0.0f, linv = 0.0f;
     if (S.evaluator == TG_EVAL_RESNET && lrow) {
-        const float vlogit = vlogit_v;
-        if (S.fc_stats)  // 64 B (wave-uniform address: scalar loads) instead of the whole row
-            fc_combine_stats(S.fc_stats + (size_t)uni((uint32_t)slot) * (size_t)S.fc_blocks * 2, S.fc_blocks, lmx, linv);
+        float vlogit = vlogit_v;
+        if (S.fc_stats)  // one 8-byte load per lane instead of the whole row
+            fc_combine_stats(S.fc_stats + (size_t)uni((uint32_t)slot) * (size_t)S.fc_stride * 2, S.fc_blocks, lmx, linv, clog ? &vlogit : nullptr);
         else if (live) softmax_stats_wave(lrow, S.P, lmx, linv);
         e = tanhf(vlogit);
     } else if (S.evaluator == TG_EVAL_RESNET) e = S.eval[slot];
@@ -449,7 +454,10 @@ __device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, con
         const uint32_t idx = i == (uint32_t)lane ? my_idx : i == (uint32_t)lane + 64u ? raw_idx2 : (uint32_t)pidx[i];
         float p;
         if (idx == 0xFFFFu) { bad = true; p = 0.0f; }
-        else if (S.evaluator == TG_EVAL_RESNET) p = !lrow ? pol[idx] : S.fc_stats ? stat_exp(lrow[idx] - lmx) * linv : expf(lrow[idx] - lmx) * linv;
+        else if (S.evaluator == TG_EVAL_RESNET) {
+            if (clog) p = stat_exp((i == (uint32_t)lane ? clog_v : i == (uint32_t)lane + 64u ? clog_v2 : clog[i]) - lmx) * linv;
+            else p = !lrow ? pol[idx] : S.fc_stats ? stat_exp(lrow[idx] - lmx) * linv : expf(lrow[idx] - lmx) * linv;
+        }
         else if (S.evaluator == TG_EVAL_HASH) p = hash_policy(hsh, idx);
         else p = 1.0f;
         hot[cb + i].prior = p;

@@ -1,6 +1,7 @@
 """Kernel variants selected by the launchers' A/B switches must return the same BITS: the halo-image towers against the
-plain-image ones (TG_NO_HALO_TOWER), the barrier-free policy FC against the barrier version (TG_FC_BARRIER), fragment-major
-against row-major FC input (TG_NO_FRAG_OUT), in exact f32 and on the split-bf16 path.  The switches are read once per process, so every variant runs scripts/ab_bits.py (sha256 of
+plain-image ones (TG_NO_HALO_TOWER), fragment-major against row-major FC input (TG_NO_FRAG_OUT), in exact f32 and on the
+split-bf16 path; the ring FC against the small-batch FC is covered by test_gpu_net (batch independence), the FC's gather epilogue
+against the logits-row epilogue by test_fc_gather_epilogue_builds_the_same_trees below.  The switches are read once per process, so every variant runs scripts/ab_bits.py (sha256 of
 policy + eval of 4093 positions of one BASELINE topology, a ragged last workgroup included) in its own process."""
 import os
 import subprocess
@@ -13,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _digest(cfg, batch, **env):
     e = dict(os.environ)
-    for k in ("TG_NO_HALO_TOWER", "TG_FC_BARRIER", "TG_NO_FRAG_OUT", "TG_PRECISION", "TG_NO_CONST_BIAS", "TG_NO_FC_STATS"):
+    for k in ("TG_NO_HALO_TOWER", "TG_NO_FC_GATHER", "TG_NO_FRAG_OUT", "TG_PRECISION", "TG_NO_CONST_BIAS", "TG_NO_FC_STATS"):
         e.pop(k, None)
     e.update(env)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "ab_bits.py"), cfg, str(batch)], env=e, check=True,
@@ -28,9 +29,7 @@ def test_launcher_variants_return_identical_bits(cfg, batch):
     assert len(base) == 64
     assert _digest(cfg, batch, TG_NO_HALO_TOWER="1") == base
     if cfg != "c3":  # FC policy head
-        assert _digest(cfg, batch, TG_FC_BARRIER="1") == base
         assert _digest(cfg, batch, TG_NO_FRAG_OUT="1") == base  # row-major tower output into the ring FC
-        assert _digest(cfg, batch, TG_NO_FRAG_OUT="1", TG_FC_BARRIER="1") == base
     # layer 0 with every input plane as data (the order of round 2) is another summation order: other low bits, and ITS
     # halo / plain variants agree with each other
     dense = _digest(cfg, batch, TG_NO_CONST_BIAS="1")
@@ -39,3 +38,47 @@ def test_launcher_variants_return_identical_bits(cfg, batch):
     s3 = _digest(cfg, batch, TG_PRECISION="bf16x3")
     assert s3 != base
     assert _digest(cfg, batch, TG_PRECISION="bf16x3", TG_NO_HALO_TOWER="1") == s3
+
+
+TREE_DIGEST = r"""
+import hashlib, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+import numpy as np
+import tak_amd, torch_ref
+from oracle import oracle as orc
+G = 1024
+net = torch_ref.make_net(5, 2, 64, "fc5", seed=5)
+e = tak_amd.Engine(5, res_blocks=2, filters=64, evaluator=tak_amd.EVAL_RESNET, max_batch=G)
+e.load_state_dict(torch_ref.abi_tensors(net))
+base = orc.random_positions(5, 3000, seed=9, max_plies=60, half_komi=4)
+base = base[orc.result(5, base) == 0]
+sts = np.tile(base, (G // len(base) + 1, 1))[:G]
+e.search_create(G, arena_nodes=1 << 12)
+e.search_reset(sts)
+e.search_run(40)
+h = hashlib.sha256()
+for g in range(0, G, 7):
+    d = e.search_dump(g)
+    for f in d.dtype.names:
+        h.update(np.ascontiguousarray(d[f]).tobytes())
+r = e.search_root()
+for k in sorted(r):
+    h.update(np.ascontiguousarray(r[k]).tobytes())
+print("DIGEST", h.hexdigest())
+"""
+
+
+@pytest.mark.gpu
+def test_fc_gather_epilogue_builds_the_same_trees():
+    """Search iterations at ≥ 513 leaves run the policy FC with its gather epilogue (no logits rows: the children's logits of every
+    leaf and the statistics record with the value pre-activation); TG_NO_FC_GATHER=1 writes the logits rows and lets the backup
+    gather — the round-3 data flow.  Same logits, same statistics, so the same trees, bit for bit: 147 whole trees and all roots
+    of 1024 games after 40 iterations."""
+    def digest(**env):
+        e = {k: v for k, v in os.environ.items() if not k.startswith("TG_")}
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", TREE_DIGEST.format(root=ROOT)], env=e, check=True, capture_output=True, text=True,
+                             timeout=600).stdout
+        return [l for l in out.splitlines() if l.startswith("DIGEST")][-1].split()[1]
+
+    assert digest() == digest(TG_NO_FC_GATHER="1")

@@ -965,7 +965,10 @@ struct FcGather {
 // the LDS-DMA pieces' issue slots beside the fragment reads and waves held back for a slower one; the MFMAs of the 88 padded
 // columns were 3.2 µs, the logits burst 3.7 µs.  Measured and discarded: a ninth wave that only fills the ring (8 – 10 µs
 // slower), non-temporal logits stores, the barrier version k_fc_lds (rounds 1 – 3: + 6 µs), a register-tiled FC without LDS
-// (k_fc_reg, scripts/probes/fc_reg.cuh: 227 µs — 2.7 × the operand bytes through the vector-memory path).
+// (k_fc_reg, scripts/probes/fc_reg.cuh: 227 µs — 2.7 × the operand bytes through the vector-memory path); round 4 also: a static
+// s_setprio 1 for waves 4-7 (−1 µs, inside the noise) or for waves 0-3 (0), and waves 4-7 issuing their share of a refill half a
+// step after waves 0-3 so that the two waves of a SIMD never issue LDS-DMA pieces at the same time (+ 11 µs: the older wave of
+// a SIMD runs ahead of the younger one anyway, and the later refill makes the younger one the workgroup's laggard).
 constexpr int FC_RING = 3;
 constexpr int FC_RING_SLOTS = 4 * FC_PLANE;                                        // f32x4 slots per buffer (3328)
 constexpr size_t FC_RING_LDS = (size_t)FC_RING * FC_RING_SLOTS * 16 + 2 * FC_RING * sizeof(uint32_t);

@@ -148,6 +148,106 @@ __global__ __launch_bounds__(512) void probe3(float* out, const f32x4* __restric
         for (int j = 0; j < 3; j++) s += acc[i][j];
     out[blockIdx.x * 512 + tid] = s[0] + s[1] + s[2] + s[3];
 }
+// ------------------------------------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) for one F -> F layer of the C2 tower (16 positions per workgroup, 64 -> 64, 5x5 board): a stand-in for
+// its MAIN LOOP that keeps every cost the real one has and drops what could only make it slower.  9 output tiles of 2x2 per
+// position -> 144 (position, tile) rows = 9 MFMA row tiles; 16 transformed elements x 4 output-channel tiles; K = 64.
+// A wave owns (row tile, channel tile) pairs with all 16 elements (64 accumulator registers: the output transform A^T M A needs the
+// 16 elements of a row in ONE wave — there is no LDS left to exchange them: the image fills it); 36 pairs: waves 0-3 take 5,
+// waves 4-7 take 4 (9 per SIMD).  Per (pair, 16-channel chunk) UNIT: the 4x4 input patch of the lane's row from the LDS image
+// (16 ds_read_b128 at immediate offsets), V = B^T d B in registers (32 f32x4 add/sub), the 16 transformed-weight fragments of the
+// channel tile (16 x 1 KB from the 256 KB U table of the layer: L1 / L2), 64 MFMAs.  Not modelled: the output transform
+// (24 f32x4 add/sub per pair), the wider halo the 6x6 coverage needs (it does not fit beside 16 positions), bias / ReLU / skip.
+// VAR bit 0: no weight stream (U fragments stay in registers); bit 1: no input transform; bit 2: no LDS reads.
+// ------------------------------------------------------------------------------------------------------------------
+template <int VAR>
+__global__ __launch_bounds__(512) void probe_wino(float* out, const f32x4* __restrict__ U, int layers) {
+    extern __shared__ f32x4 img[];  // 583 cells x 17 slots (the tower's halo image, 158.6 KB)
+    const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 583 * 17; i += 512) img[i] = f32x4{0.001f * (i % 97), 0.5f, -0.25f, 0.002f * (i % 31)};
+    __syncthreads();
+    const int ct = wave & 3, npairs = wave < 4 ? 5 : 4, rt0 = wave < 4 ? 0 : 5;
+    const f32x4* ub = U + ((size_t)(ct * 16 + r16) * 4 + q);  // fragment (element e, chunk c) at ((e*4 + c)*64 + col)*4 + q slots
+    f32x4 s = f32x4{0, 0, 0, 0};
+    for (int layer = 0; layer < layers; layer++) {
+        for (int pr = 0; pr < npairs; pr++) {
+            const int row = (rt0 + pr) * 16 + r16;      // (position, tile)
+            const int pos = row / 9, tile = row - pos * 9, ty = tile / 3, tx = tile - ty * 3;
+            int base = (7 + pos * 36 + (2 * ty) * 6 + 2 * tx) * 17 + q;  // top-left cell of the 4x4 patch
+            base = min(base, (583 - 22) * 17);                           // (the last tiles would reach past the image: clamp)
+            f32x4 acc[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[e] = f32x4{0, 0, 0, 0};
+#pragma unroll 1
+            for (int c = 0; c < 4; c++) {
+                f32x4 d[4][4], w[16];
+#pragma unroll
+                for (int e = 0; e < 16; e++) w[e] = (VAR & 1) ? f32x4{0.01f * e, 0.02f, 0.03f, 0.04f} : ub[(size_t)((e * 4 + c) * 64) * 4 + (size_t)layer * 0];
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+#pragma unroll
+                    for (int x = 0; x < 4; x++) d[y][x] = (VAR & 4) ? f32x4{0.1f * y, 0.2f * x, 0.3f, 0.4f} : img[base + (y * 6 + x) * 17 + c * 4];
+                f32x4 v[4][4];
+                if (VAR & 2) {
+#pragma unroll
+                    for (int y = 0; y < 4; y++)
+#pragma unroll
+                        for (int x = 0; x < 4; x++) v[y][x] = d[y][x];
+                } else {  // V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+                    f32x4 t[4][4];
+#pragma unroll
+                    for (int x = 0; x < 4; x++) {
+                        t[0][x] = d[0][x] - d[2][x];
+                        t[1][x] = d[1][x] + d[2][x];
+                        t[2][x] = d[2][x] - d[1][x];
+                        t[3][x] = d[1][x] - d[3][x];
+                    }
+#pragma unroll
+                    for (int y = 0; y < 4; y++) {
+                        v[y][0] = t[y][0] - t[y][2];
+                        v[y][1] = t[y][1] + t[y][2];
+                        v[y][2] = t[y][2] - t[y][1];
+                        v[y][3] = t[y][1] - t[y][3];
+                    }
+                }
+#pragma unroll
+                for (int t4 = 0; t4 < 4; t4++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e][t4], v[e >> 2][e & 3][t4], acc[e], 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; e++) s += acc[e];
+        }
+        asm volatile("" : "+v"(s));
+    }
+    out[blockIdx.x * 512 + tid] = s[0] + s[1] + s[2] + s[3];
+}
+template <int VAR>
+void run_wino(const char* name) {
+    float* d; hipMalloc(&d, 256 * 512 * 4);
+    f32x4* U; hipMalloc(&U, 16 * 4 * 64 * 4 * 16);
+    float* h = (float*)malloc(16 * 4 * 64 * 4 * 16);
+    for (int i = 0; i < 16 * 4 * 64 * 4 * 4; i++) h[i] = ((float)rand() / (float)RAND_MAX - 0.5f) * 0.1f;
+    hipMemcpy(U, h, 16 * 4 * 64 * 4 * 16, hipMemcpyHostToDevice);
+    const size_t lds = 583 * 17 * 16;
+    hipFuncSetAttribute((const void*)probe_wino<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms[2];
+    for (int k = 0; k < 2; k++) {
+        const int layers = k == 0 ? 12 : 36;
+        probe_wino<VAR><<<256, 512, lds>>>(d, U, 2);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        for (int rep = 0; rep < 10; rep++) probe_wino<VAR><<<256, 512, lds>>>(d, U, layers);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms[k], e0, e1);
+        ms[k] /= 10;
+    }
+    const double per_layer_us = (ms[1] - ms[0]) / 24 * 1000;
+    printf("%-58s %.1f us per layer (direct conv_mainloop_halo: 51; MFMA issue alone: %.1f)\n", name, per_layer_us, 9216.0 / 4 * 32 / 2.4e3);
+    hipFree(d); hipFree(U); free(h);
+}
 template <int ORDER>
 void run3(const char* name, int threads, bool random) {
     float* d; hipMalloc(&d, 256 * 512 * 4);
@@ -168,6 +268,11 @@ void run3(const char* name, int threads, bool random) {
     hipFree(d); hipFree(src); free(h);
 }
 int main() {
+    run_wino<0>("Winograd F(2x2,3x3) main-loop stand-in, everything");
+    run_wino<1>("  without the transformed-weight stream");
+    run_wino<2>("  without the input transform");
+    run_wino<4>("  without the LDS reads");
+    run_wino<7>("  MFMAs only");
     run3<0>("4x3 register tile, order t,i,j", 512, true);
     run3<0>("4x3 register tile, order t,i,j", 512, false);
     run3<1>("4x3 register tile, order t,j,i", 512, true);

@@ -26,6 +26,7 @@ step "board pass micro-benchmark and its instruction mix"
 python3 $R/scripts/bench_board.py > $O/board_pass_5x5.json 2> $O/board.err
 python3 $R/scripts/bench_board.py --board 6 > $O/board_pass_6x6.json 2>> $O/board.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_board -o p -- python3 $R/scripts/bench_board.py --reps 3 > /dev/null 2>> $O/board.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_board6 -o p -- python3 $R/scripts/bench_board.py --board 6 --reps 3 > /dev/null 2>> $O/board.err
 step "HBM traffic counters, board pass (5x5 and 6x6)"
 rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_WRREQ --output-format csv -d $O/pmc_board_t5 -o p -- python3 $R/scripts/bench_board.py --reps 3 > /dev/null 2>> $O/board.err
 rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_WRREQ --output-format csv -d $O/pmc_board_t6 -o p -- python3 $R/scripts/bench_board.py --board 6 --reps 3 > /dev/null 2>> $O/board.err
@@ -38,12 +39,13 @@ $P $R/scripts/pmc_traffic.py $(find $O/pmc_traffic -name '*counter_collection.cs
 for d in pmc_sq1 pmc_sq2; do $P $R/scripts/pmc_summary.py $(find $O/$d -name '*counter_collection.csv' | head -1) k_tower_halo k_fc_ring; done > $O/pmc_sq_tower_fc.txt
 $P $R/scripts/pmc_summary.py $(find $O/pmc_tree -name '*counter_collection.csv' | head -1) k_backup_select k_select k_reroot > $O/pmc_tree_kernels.txt
 $P $R/scripts/pmc_summary.py $(find $O/pmc_board -name '*counter_collection.csv' | head -1) k_board_pass > $O/pmc_board_pass_instruction_mix.txt
+$P $R/scripts/pmc_summary.py $(find $O/pmc_board6 -name '*counter_collection.csv' | head -1) k_board_pass >> $O/pmc_board_pass_instruction_mix.txt
 # board pass: 2^20 positions x (state in + state out + unpadded f32 planes) = 7712 B (5x5) / 14016 B (6x6)
 $P $R/scripts/pmc_traffic.py $(find $O/pmc_board_t5 -name '*counter_collection.csv' | head -1) k_board_pass 8086618112 $O/pmc_traffic_k_board_pass_5x5.json > /dev/null
 $P $R/scripts/pmc_traffic.py $(find $O/pmc_board_t6 -name '*counter_collection.csv' | head -1) k_board_pass 14696841216 $O/pmc_traffic_k_board_pass_6x6.json > /dev/null
 cp $(find $O/kt_bench -name '*kernel_stats.csv' | head -1) $O/kernel_stats_bench.csv 2>/dev/null
 cp $(find $O/kt_train -name '*kernel_stats.csv' | head -1) $O/kernel_stats_train_step.csv 2>/dev/null
 # the raw traces are large: keep the summaries only
-rm -rf $O/kt_bench $O/kt_train $O/pmc_traffic $O/pmc_sq1 $O/pmc_sq2 $O/pmc_tree $O/pmc_board $O/pmc_board_t5 $O/pmc_board_t6
+rm -rf $O/kt_bench $O/kt_train $O/pmc_traffic $O/pmc_sq1 $O/pmc_sq2 $O/pmc_tree $O/pmc_board $O/pmc_board6 $O/pmc_board_t5 $O/pmc_board_t6
 ls -la $O
 step "done"

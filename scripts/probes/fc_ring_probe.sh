@@ -4,6 +4,7 @@
 # rocprofv3 --kernel-trace --stats and prints the average k_fc_ring launch.  Run on the GPU box:
 #   bash scripts/probes/fc_ring_probe.sh "0 64 128 192"
 set -u
+EXTRA_DEFS=${EXTRA_DEFS:-}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 B=$R/scripts/probes/_bin
 O=$R/gpurun_out/fc_probe
@@ -12,7 +13,7 @@ FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-
 OBJS=$(ls $R/tak_amd/csrc/_obj/*.o | grep -v net_kernels.o)
 cd /tmp && export TMPDIR=/tmp
 for m in ${1:-0 64 128 192}; do
-    /opt/rocm/bin/hipcc $FLAGS -D${PROBE_MACRO:-TG_RING_PROBE}=$m -c $R/tak_amd/csrc/net_kernels.hip -o $B/net_kernels_p$m.o || exit 1
+    /opt/rocm/bin/hipcc $FLAGS -D${PROBE_MACRO:-TG_RING_PROBE}=$m $EXTRA_DEFS -c $R/tak_amd/csrc/net_kernels.hip -o $B/net_kernels_p$m.o || exit 1
     /opt/rocm/bin/hipcc $FLAGS -shared -o $B/libtakgpu_fc_p$m.so $OBJS $B/net_kernels_p$m.o -ldl || exit 1
     export TAKGPU_LIB=$B/libtakgpu_fc_p$m.so
     rm -rf $O/kt_$m

@@ -17,6 +17,8 @@ step "kernel trace of the training step"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_train -o kt -- python3 $R/scripts/train_step_ab.py 10 > $O/train_step.json 2> $O/kt_train.err
 step "HBM traffic counters, forward C2"
 rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_WRREQ --output-format csv -d $O/pmc_traffic -o p -- python3 $R/scripts/ab_forward.py c2 > $O/ab_forward_c2_under_pmc.json 2> $O/pmc_traffic.err
+step "HBM traffic counters, policy FC inside the search loop (gather epilogue)"
+rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_WRREQ --output-format csv -d $O/pmc_traffic_bench -o p -- python3 $R/bench.py --no-extras --no-cpu-baseline --no-alt-precision --no-train --steps 1 --warmup 1 > /dev/null 2> $O/pmc_traffic_bench.err
 step "SQ counters, forward C2 (two passes)"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq1 -o p -- python3 $R/scripts/ab_forward.py c2 > /dev/null 2> $O/pmc_sq1.err
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_SALU SQ_INSTS_VMEM GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq2 -o p -- python3 $R/scripts/ab_forward.py c2 > /dev/null 2> $O/pmc_sq2.err
@@ -36,6 +38,8 @@ step "summaries"
 P=python3
 $P $R/scripts/pmc_traffic.py $(find $O/pmc_traffic -name '*counter_collection.csv' | head -1) k_tower_halo 27262976 $O/pmc_traffic_k_tower_halo.json > /dev/null
 $P $R/scripts/pmc_traffic.py $(find $O/pmc_traffic -name '*counter_collection.csv' | head -1) k_fc_ring 36836352 $O/pmc_traffic_k_fc_ring.json > /dev/null
+# search loop: activations 26.2 MB + the 99 tiles' weights 10.1 MB + child_pidx 1.0 MB in, children's logits 0.7 MB + statistics 0.4 MB out
+$P $R/scripts/pmc_traffic.py $(find $O/pmc_traffic_bench -name '*counter_collection.csv' | head -1) k_fc_ring 38563840 $O/pmc_traffic_k_fc_ring_gather.json > /dev/null
 for d in pmc_sq1 pmc_sq2; do $P $R/scripts/pmc_summary.py $(find $O/$d -name '*counter_collection.csv' | head -1) k_tower_halo k_fc_ring; done > $O/pmc_sq_tower_fc.txt
 $P $R/scripts/pmc_summary.py $(find $O/pmc_tree -name '*counter_collection.csv' | head -1) k_backup_select k_select k_reroot > $O/pmc_tree_kernels.txt
 $P $R/scripts/pmc_summary.py $(find $O/pmc_board -name '*counter_collection.csv' | head -1) k_board_pass > $O/pmc_board_pass_instruction_mix.txt
@@ -46,6 +50,6 @@ $P $R/scripts/pmc_traffic.py $(find $O/pmc_board_t6 -name '*counter_collection.c
 cp $(find $O/kt_bench -name '*kernel_stats.csv' | head -1) $O/kernel_stats_bench.csv 2>/dev/null
 cp $(find $O/kt_train -name '*kernel_stats.csv' | head -1) $O/kernel_stats_train_step.csv 2>/dev/null
 # the raw traces are large: keep the summaries only
-rm -rf $O/kt_bench $O/kt_train $O/pmc_traffic $O/pmc_sq1 $O/pmc_sq2 $O/pmc_tree $O/pmc_board $O/pmc_board6 $O/pmc_board_t5 $O/pmc_board_t6
+rm -rf $O/kt_bench $O/kt_train $O/pmc_traffic $O/pmc_traffic_bench $O/pmc_sq1 $O/pmc_sq2 $O/pmc_tree $O/pmc_board $O/pmc_board6 $O/pmc_board_t5 $O/pmc_board_t6
 ls -la $O
 step "done"

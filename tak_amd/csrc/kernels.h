@@ -115,8 +115,11 @@ bool fc_s3_supported(int K, int NP);
 int fc_s3_cols(int NP);
 // Wp: [chunk of 32 k][NP/208 column blocks][q][hi|lo][208 outputs][8 bf16], k = sq·F + c
 // stats (optional, NP % 112 == 0): block-wise softmax statistics over columns < n_soft, [M][NP/112][2] (softmax.cuh)
-hipError_t launch_fc_s3(hipStream_t st, const float* act_split, const void* Wp, const float* bias, float* out, int M, int K, int NP,
-                        int out_stride, int n_valid, float* stats = nullptr, int n_soft = 0);
+struct FcGatherArgs;
+hipError_t launch_fc_s3(hipStream_t st, const float* act_split, const void* Wp, const void* Wr, const float* bias, float* out, int M, int K, int NP,
+                        int out_stride, int n_valid, float* stats = nullptr, int n_soft = 0, const FcGatherArgs* gather = nullptr);
+bool fc_s3_ring_supported(int M, int K, int n_valid);
+hipError_t launch_fc_stats(hipStream_t st, const float* logits, int ld, int M, int n_soft, float* stats);  // softmax.cuh's statistics of logits in memory
 hipError_t launch_value_head_s3(hipStream_t st, const float* act_split, const float* wv, float bv, int B, int len, float* eval);
 // a_frag: A is in the fragment-major order of TowerParams.frag_out (needs fc_frag_supported(K, NP))
 // stats (optional, needs fc_stats_supported): the block-wise softmax statistics of softmax.cuh over columns < n_soft,

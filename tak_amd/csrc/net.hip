@@ -33,6 +33,8 @@ struct Net {
     float value_b = 0.0f;
     // activations (max_batch positions)
     DevBuf x, y, logits, planes_nhwc, planes_nchw;
+    DevBuf s3_fc_ring;                // the same weights in k_fc_s3_ring's layout [chunk of 32][tile 0 … 98][hi|lo][lane] (full batches)
+    bool s3_fc_ring_on = false;
     DevBuf fc_stats;                  // [max_batch][fc_stat_blocks][2]: block-wise softmax statistics of the policy FC (softmax.cuh)
     bool fc_stats_on = false;
     int fc_stat_blocks = 0;           // FC_STAT_BLOCKS (11) on the exact path, s3_np / 112 on the split-bf16 FC
@@ -457,6 +459,29 @@ int net_finalize(TgEngine* e) {
             }
             TG_HIP(n->s3_fc.ensure(ws.size() * 2));
             TG_HIP(hipMemcpy(n->s3_fc.p, ws.data(), ws.size() * 2, hipMemcpyHostToDevice));
+            // the ring kernel's copy: [chunk][tile][hi|lo][lane = q·16 + column within the tile][8 bf16]: a (chunk, tile, half) block
+            // is one KB in the reader's lane order = one LDS-DMA instruction
+            n->s3_fc_ring_on = false;
+            if (P + 1 <= FC_TILES * 16 && K % 64 == 0) {
+                std::vector<uint16_t> wr((size_t)(K / 32) * FC_TILES * 2 * 64 * 8, 0);
+                auto put = [&](size_t o, size_t k, float v) {
+                    uint16_t hi = f32_to_bf16(v), lo = f32_to_bf16(v - bf16_to_f32(hi));
+                    const size_t lane = ((k & 31) >> 3) * 16 + (o & 15);
+                    const size_t slot = (((k >> 5) * FC_TILES + (o >> 4)) * 2) * 64 + lane;
+                    wr[slot * 8 + (k & 7)] = hi;
+                    wr[(slot + 64) * 8 + (k & 7)] = lo;
+                };
+                for (int o = 0; o < P; o++)
+                    for (size_t k = 0; k < K; k++) put((size_t)o, k, (*w)[(size_t)o * K + (size_t)(k % F) * nsq + k / F]);
+                if (n->value_in_fc && NP > P) {
+                    auto wv = find(n, "value.weight", K, err);
+                    if (!wv) return fail(TG_ERR_WEIGHTS, err);
+                    for (size_t k = 0; k < K; k++) put((size_t)P, k, (*wv)[(size_t)(k % F) * nsq + k / F]);
+                }
+                TG_HIP(n->s3_fc_ring.ensure(wr.size() * 2));
+                TG_HIP(hipMemcpy(n->s3_fc_ring.p, wr.data(), wr.size() * 2, hipMemcpyHostToDevice));
+                n->s3_fc_ring_on = true;
+            }
             std::vector<float> bp(NP, 0.0f);
             std::copy(bsrc->begin(), bsrc->end(), bp.begin());
             if (n->value_in_fc && NP > P) bp[P] = n->value_b;
@@ -475,10 +500,12 @@ int net_finalize(TgEngine* e) {
     TG_HIP(n->planes_nhwc.ensure(mb * nsq * n->cin_pad * 4));
     // f32 FC head with the value column: the FC emits the softmax statistics per column block, nobody re-reads whole rows
     const bool s3fc = n->s3 && n->s3_fc_on;
-    n->fc_stats_on = e->cfg.policy_head == TG_HEAD_FC5 && n->value_in_fc && !getenv("TG_NO_FC_STATS") &&
-                     (s3fc ? (n->s3_np % 112 == 0 && n->s3_np / 112 <= 64) : fc_stats_supported(nsq * F, n->policy_np, n->policy_np));
-    n->fc_stat_blocks = n->fc_stats_on ? (s3fc ? n->s3_np / 112 : FC_STAT_BLOCKS) : 0;
-    n->fc_stat_stride = n->fc_stats_on ? (s3fc ? n->fc_stat_blocks : FC_STAT_STRIDE) : 0;
+    // (one statistics geometry — softmax.cuh — on both precisions since round 4: the split-bf16 FC's ring kernel emits it from its
+    // epilogue, k_fc_stats computes it behind k_fc_s3b for ≤ 512 rows)
+    n->fc_stats_on = e->cfg.policy_head == TG_HEAD_FC5 && n->value_in_fc && !getenv("TG_NO_FC_STATS") && e->policy_size + 1 <= FC_TILES * 16 &&
+                     (s3fc ? n->s3_np >= FC_TILES * 16 : fc_stats_supported(nsq * F, n->policy_np, n->policy_np));
+    n->fc_stat_blocks = n->fc_stats_on ? FC_STAT_BLOCKS : 0;
+    n->fc_stat_stride = n->fc_stats_on ? FC_STAT_STRIDE : 0;
     if (n->fc_stats_on) TG_HIP(n->fc_stats.ensure(mb * (size_t)n->fc_stat_stride * 2 * 4));
     n->ready = true;
     return TG_OK;
@@ -523,8 +550,9 @@ bool net_gather_ok(const TgEngine* e, int leaves) {
     if (!net_ready(e)) return false;
     const Net* n = e->net;
     static const bool off = getenv("TG_NO_FC_GATHER") != nullptr;  // A/B: logits rows + the backup's own gather (same bits)
-    return !off && e->cfg.policy_head == TG_HEAD_FC5 && !n->s3 && n->fc_stats_on && n->value_in_fc &&
-           fc_gather_supported(leaves, e->g.nsq * n->F, n->policy_np);
+    if (off || e->cfg.policy_head != TG_HEAD_FC5 || !n->fc_stats_on || !n->value_in_fc) return false;
+    if (n->s3) return n->s3_fc_on && n->s3_fc_ring_on && !getenv("TG_S3_NO_FC_RING") && fc_s3_ring_supported(leaves, e->g.nsq * n->F, e->policy_size + 1);
+    return fc_gather_supported(leaves, e->g.nsq * n->F, n->policy_np);
 }
 void net_set_gather(TgEngine* e, const FcGatherArgs* g) {
     if (!e || !e->net) return;
@@ -617,8 +645,9 @@ static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const ui
         TG_HIP(launch_softmax(st, logits, nsq * L.cout_pad, true, nsq, L.cout_pad, e->policy_size, nb, d_policy));
     } else if (n->s3 && n->s3_fc_on) {
         float* stats = n->fc_stats_on ? n->fc_stats.as<float>() + (size_t)pos0 * n->fc_stat_stride * 2 : nullptr;
-        TG_HIP(launch_fc_s3(st, x, n->s3_fc.p, n->s3_fc_b.as<float>(), logits, nb, nsq * F, n->s3_np, n->s3_np, e->policy_size + (n->value_in_fc ? 1 : 0),
-                            stats, e->policy_size));
+        const bool gather = !d_policy && pos0 == 0 && n->gather_on && net_gather_ok(e, nb);
+        TG_HIP(launch_fc_s3(st, x, n->s3_fc.p, n->s3_fc_ring_on ? n->s3_fc_ring.p : nullptr, n->s3_fc_b.as<float>(), logits, nb, nsq * F, n->s3_np, n->s3_np,
+                            e->policy_size + (n->value_in_fc ? 1 : 0), stats, e->policy_size, gather ? &n->gather : nullptr));
         if (d_policy && stats) TG_HIP(launch_softmax_stats(st, logits, n->s3_np, stats, n->fc_stat_blocks, n->fc_stat_stride, e->policy_size, nb, d_policy, d_eval));
         else if (d_policy) TG_HIP(launch_softmax(st, logits, n->s3_np, false, nsq, 0, e->policy_size, nb, d_policy, n->value_in_fc ? d_eval : nullptr));
     } else {

@@ -31,6 +31,7 @@
 
 #include "board.cuh"
 #include "conv_mainloop.cuh"
+#include "fc_ring.cuh"
 #include "softmax.cuh"
 #include "tower_cb.cuh"
 #include "kernels.h"
@@ -932,25 +933,6 @@ constexpr int FC_CT = FC_MAIN_TILES + 1;  // tile slots per workgroup: 12 main +
 constexpr int FC_KSTEP = 64;              // 4 chunks of 16
 constexpr int FC_PLANE = (FC_KSTEP / 16) * FC_CT * 16;  // 832 slots per k-quarter plane (≡ 0 mod 16)
 
-// which leftover tile (l), from which row tile on (s), for how many row tiles (ne) workgroup column cb computes it
-struct FcExtra { int l, s, ne; };
-__host__ __device__ inline FcExtra fc_extra(int cb) {
-    if (cb < 6) { const int g = cb % 3; return FcExtra{cb / 3, 3 * g, g < 2 ? 3 : 2}; }
-    return FcExtra{2, 4 * (cb - 6), 4};
-}
-
-// What a search iteration needs of the FC's output is not the 1576 logits of a leaf but the ≈ 45 of its children: with
-// `gather` set the epilogue writes NO logits row; every wave parks its 16 rows × 13 tiles in LDS and copies, for each of its
-// rows, the logits of that leaf's children (child_pidx: the policy index of child c, recorded by the select kernel) that fall
-// into its columns to child_logit[row][c] — 0.7 MB per iteration instead of a 27 MB logits burst that the tree backup then
-// gathers 45 of 1664 floats from.  The statistics record carries the value pre-activation (pair FC_STAT_BLOCKS).
-struct FcGather {
-    const uint16_t* child_pidx;  // [M][stride] policy index per child of row's leaf, 0xFFFF = unmapped
-    const uint32_t* leaf_rec;    // [M][2]: {children block, child count}
-    float* child_logit;          // [M][stride]
-    int stride;                  // EX_MOVES
-};
-
 // Barrier-free ring: three weight buffers of one K-step filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, no
 // ds_write phase, 16 cache lines per instruction); the eight waves synchronise through two sets of monotonic counters in LDS
 // instead of s_barrier:
@@ -972,19 +954,6 @@ struct FcGather {
 constexpr int FC_RING = 3;
 constexpr int FC_RING_SLOTS = 4 * FC_PLANE;                                        // f32x4 slots per buffer (3328)
 constexpr size_t FC_RING_LDS = (size_t)FC_RING * FC_RING_SLOTS * 16 + 2 * FC_RING * sizeof(uint32_t);
-// flags are read and bumped with explicit LDS instructions: a volatile access through a generic pointer becomes a flat load
-// with s_waitcnt vmcnt(0), which would drain the LDS-DMA loads in flight at every poll
-__device__ __forceinline__ void fc_ring_wait(uint32_t flag_addr, uint32_t target) {
-    for (;;) {
-        uint32_t v;
-        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(flag_addr) : "memory");
-        if (__builtin_amdgcn_readfirstlane((int)v) >= (int)target) break;
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
-__device__ __forceinline__ void fc_ring_signal(uint32_t flag_addr) {
-    if ((threadIdx.x & 63) == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(flag_addr), "v"(1u) : "memory");
-}
 __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, int lda, const float* __restrict__ Wp,
                                                  const float* __restrict__ bias, float* __restrict__ out, int M, int K, int NP,
                                                  int out_stride, int n_valid, int a_frag, float* __restrict__ stats, int n_soft,
@@ -1773,6 +1742,12 @@ hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp,
     }
     dim3 grid((M + 127) / 128, NP / 64);
     hipLaunchKernelGGL((k_gemm<2, 1>), grid, dim3(256), 0, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid);
+    return hipGetLastError();
+}
+
+hipError_t launch_fc_stats(hipStream_t st, const float* logits, int ld, int M, int n_soft, float* stats) {
+    const long pairs = (long)M * FC_STAT_BLOCKS;
+    hipLaunchKernelGGL(k_fc_stats, dim3((unsigned)((pairs + 63) / 64)), dim3(256), 0, st, logits, ld, M, n_soft, stats);
     return hipGetLastError();
 }
 

@@ -29,6 +29,7 @@
 #include "board.cuh"
 #include "conv_mainloop.cuh"
 #include "softmax.cuh"
+#include "fc_ring.cuh"
 #include "tower_cb.cuh"
 #include "kernels.h"
 
@@ -1038,6 +1039,258 @@ __global__ __launch_bounds__(NW * 64) void k_fc_s3b(const u32x4* __restrict__ A,
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// k_fc_s3_ring (round 4) — the policy FC on split operands with k_fc_ring's structure (net_kernels.hip): 128 rows × (12 main + 1
+// leftover) output tiles per workgroup, 32 × 8 workgroups, the 99 tiles and the statistics geometry of softmax.cuh, the weights
+// of a K-step of 64 (2 chunks of 32 × 13 tile slots × hi | lo = 52 blocks of 1 KB) through a three-buffer LDS-DMA ring with flag
+// counters, statistics + value pre-activation + logits rows or the children's logits from the epilogue.  What differs: FOUR waves
+// (one per SIMD), each with TWO row tiles (a weight fragment pair feeds 6 MFMAs; with one row tile per wave the 26 ds_read_b128
+// per 39 MFMAs of 16 cycles would take two thirds of the LDS's cycles), `v_mfma_f32_16x16x32_bf16`, three per product in the order
+// of k_fc_s3b (w_hi·a_hi, w_hi·a_lo, w_lo·a_hi per chunk, chunks ascending) → the same logits bits as k_fc_s3b, which keeps
+// serving ≤ 512 rows (statistics behind it by k_fc_stats).  k_fc_s3b moved 737 MB per launch through the CUs' vector-memory ports
+// (every 4-wave workgroup of 128 × 112 staged its weights through registers and read its activations straight from global: MFMA
+// busy 0.36); here a CU takes in 1.33 MB of weights by LDS-DMA and 0.82 MB of activations.
+// Weights: Wr[chunk of 32][tile 0 … 98][hi | lo][lane] 16-byte slots, lane = q·16 + column — a block is 1 KB in the reader's lane order.
+// ------------------------------------------------------------------------------------------------------------------
+#ifndef TG_FSR_NW
+#define TG_FSR_NW 8
+#endif
+#ifndef TG_FSR_PROBE
+#define TG_FSR_PROBE 0  // timing probes (wrong results): 1 = no refills and no flags, 2 = no activation stream, 4 = half the LDS fragment reads
+#endif
+constexpr int FSR_NW = TG_FSR_NW;                           // waves per workgroup (4: one per SIMD, two row tiles each; 8: two per SIMD, one row tile each)
+constexpr int FSR_RT = 8 / FSR_NW;                          // row tiles per wave
+constexpr int FSR_CT = FC_MAIN_TILES + 1;                   // 13 tile slots
+constexpr int FSR_BLOCKS = 2 * FSR_CT * 2;                  // 1 KB blocks per K-step: chunk × tile slot × hi|lo = 52
+constexpr int FSR_SLOTS = FSR_BLOCKS * 64;                  // 3328 slots per buffer
+constexpr int FSR_RING = 3;
+constexpr size_t FSR_LDS = (size_t)FSR_RING * FSR_SLOTS * 16 + 2 * FSR_RING * sizeof(uint32_t);
+constexpr int FSR_PER = (FSR_BLOCKS + FSR_NW - 1) / FSR_NW; // blocks a wave fills per K-step (13)
+
+__global__ __launch_bounds__(FSR_NW * 64) void k_fc_s3_ring(const u32x4* __restrict__ A, const u32x4* __restrict__ Wr, const float* __restrict__ bias,
+                                                            float* __restrict__ out, int M, int K, int out_stride, int n_valid,
+                                                            float* __restrict__ stats, int n_soft, const FcGather gather) {
+    static_assert(FSR_NW == 4 || FSR_NW == 8, "a wave's 128 / NW rows park in its share (64 / NW rows) of the two free ring buffers");
+    extern __shared__ __attribute__((aligned(16))) uint32_t fsr_lds[];
+    u32x4* wl = (u32x4*)fsr_lds;                                       // [FSR_RING][chunk][tile slot][hi|lo][lane]
+    uint32_t* flags = (uint32_t*)(wl + FSR_RING * FSR_SLOTS);          // ready[3], done[3]
+    const uint32_t ready0 = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)flags;
+    const uint32_t done0 = ready0 + FSR_RING * 4;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int cb = blockIdx.y;
+    const FcExtra X = fc_extra(cb);
+    const bool has13 = wave < X.ne;                 // this wave also computes the leftover tile, for its row tile 0 (wave-uniform)
+    const int n0 = cb * (FC_MAIN_TILES * 16);
+    const int nx = (FC_MAIN_TILES * FC_MAIN_BLOCKS + X.l) * 16;
+    const int rpitch = K >> 2;                      // slots per activation row: per chunk of 32, 4 hi slots then 4 lo slots
+    int rt[FSR_RT], row[FSR_RT];
+    bool row_ok[FSR_RT];
+    const u32x4* ap[FSR_RT];
+#pragma unroll
+    for (int i = 0; i < FSR_RT; i++) {
+        rt[i] = (wave + i * FSR_NW + X.s) & 7;      // row tile 0 of waves 0 … ne − 1 are the rows that need the leftover tile
+        row[i] = blockIdx.x * 128 + rt[i] * 16 + r16;
+        row_ok[i] = row[i] < M;
+        ap[i] = A + (size_t)(row_ok[i] ? row[i] : M - 1) * rpitch + q;  // rows past the end load a valid row; never stored
+    }
+    const int nsteps = K / 64, nchunks = nsteps * 2;
+    // LDS-DMA: block b = (chunk·13 + tile slot)·2 + hi|lo of a K-step goes to slots b·64 … b·64 + 63 of the buffer; wave w fills
+    // blocks w, w + 4, …
+    uint32_t src0[FSR_PER];
+#pragma unroll
+    for (int u = 0; u < FSR_PER; u++) {
+        int b = wave + FSR_NW * u;
+        b = b < FSR_BLOCKS ? b : FSR_BLOCKS - 1;
+        const int h = b & 1, cj = b >> 1, c = cj / FSR_CT, j = cj - c * FSR_CT;
+        const int tile = j < FC_MAIN_TILES ? cb * FC_MAIN_TILES + j : FC_MAIN_TILES * FC_MAIN_BLOCKS + X.l;
+        src0[u] = (uint32_t)((((size_t)c * FC_TILES + tile) * 2 + h) * 64 + lane);
+    }
+    const uint32_t step_slots = 2u * FC_TILES * 2u * 64u;
+    auto fill = [&](int step, int buf) {
+#pragma unroll
+        for (int u = 0; u < FSR_PER; u++)
+            if (wave + FSR_NW * u < FSR_BLOCKS)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wr + (size_t)step * step_slots + src0[u]),
+                                                 (__attribute__((address_space(3))) void*)(wl + buf * FSR_SLOTS + (wave + FSR_NW * u) * 64), 16, 0, 0);
+    };
+    auto aload = [&](int i, int kc, int lo) { return ap[i][(size_t)((TG_FSR_PROBE & 2) ? 0 : (kc < nchunks ? kc : nchunks - 1)) * 8 + 4 * lo]; };
+    if (tid < 2 * FSR_RING) flags[tid] = 0u;
+    __syncthreads();
+    fill(0, 0);
+    if (nsteps > 1) fill(1, 1);
+    f32x4 acc[FSR_RT][FSR_CT];
+#pragma unroll
+    for (int i = 0; i < FSR_RT; i++)
+#pragma unroll
+        for (int j = 0; j < FSR_CT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // activations [row tile][hi, lo]: chunk 0 of the step in a0, chunk 1 in a1, chunk 0 of the next step in b0 (as k_fc_ring: requested
+    // at the top of a step, forced complete before the refill is issued, so none queues behind a young LDS-DMA)
+    u32x4 a0[FSR_RT][2], a1[FSR_RT][2], b0[FSR_RT][2];
+#pragma unroll
+    for (int i = 0; i < FSR_RT; i++) { a0[i][0] = aload(i, 0, 0); a0[i][1] = aload(i, 0, 1); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    fc_ring_signal(ready0);
+    if (nsteps > 1) fc_ring_signal(ready0 + 4);
+    constexpr int H1 = 7;
+    u32x4 wh[FSR_CT], wo[FSR_CT];
+#define TG_FS_LOAD(C, J0, J1) _Pragma("unroll") for (int j = J0; j < J1; j++) { wh[j] = wb[(((C) * FSR_CT + j) * 2 + 0) * 64 + lane]; if (!(TG_FSR_PROBE & 4)) wo[j] = wb[(((C) * FSR_CT + j) * 2 + 1) * 64 + lane]; else wo[j] = wh[j]; }
+// (the three products of an accumulator — hi·hi, hi·lo, lo·hi, in that order — are issued a whole tile group apart, not back to
+// back: with one row tile per wave consecutive MFMAs into the same accumulator waited out the matrix pipe's latency)
+#define TG_FS_MFMA(AV, J0, J1)                                                                                                              \
+    _Pragma("unroll") for (int j = J0; j < J1; j++)                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < FSR_RT; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wh[j]), as_bf((AV)[i][0]), acc[i][j], 0, 0, 0); \
+    _Pragma("unroll") for (int j = J0; j < J1; j++)                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < FSR_RT; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wh[j]), as_bf((AV)[i][1]), acc[i][j], 0, 0, 0); \
+    _Pragma("unroll") for (int j = J0; j < J1; j++)                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < FSR_RT; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wo[j]), as_bf((AV)[i][0]), acc[i][j], 0, 0, 0);
+#define TG_FS_XMFMA(AV)                                                                                                                     \
+    acc[0][FC_MAIN_TILES] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wh[FC_MAIN_TILES]), as_bf((AV)[0][0]), acc[0][FC_MAIN_TILES], 0, 0, 0); \
+    acc[0][FC_MAIN_TILES] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wh[FC_MAIN_TILES]), as_bf((AV)[0][1]), acc[0][FC_MAIN_TILES], 0, 0, 0); \
+    acc[0][FC_MAIN_TILES] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wo[FC_MAIN_TILES]), as_bf((AV)[0][0]), acc[0][FC_MAIN_TILES], 0, 0, 0);
+#define TG_FS_CHUNK(C, AV, NEXT, EARLY)                                                                              \
+    TG_FS_LOAD(C, H1, FSR_CT)                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    TG_FS_MFMA(AV, 0, H1)                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    if (NEXT) { TG_FS_LOAD((C) + 1, 0, H1) }                                                                         \
+    EARLY;                                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    TG_FS_MFMA(AV, H1, FC_MAIN_TILES)                                                                                \
+    if (has13) { TG_FS_XMFMA(AV) }                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);
+    const volatile __attribute__((address_space(3))) uint32_t* flag_lds = (const volatile __attribute__((address_space(3))) uint32_t*)flags;
+    uint32_t early_ready = 0u, early_done = 0u;
+    uint32_t g_cnt[FSR_RT], g_pidx[FSR_RT][16];
+#pragma unroll
+    for (int i = 0; i < FSR_RT; i++) {
+        g_cnt[i] = 0u;
+#pragma unroll
+        for (int r = 0; r < 16; r++) g_pidx[i][r] = 0u;
+    }
+    for (int step = 0; step < nsteps; step++) {
+        const int buf = step % FSR_RING;
+        const u32x4* wb = wl + buf * FSR_SLOTS;
+        if (!(TG_FSR_PROBE & 1) && (int)__builtin_amdgcn_readfirstlane((int)early_ready) < FSR_NW * (step / FSR_RING + 1))
+            fc_ring_wait(ready0 + 4 * buf, (uint32_t)FSR_NW * (uint32_t)(step / FSR_RING + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        TG_FS_LOAD(0, 0, H1)
+#pragma unroll
+        for (int i = 0; i < FSR_RT; i++) {
+            a1[i][0] = aload(i, step * 2 + 1, 0); a1[i][1] = aload(i, step * 2 + 1, 1);
+            b0[i][0] = aload(i, step * 2 + 2, 0); b0[i][1] = aload(i, step * 2 + 2, 1);
+        }
+        if (gather.child_logit && step == nsteps - 1) {  // (no refill follows in the last step: these loads wait for nobody)
+#pragma unroll
+            for (int i = 0; i < FSR_RT; i++) {
+                const int tile_row0 = blockIdx.x * 128 + rt[i] * 16;
+                g_cnt[i] = gather.leaf_rec[2 * (size_t)min(tile_row0 + r16, M - 1) + 1];
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    g_pidx[i][r] = ((const uint32_t*)(gather.child_pidx + (size_t)min(tile_row0 + r, M - 1) * gather.stride))[lane];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        TG_FS_CHUNK(0, a0, true, early_done = flag_lds[FSR_RING + (step + 2) % FSR_RING])
+        // the middle of the step: signal the step after this one, refill the buffer of the step before it
+#pragma unroll
+        for (int i = 0; i < FSR_RT; i++) asm volatile("" : "+v"(a1[i][0]), "+v"(a1[i][1]), "+v"(b0[i][0]), "+v"(b0[i][1]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (step >= 1 && step + 1 < nsteps) fc_ring_signal(ready0 + 4 * ((step + 1) % FSR_RING));
+        if (!(TG_FSR_PROBE & 1) && step + 2 < nsteps) {
+            if ((int)__builtin_amdgcn_readfirstlane((int)early_done) < FSR_NW * ((step + 2) / FSR_RING))
+                fc_ring_wait(done0 + 4 * ((step + 2) % FSR_RING), (uint32_t)FSR_NW * (uint32_t)((step + 2) / FSR_RING));
+            fill(step + 2, (step + 2) % FSR_RING);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        TG_FS_CHUNK(1, a1, false, early_ready = flag_lds[(step + 1) % FSR_RING])
+        fc_ring_signal(done0 + 4 * buf);
+#pragma unroll
+        for (int i = 0; i < FSR_RT; i++) { a0[i][0] = b0[i][0]; a0[i][1] = b0[i][1]; }
+    }
+#undef TG_FS_LOAD
+#undef TG_FS_MFMA
+#undef TG_FS_XMFMA
+#undef TG_FS_CHUNK
+    // ---- epilogue (per row tile): bias; the statistics of the wave's blocks; logits rows or the children's logits ----
+    // gather: the wave's 128 / NW rows park in its share (64 / NW rows × 13 tiles) of each of the two ring buffers that hold nothing of
+    // the last K-step, once every wave has read the steps that lived there (done[]; every LDS-DMA into them landed steps ago)
+    constexpr int RP = FSR_CT * 16;        // floats per parked row (208)
+    constexpr int SHARE = 64 / FSR_NW;     // rows per wave and buffer
+    float* park[2] = {nullptr, nullptr};
+    if (gather.child_logit) {
+        const int bf[2] = {nsteps % FSR_RING, (nsteps + 1) % FSR_RING};
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int uses = bf[b] < nsteps ? (nsteps - bf[b] + FSR_RING - 1) / FSR_RING : 0;
+            fc_ring_wait(done0 + 4 * bf[b], (uint32_t)FSR_NW * (uint32_t)uses);
+            park[b] = (float*)(wl + bf[b] * FSR_SLOTS) + wave * (SHARE * RP);
+        }
+    }
+    auto parked = [&](int i, int r) { const int rho = i * 16 + r; return park[rho / SHARE] + (rho % SHARE) * RP; };
+#pragma unroll
+    for (int i = 0; i < FSR_RT; i++) {
+        const bool x13 = has13 && i == 0;
+        f32x4 v[FSR_CT];
+#pragma unroll
+        for (int j = 0; j < FC_MAIN_TILES; j++) v[j] = acc[i][j] + *(const f32x4*)&bias[n0 + j * 16 + 4 * q];
+        v[FC_MAIN_TILES] = acc[i][FC_MAIN_TILES] + *(const f32x4*)&bias[nx + 4 * q];
+        if (stats) {
+            float m, sm;
+            float* srow = stats + (size_t)(row_ok[i] ? row[i] : 0) * (FC_STAT_STRIDE * 2);
+            fc_block_stats<FC_MAIN_TILES>(*reinterpret_cast<const f32x4(*)[FC_MAIN_TILES]>(&v[0]), n0 + 4 * q, min(n_soft, n0 + FC_MAIN_TILES * 16), m, sm);
+            if (row_ok[i] && q == 0) *(float2*)&srow[cb * 2] = make_float2(m, sm);
+            if (x13) {
+                fc_block_stats<1>(*reinterpret_cast<const f32x4(*)[1]>(&v[FC_MAIN_TILES]), nx + 4 * q, min(n_soft, nx + 16), m, sm);
+                if (row_ok[i] && q == 0) *(float2*)&srow[(FC_MAIN_BLOCKS + X.l) * 2] = make_float2(m, sm);
+                const int dv = n_soft - (nx + 4 * q);  // column n_soft (= P): the value head's pre-activation → pair FC_STAT_BLOCKS
+                if (row_ok[i] && dv >= 0 && dv < 4)
+                    *(float2*)&srow[FC_STAT_BLOCKS * 2] = make_float2(dv == 0 ? v[FC_MAIN_TILES][0] : dv == 1 ? v[FC_MAIN_TILES][1] : dv == 2 ? v[FC_MAIN_TILES][2] : v[FC_MAIN_TILES][3], 0.0f);
+            }
+        }
+        if (out && row_ok[i]) {
+#pragma unroll
+            for (int j = 0; j < FSR_CT; j++) {
+                const int nn = (j < FC_MAIN_TILES ? n0 + j * 16 : nx) + 4 * q;
+                if (nn < n_valid && (j < FC_MAIN_TILES || x13)) {
+                    float* o = out + (size_t)row[i] * out_stride + nn;
+                    if (nn + 3 < n_valid) *(f32x4*)o = v[j];
+                    else for (int t = 0; t < 4; t++) if (nn + t < n_valid) o[t] = v[j][t];
+                }
+            }
+        }
+        if (gather.child_logit) {
+            {
+                float* dst = parked(i, r16) + 4 * q;
+#pragma unroll
+                for (int j = 0; j < FSR_CT; j++) *(f32x4*)&dst[j * 16] = v[j];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own parked rows, now read by other lanes of the same wave
+            const int tile_row0 = blockIdx.x * 128 + rt[i] * 16;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int grow = min(tile_row0 + r, M - 1);
+                const uint32_t cnt = tile_row0 + r < M ? min((uint32_t)__builtin_amdgcn_readlane((int)g_cnt[i], r), (uint32_t)gather.stride) : 0u;
+                const float* prow = parked(i, r);
+                float* crow = gather.child_logit + (size_t)grow * gather.stride;
+                const uint16_t* irow = gather.child_pidx + (size_t)grow * gather.stride;
+                for (uint32_t c0 = 0; c0 < cnt; c0 += 128) {
+                    const uint32_t pair = c0 == 0 ? g_pidx[i][r] : ((const uint32_t*)(irow + c0))[lane];
+#pragma unroll
+                    for (int hlf = 0; hlf < 2; hlf++) {
+                        const uint32_t c = c0 + 2 * lane + hlf;
+                        const uint32_t p = hlf ? pair >> 16 : pair & 0xFFFFu;
+                        const uint32_t dm = p - (uint32_t)n0, dx = p - (uint32_t)nx;
+                        const bool in_main = dm < (uint32_t)(FC_MAIN_TILES * 16), in_x = x13 && dx < 16u;
+                        if (c < cnt && (in_main || in_x)) crow[c] = prow[in_main ? dm : FC_MAIN_TILES * 16 + dx];
+                    }
+                }
+            }
+        }
+    }
+}
+
 // value head on the split activations: Linear(F·N² → 1) + tanh; wv in NHWC order (f32)
 __global__ __launch_bounds__(256) void k_value_head_s3(const u32x4* __restrict__ act, const float* __restrict__ wv, float bv, int B, int len,
                                                        float* __restrict__ eval) {
@@ -1138,18 +1391,34 @@ hipError_t launch_tower_s3_states(hipStream_t st, const uint8_t* states, const T
 }
 bool fc_s3_supported(int K, int NP) { return K % 64 == 0 && (NP % FS_COLS == 0 || NP % 112 == 0); }
 int fc_s3_cols(int NP) { return NP % 112 == 0 ? 112 : FS_COLS; }  // column-block width of the weight layout
-hipError_t launch_fc_s3(hipStream_t st, const float* act_split, const void* Wp, const float* bias, float* out, int M, int K, int NP,
-                        int out_stride, int n_valid, float* stats, int n_soft) {
+bool fc_s3_ring_supported(int M, int K, int n_valid) { return K % 64 == 0 && n_valid <= FC_TILES * 16 && M > 512; }
+// Wp: the [chunk][column block][q][hi|lo][column] layout of k_fc_s3b / k_fc_s3 (≤ 512 rows); Wr (optional): the ring layout of
+// k_fc_s3_ring (full batches).  stats: the block statistics of softmax.cuh's geometry (the exact-f32 FC's), from the ring's epilogue
+// or by k_fc_stats behind k_fc_s3b — the same bits.  gather: as launch_gemm's (needs Wr and > 512 rows).
+hipError_t launch_fc_s3(hipStream_t st, const float* act_split, const void* Wp, const void* Wr, const float* bias, float* out, int M, int K, int NP,
+                        int out_stride, int n_valid, float* stats, int n_soft, const FcGatherArgs* gather) {
+    if (stats && (n_valid > FC_TILES * 16 || out_stride < FC_TILES * 16)) return hipErrorInvalidValue;
+    static const bool no_ring = getenv("TG_S3_NO_FC_RING") != nullptr;  // A/B: k_fc_s3b at every batch (same bits)
+    if (Wr && !no_ring && fc_s3_ring_supported(M, K, n_valid)) {
+        static LdsAttr lds_attr;
+        if (hipError_t e = lds_attr.ensure((const void*)k_fc_s3_ring, FSR_LDS); e != hipSuccess) return e;
+        FcGather g{nullptr, nullptr, nullptr, 0};
+        if (gather) g = FcGather{gather->child_pidx, gather->leaf_rec, gather->child_logit, gather->stride};
+        hipLaunchKernelGGL(k_fc_s3_ring, dim3((M + 127) / 128, FC_MAIN_BLOCKS), dim3(FSR_NW * 64), FSR_LDS, st, (const u32x4*)act_split, (const u32x4*)Wr, bias,
+                           gather ? nullptr : out, M, K, out_stride, n_valid, stats, n_soft, g);
+        return hipGetLastError();
+    }
+    if (gather) return hipErrorInvalidValue;
     if (NP % 112 == 0) {
         dim3 grid((M + 127) / 128, NP / 112);
         hipLaunchKernelGGL((k_fc_s3b<7, 4>), grid, dim3(256), 0, st, (const u32x4*)act_split, (const u32x4*)Wp, bias, out, M, K, NP, out_stride, n_valid,
-                           stats, n_soft);
-        return hipGetLastError();
+                           nullptr, n_soft);
+    } else {
+        dim3 grid((M + 127) / 128, NP / FS_COLS);
+        hipLaunchKernelGGL(k_fc_s3, grid, dim3(512), 0, st, (const u32x4*)act_split, (const u32x4*)Wp, bias, out, M, K, NP, out_stride, n_valid);
     }
-    if (stats) return hipErrorInvalidValue;  // (only the 112-column kernel emits statistics)
-    dim3 grid((M + 127) / 128, NP / FS_COLS);
-    hipLaunchKernelGGL(k_fc_s3, grid, dim3(512), 0, st, (const u32x4*)act_split, (const u32x4*)Wp, bias, out, M, K, NP, out_stride, n_valid);
-    return hipGetLastError();
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    return stats ? launch_fc_stats(st, out, out_stride, M, n_soft, stats) : hipSuccess;
 }
 hipError_t launch_value_head_s3(hipStream_t st, const float* act_split, const float* wv, float bv, int B, int len, float* eval) {
     hipLaunchKernelGGL(k_value_head_s3, dim3((B + 3) / 4), dim3(256), 0, st, (const u32x4*)act_split, wv, bv, B, len, eval);

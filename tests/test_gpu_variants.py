@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _digest(cfg, batch, **env):
     e = dict(os.environ)
-    for k in ("TG_NO_HALO_TOWER", "TG_NO_FC_GATHER", "TG_NO_FRAG_OUT", "TG_PRECISION", "TG_NO_CONST_BIAS", "TG_NO_FC_STATS"):
+    for k in ("TG_NO_HALO_TOWER", "TG_NO_FC_GATHER", "TG_S3_NO_FC_RING", "TG_NO_FRAG_OUT", "TG_PRECISION", "TG_NO_CONST_BIAS", "TG_NO_FC_STATS"):
         e.pop(k, None)
     e.update(env)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "ab_bits.py"), cfg, str(batch)], env=e, check=True,
@@ -38,6 +38,8 @@ def test_launcher_variants_return_identical_bits(cfg, batch):
     s3 = _digest(cfg, batch, TG_PRECISION="bf16x3")
     assert s3 != base
     assert _digest(cfg, batch, TG_PRECISION="bf16x3", TG_NO_HALO_TOWER="1") == s3
+    if cfg != "c3":  # the split-bf16 FC's ring kernel (full batches) against k_fc_s3b + k_fc_stats
+        assert _digest(cfg, batch, TG_PRECISION="bf16x3", TG_S3_NO_FC_RING="1") == s3
 
 
 TREE_DIGEST = r"""
@@ -49,6 +51,8 @@ from oracle import oracle as orc
 G = 1024
 net = torch_ref.make_net(5, 2, 64, "fc5", seed=5)
 e = tak_amd.Engine(5, res_blocks=2, filters=64, evaluator=tak_amd.EVAL_RESNET, max_batch=G)
+if {precision!r} != "f32":
+    e.set_precision({precision!r})
 e.load_state_dict(torch_ref.abi_tensors(net))
 base = orc.random_positions(5, 3000, seed=9, max_plies=60, half_komi=4)
 base = base[orc.result(5, base) == 0]
@@ -69,16 +73,21 @@ print("DIGEST", h.hexdigest())
 
 
 @pytest.mark.gpu
-def test_fc_gather_epilogue_builds_the_same_trees():
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_fc_gather_epilogue_builds_the_same_trees(precision):
     """Search iterations at ≥ 513 leaves run the policy FC with its gather epilogue (no logits rows: the children's logits of every
     leaf and the statistics record with the value pre-activation); TG_NO_FC_GATHER=1 writes the logits rows and lets the backup
     gather — the round-3 data flow.  Same logits, same statistics, so the same trees, bit for bit: 147 whole trees and all roots
-    of 1024 games after 40 iterations."""
+    of 1024 games after 40 iterations.  On the split-bf16 path the ring FC with its gather epilogue is also compared with the
+    small-workgroup FC + statistics kernel + logits rows (TG_S3_NO_FC_RING)."""
     def digest(**env):
         e = {k: v for k, v in os.environ.items() if not k.startswith("TG_")}
         e.update(env)
-        out = subprocess.run([sys.executable, "-c", TREE_DIGEST.format(root=ROOT)], env=e, check=True, capture_output=True, text=True,
+        out = subprocess.run([sys.executable, "-c", TREE_DIGEST.format(root=ROOT, precision=precision)], env=e, check=True, capture_output=True, text=True,
                              timeout=600).stdout
         return [l for l in out.splitlines() if l.startswith("DIGEST")][-1].split()[1]
 
-    assert digest() == digest(TG_NO_FC_GATHER="1")
+    base = digest()
+    assert base == digest(TG_NO_FC_GATHER="1")
+    if precision == "bf16x3":
+        assert base == digest(TG_S3_NO_FC_RING="1")

@@ -43,9 +43,14 @@ void launch_perft_expand(hipStream_t st, const uint8_t* states, int count, int n
 // accumulators (the halo kernel, all channels in one workgroup column) it writes *stats_blocks partial rows
 // part[(block·2 + {Σ, Σ²})·CoutP + channel] as doubles and sets *stats_blocks > 0; otherwise *stats_blocks = 0 and the caller
 // reduces the output itself (launch_bn_stats)
+// stats_part / stats_blocks (optional; honoured by the halo kernel for layers whose channels one workgroup column covers, else
+// *stats_blocks = 0): per-channel column sums of the output leave the kernel as doubles, one partial row per (workgroup, row group),
+// in k_col_reduce's layout part[(row·2 + {0, 1})·CoutP + channel] — Σz and Σz² (BatchNorm's batch statistics, training forward), or,
+// with bnb set (the data-gradient convolution: the output is dy of the layer below), that layer's BatchNorm-backward sums Σg, Σg·x̂
+struct ConvBnBwdIn { const float* y; const float* z; const float* mean; const float* invstd; };  // of the layer BELOW, rows as the output's
 hipError_t launch_conv3x3(hipStream_t st, const float* in, const float* Wp, const float* bias, const float* res, float* out,
                           int M, int n, int Cpad, int CoutP, int out_stride, int cout_valid, bool relu,
-                          double* stats_part = nullptr, int* stats_blocks = nullptr);
+                          double* stats_part = nullptr, int* stats_blocks = nullptr, const ConvBnBwdIn* bnb = nullptr);
 // mean, 1/σ and the running statistics from such partial rows (Σz, Σz² in double): replaces launch_bn_stats' two passes over z
 hipError_t launch_bn_stats_from_partials(hipStream_t st, const double* part, int nblk, int M, int F, float eps, float momentum,
                                          float* mean, float* invstd, float* running_mean, float* running_var);
@@ -160,7 +165,8 @@ hipError_t launch_bn_fwd_apply(hipStream_t st, const float* z, const float* mean
                                const float* beta, const float* skip, float* y, int M, int F);
 hipError_t launch_bn_bwd(hipStream_t st, const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
                          const float* gamma, int M, int F, double* part, double* mean_g, double* mean_gx, float* grad_gamma,
-                         float* grad_beta, float* dz, float* gskip, float* grad_conv_bias = nullptr);  // grad_conv_bias += column sums of dz
+                         float* grad_beta, float* dz, float* gskip, float* grad_conv_bias = nullptr,  // grad_conv_bias += column sums of dz
+                         int sums_in_part = 0);  // > 0: Σg, Σg·x̂ already in `part` (that many partial rows, from launch_conv3x3's ConvBnBwdIn)
 hipError_t launch_colsum_acc(hipStream_t st, const float* a, int M, int Fp, int valid, double* part, float* grad);
 hipError_t launch_policy_loss(hipStream_t st, const float* logits, int row_stride, bool conv_head, int nsq, int ch_stride, int P, int B,
                               const float* pi, float inv_b, float* dlogits, float* logp_out, float* loss_rows);

@@ -710,7 +710,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restri
                                                            const float* __restrict__ bias, const float* __restrict__ res,
                                                            float* __restrict__ out, const uint32_t* __restrict__ slotmap, int B, int PW,
                                                            int PS, int CTW, int out_stride, int cout_valid, int relu,
-                                                           double* __restrict__ stats_part) {
+                                                           double* __restrict__ stats_part, const ConvBnBwdIn bnb) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     f32x4* lds4 = (f32x4*)lds;
     constexpr int n = NB, nsq = NB * NB, RS = NB + 1, LEAD = NB + 2, F4 = 4 * CH, P4 = 4 * CH + 1;
@@ -801,8 +801,13 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restri
     const int ch = ch0 + 4 * q;
     const f32x4 bv = *(const f32x4*)&bias[ch];
     // stats_part: Σ and Σ² of this lane's outputs, per channel — in double from the first add on: var = E[z²] − E[z]² loses
-    // (mean/σ)² of the sums' relative accuracy, and f32 partials over up to 208 rows left 1e-4 of the variance at |mean| = 10σ
+    // (mean/σ)² of the sums' relative accuracy, and f32 partials over up to 208 rows left 1e-4 of the variance at |mean| = 10σ.
+    // With bnb.y set (round 4; the data-gradient convolution of the training step): the output IS dy of the layer below, and the
+    // same two slots collect that layer's BatchNorm-backward sums Σg and Σg·x̂ (g = dy·[y > 0], x̂ = (z − mean)·invstd) while dy is
+    // in registers — k_col_reduce<RED_BNBWD>'s pass over dy, y and z (27 µs per layer) is gone
     double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    f32x4 bn_mu = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, bn_is = bn_mu;
+    if (bnb.y && ch0 + 4 * q < cout_valid) { bn_mu = *(const f32x4*)&bnb.mean[ch0 + 4 * q]; bn_is = *(const f32x4*)&bnb.invstd[ch0 + 4 * q]; }
 #pragma unroll
     for (int j = 0; j < RTW; j++) {
         if (rowid[j] < rows && ch < cout_valid) {
@@ -812,9 +817,17 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restri
             if (relu) { v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f); }
             if (ch + 3 < cout_valid) *(f32x4*)&out[o] = v;
             else for (int t = 0; t < 4; t++) if (ch + t < cout_valid) out[o + t] = v[t];
-            if (stats_part) {
+            if (stats_part && !bnb.y) {
 #pragma unroll
                 for (int t = 0; t < 4; t++) { const double d = (double)v[t]; s1[t] += d; s2[t] = fma(d, d, s2[t]); }
+            } else if (stats_part) {
+                const f32x4 yy = *(const f32x4*)&bnb.y[o], zz = *(const f32x4*)&bnb.z[o];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const float g = yy[t] > 0.0f ? v[t] : 0.0f;
+                    s1[t] += (double)g;
+                    s2[t] += (double)(g * ((zz[t] - bn_mu[t]) * bn_is[t]));
+                }
             }
         }
     }
@@ -1465,22 +1478,25 @@ static const uint32_t* conv_halo_slotmap(int n, int F, int pw, int ps) {
 template <int RTW, int NWAVES, int CH, int NB, int COT, int PSC>
 static hipError_t launch_conv_halo_t(hipStream_t st, const float* in, const float* Wp, const float* bias, const float* res, float* out,
                                      const uint32_t* slotmap, int B, int PW, int PS, int CTW, int out_stride, int cout_valid, bool relu,
-                                     double* stats_part, int* stats_blocks) {
+                                     double* stats_part, int* stats_blocks, const ConvBnBwdIn* bnb) {
     if (PS != PSC) return hipErrorInvalidValue;
     const size_t lds = (size_t)(NB + 2 + PW * PS + 1) * (16 * CH + 4) * sizeof(float);
     static LdsAttr lds_attr;
     if (hipError_t e = lds_attr.ensure((const void*)k_conv_halo<RTW, NWAVES, CH, NB, COT, PSC>, lds); e != hipSuccess) return e;
     dim3 grid((B + PW - 1) / PW, COT / CTW);
     if (grid.y != 1) stats_part = nullptr;  // (statistics only for layers whose channels one workgroup column covers)
+    ConvBnBwdIn bn{nullptr, nullptr, nullptr, nullptr};
+    if (bnb && stats_part && out_stride == 16 * COT) bn = *bnb;  // (y and z share the output's row layout)
+    else if (bnb) stats_part = nullptr;
     hipLaunchKernelGGL((k_conv_halo<RTW, NWAVES, CH, NB, COT, PSC>), grid, dim3(NWAVES * 64), lds, st, in, Wp, bias, res, out, slotmap, B, PW, PS,
-                       CTW, out_stride, cout_valid, relu ? 1 : 0, stats_part);
+                       CTW, out_stride, cout_valid, relu ? 1 : 0, stats_part, bn);
     if (stats_blocks) *stats_blocks = stats_part ? (int)grid.x * (NWAVES / CTW) : 0;
     return hipGetLastError();
 }
 
 hipError_t launch_conv3x3(hipStream_t st, const float* in, const float* Wp, const float* bias, const float* res, float* out,
                           int M, int n, int Cpad, int CoutP, int out_stride, int cout_valid, bool relu, double* stats_part,
-                          int* stats_blocks) {
+                          int* stats_blocks, const ConvBnBwdIn* bnb) {
     const int B = M / (n * n);
     if (stats_blocks) *stats_blocks = 0;
     {   // F → F (and F → 2F) layers of the BASELINE topologies at full batches: the halo image (k_conv_halo), same bits as k_conv_pos
@@ -1489,10 +1505,10 @@ hipError_t launch_conv3x3(hipStream_t st, const float* in, const float* Wp, cons
         if (!off && B >= 1024 && tower_halo_geometry(n, Cpad, &pw, &ps)) {
             const uint32_t* map = conv_halo_slotmap(n, Cpad, pw, ps);
             if (map) {
-                if (n == 5 && Cpad == 64 && CoutP == 64) return launch_conv_halo_t<13, 8, 4, 5, 4, 36>(st, in, Wp, bias, res, out, map, B, pw, ps, 4, out_stride, cout_valid, relu, stats_part, stats_blocks);
-                if (n == 5 && Cpad == 128 && CoutP == 128) return launch_conv_halo_t<13, 8, 8, 5, 8, 37>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu, stats_part, stats_blocks);
-                if (n == 6 && Cpad == 128 && CoutP == 128) return launch_conv_halo_t<9, 8, 8, 6, 8, 51>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu, stats_part, stats_blocks);
-                if (n == 6 && Cpad == 128 && CoutP == 256) return launch_conv_halo_t<9, 8, 8, 6, 16, 51>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu, stats_part, stats_blocks);
+                if (n == 5 && Cpad == 64 && CoutP == 64) return launch_conv_halo_t<13, 8, 4, 5, 4, 36>(st, in, Wp, bias, res, out, map, B, pw, ps, 4, out_stride, cout_valid, relu, stats_part, stats_blocks, bnb);
+                if (n == 5 && Cpad == 128 && CoutP == 128) return launch_conv_halo_t<13, 8, 8, 5, 8, 37>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu, stats_part, stats_blocks, bnb);
+                if (n == 6 && Cpad == 128 && CoutP == 128) return launch_conv_halo_t<9, 8, 8, 6, 8, 51>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu, stats_part, stats_blocks, bnb);
+                if (n == 6 && Cpad == 128 && CoutP == 256) return launch_conv_halo_t<9, 8, 8, 6, 16, 51>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu, stats_part, stats_blocks, bnb);
             }
         }
     }

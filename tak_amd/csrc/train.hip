@@ -278,20 +278,30 @@ int backward_train(TgEngine* e, int B) {
     }
     TG_HIP(launch_value_bwd(st, s, t->dpre.as<float>(), t->wv.as<float>(), B, F, nsq, dcur, part_d, G + t->val_w, G + t->val_b));
     // ---- tower, last layer first ----
+    // Round 4: the data-gradient convolution of layer l produces dy of layer l − 1 — its epilogue also takes that layer's
+    // BatchNorm-backward sums Σg, Σg·x̂ while dy is in registers (halo kernel, full chunks), and the pass over dy, y and z that took
+    // them (k_col_reduce, 27 µs per layer) is skipped; TG_NO_BWD_SUMS_FUSION restores it (other summation order: other low bits)
+    static const bool fuse_sums = getenv("TG_NO_BWD_SUMS_FUSION") == nullptr;
+    int sums_in_part = 0;
     for (int l = (int)t->convs.size() - 1; l >= 0; l--) {
         TrainConv& c = t->convs[l];
         float* mean = stats + (size_t)c.bn * 2 * F;
         float* invstd = mean + F;
         const bool block_end = l >= 2 && (l % 2) == 0;  // conv2: its masked gradient also flows into the skip
         TG_HIP(launch_bn_bwd(st, dcur, c.y.as<float>(), c.z.as<float>(), mean, invstd, P + c.gamma, M, F, part_d, t->mean_g.as<double>(),
-                             t->mean_gx.as<double>(), G + c.gamma, G + c.beta, dz, block_end ? gskip : nullptr, G + c.b));
+                             t->mean_gx.as<double>(), G + c.gamma, G + c.beta, dz, block_end ? gskip : nullptr, G + c.b, sums_in_part));
+        sums_in_part = 0;
         const float* x = l == 0 ? t->planes.as<float>() : t->convs[l - 1].y.as<float>();
         TG_HIP(launch_wgrad_conv(st, x, c.in_stride, c.I, dz, F, c.O, B, N, part_w, G + c.w));
         if (l == 0) break;
         // conv1 (odd l) closes the block: its data gradient joins the gradient that went through the skip
         const bool block_begin = (l % 2) == 1;
         float* dst = block_end ? dtmp : dcur;
-        TG_HIP(launch_conv3x3(st, dz, c.wb.as<float>(), zero_bias, block_begin ? gskip : nullptr, dst, M, N, F, round_up(c.I, 64), F, F, false));
+        const TrainConv& below = t->convs[l - 1];
+        const float* mean_b = stats + (size_t)below.bn * 2 * F;
+        const ConvBnBwdIn bnb{below.y.as<float>(), below.z.as<float>(), mean_b, mean_b + F};
+        TG_HIP(launch_conv3x3(st, dz, c.wb.as<float>(), zero_bias, block_begin ? gskip : nullptr, dst, M, N, F, round_up(c.I, 64), F, F, false,
+                              fuse_sums ? part_d : nullptr, fuse_sums ? &sums_in_part : nullptr, fuse_sums ? &bnb : nullptr));
         if (block_end) std::swap(dcur, dtmp);
     }
     return TG_OK;

@@ -847,10 +847,12 @@ hipError_t launch_bn_fwd_apply(hipStream_t st, const float* z, const float* mean
 }
 hipError_t launch_bn_bwd(hipStream_t st, const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
                          const float* gamma, int M, int F, double* part, double* mean_g, double* mean_gx, float* grad_gamma,
-                         float* grad_beta, float* dz, float* gskip, float* grad_conv_bias) {
+                         float* grad_beta, float* dz, float* gskip, float* grad_conv_bias, int sums_in_part) {
     int rpb, nblk = col_reduce_blocks(M, F, &rpb);
-    hipLaunchKernelGGL((k_col_reduce<RED_BNBWD>), dim3(nblk), dim3(256), 0, st, dy, y, z, mean, invstd, M, F, rpb, part);
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(F), dim3(256), 0, st, part, nblk, F, M, mean_g, mean_gx, grad_gamma, grad_beta);
+    // sums_in_part > 0: Σg and Σg·x̂ already sit in `part`, that many partial rows — left there by the epilogue of the convolution
+    // that produced dy (launch_conv3x3 with ConvBnBwdIn); else a pass over dy, y and z takes them
+    if (sums_in_part <= 0) hipLaunchKernelGGL((k_col_reduce<RED_BNBWD>), dim3(nblk), dim3(256), 0, st, dy, y, z, mean, invstd, M, F, rpb, part);
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(F), dim3(256), 0, st, part, sums_in_part > 0 ? sums_in_part : nblk, F, M, mean_g, mean_gx, grad_gamma, grad_beta);
     if (grad_conv_bias) {  // dz and its column sums in one pass (the bias gradient of the convolution in front)
         hipLaunchKernelGGL(k_bn_bwd_apply_sum, dim3(nblk), dim3(256), 0, st, dy, y, z, mean, invstd, gamma, mean_g, mean_gx, dz, gskip, M, F,
                            rpb, part);

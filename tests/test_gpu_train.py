@@ -478,10 +478,14 @@ def test_full_batch_training_kernels_return_identical_bits(cfg):
                              text=True, timeout=600).stdout
         return [l for l in out.splitlines() if l.startswith("DIGEST")][-1].split()[1]
 
-    base = digest(TG_NO_CONV_STATS="1")  # (BatchNorm's sums from the conv accumulators are another summation order: compared by value)
-    assert digest(TG_NO_CONV_STATS="1", TG_NO_HALO_CONV="1") == base
-    assert digest(TG_NO_CONV_STATS="1", TG_NO_HALO_WGRAD="1") == base
-    assert digest(TG_NO_CONV_STATS="1", TG_NO_HALO_CONV="1", TG_NO_HALO_WGRAD="1") == base
+    # (BatchNorm's sums taken from the convolutions' accumulators — Σz, Σz² in the forward, Σg, Σg·x̂ in the backward — are another
+    # summation order than the passes over memory they replace: those two are compared by value, below and in
+    # test_batchnorm_statistics_from_the_conv_accumulators_by_value)
+    plain = dict(TG_NO_CONV_STATS="1", TG_NO_BWD_SUMS_FUSION="1")
+    base = digest(**plain)
+    assert digest(TG_NO_HALO_CONV="1", **plain) == base
+    assert digest(TG_NO_HALO_WGRAD="1", **plain) == base
+    assert digest(TG_NO_HALO_CONV="1", TG_NO_HALO_WGRAD="1", **plain) == base
 
 
 BN_STATS_DUMP = r"""
@@ -546,6 +550,19 @@ def test_batchnorm_statistics_from_the_conv_accumulators_by_value(orc, tmp_path)
         return dict(np.load(path))
 
     a, b = run("default"), run("two_pass", TG_NO_CONV_STATS="1")
+    # round 4: the backward's Σg, Σg·x̂ from the data-gradient convolution's epilogue against the pass over dy, y, z they replace.  The
+    # forward (and with it every ReLU mask) is identical, so every gradient agrees to the rounding of two double-precision sums
+    c = run("bwd_sums_by_pass", TG_NO_BWD_SUMS_FUSION="1")
+    assert np.array_equal(a["loss"], c["loss"])
+    for k in a:
+        if k.startswith("stat/"):
+            assert np.array_equal(a[k], c[k]), k
+        if k.startswith("grad/"):
+            name = k[5:]
+            if name.endswith(".bias") and "conv" in name and not name.startswith("policy"):
+                continue  # zero true gradient: rounding noise on both sides
+            nrm = np.linalg.norm(c[k].astype(np.float64))
+            assert np.linalg.norm(a[k].astype(np.float64) - c[k].astype(np.float64)) <= 1e-5 * nrm, (name, "fused backward sums")
     # the batch statistics PyTorch (fp64) sees, for the scale of each layer and as a third opinion
     net = _net_with_shifted_layers(n, blocks, filters, head).double().train()
     for m in net.modules():

@@ -48,18 +48,18 @@ sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
 import numpy as np
 import tak_amd, torch_ref
 from oracle import oracle as orc
-G = 1024
+G, BATCH = 1024 // {batch}, {batch}
 net = torch_ref.make_net(5, 2, 64, "fc5", seed=5)
-e = tak_amd.Engine(5, res_blocks=2, filters=64, evaluator=tak_amd.EVAL_RESNET, max_batch=G)
+e = tak_amd.Engine(5, res_blocks=2, filters=64, evaluator=tak_amd.EVAL_RESNET, max_batch=G * BATCH)
 if {precision!r} != "f32":
     e.set_precision({precision!r})
 e.load_state_dict(torch_ref.abi_tensors(net))
 base = orc.random_positions(5, 3000, seed=9, max_plies=60, half_komi=4)
 base = base[orc.result(5, base) == 0]
 sts = np.tile(base, (G // len(base) + 1, 1))[:G]
-e.search_create(G, arena_nodes=1 << 12)
+e.search_create(G, arena_nodes=1 << 12, batch=BATCH)   # BATCH virtual rollouts per tree and iteration (Player's batching): G * BATCH leaves
 e.search_reset(sts)
-e.search_run(40)
+e.search_run(40 // BATCH)
 h = hashlib.sha256()
 for g in range(0, G, 7):
     d = e.search_dump(g)
@@ -73,17 +73,18 @@ print("DIGEST", h.hexdigest())
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
-def test_fc_gather_epilogue_builds_the_same_trees(precision):
+@pytest.mark.parametrize("precision,batch", [("f32", 1), ("bf16x3", 1), ("f32", 2)])
+def test_fc_gather_epilogue_builds_the_same_trees(precision, batch):
     """Search iterations at ≥ 513 leaves run the policy FC with its gather epilogue (no logits rows: the children's logits of every
     leaf and the statistics record with the value pre-activation); TG_NO_FC_GATHER=1 writes the logits rows and lets the backup
     gather — the round-3 data flow.  Same logits, same statistics, so the same trees, bit for bit: 147 whole trees and all roots
-    of 1024 games after 40 iterations.  On the split-bf16 path the ring FC with its gather epilogue is also compared with the
+    of 1024 games after 40 iterations (and 512 games with two virtual rollouts per iteration: leaf slot = game · batch + pass).  On the
+    split-bf16 path the ring FC with its gather epilogue is also compared with the
     small-workgroup FC + statistics kernel + logits rows (TG_S3_NO_FC_RING)."""
     def digest(**env):
         e = {k: v for k, v in os.environ.items() if not k.startswith("TG_")}
         e.update(env)
-        out = subprocess.run([sys.executable, "-c", TREE_DIGEST.format(root=ROOT, precision=precision)], env=e, check=True, capture_output=True, text=True,
+        out = subprocess.run([sys.executable, "-c", TREE_DIGEST.format(root=ROOT, precision=precision, batch=batch)], env=e, check=True, capture_output=True, text=True,
                              timeout=600).stdout
         return [l for l in out.splitlines() if l.startswith("DIGEST")][-1].split()[1]
 

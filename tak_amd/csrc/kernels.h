@@ -140,7 +140,7 @@ struct FcGatherArgs {
 };
 hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp, const float* bias, float* out, int M, int K,
                        int NP, int out_stride, int n_valid, bool a_frag = false, float* stats = nullptr, int n_soft = 0,
-                       const FcGatherArgs* gather = nullptr);
+                       const FcGatherArgs* gather = nullptr, const float* Wlin = nullptr);  // Wlin: Wp with every (chunk, tile) block in lane order (k_fc_ring's LDS-DMA source)
 bool fc_frag_supported(int K, int NP);
 bool fc_stats_supported(int K, int NP, int out_stride);
 bool fc_gather_supported(int M, int K, int NP);

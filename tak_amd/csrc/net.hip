@@ -27,6 +27,7 @@ struct Net {
     std::vector<ConvLayer> res1, res2;
     ConvLayer policy_conv;            // TG_HEAD_CONV
     DevBuf policy_w, policy_b;        // TG_HEAD_FC5: Wp [K/16][NP][16]
+    DevBuf policy_w_lin;              // the same, every (chunk, tile) block of 16 columns in the MFMA fragment's lane order (k_fc_ring's LDS-DMA source)
     int policy_np = 0;                // padded FC outputs
     bool value_in_fc = false;         // the value head rides in padding column P of the policy FC (logit P = value pre-activation)
     DevBuf value_w;                   // [nsq*F] in NHWC order
@@ -288,6 +289,18 @@ int net_finalize(TgEngine* e) {
         TG_HIP(n->policy_w.ensure(wp.size() * 4));
         TG_HIP(n->policy_b.ensure(bp.size() * 4));
         TG_HIP(hipMemcpy(n->policy_w.p, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
+        {   // block (chunk, tile): slot q·16 + r holds the 4 floats (k = 16·chunk + 4q … 4q + 3) of column 16·tile + r
+            std::vector<float> wl(wp.size());
+            const size_t tiles = (size_t)NP / 16;
+            for (size_t c = 0; c < K / 16; c++)
+                for (size_t t = 0; t < tiles; t++)
+                    for (size_t r = 0; r < 16; r++)
+                        for (size_t qq = 0; qq < 4; qq++)
+                            for (size_t u = 0; u < 4; u++)
+                                wl[((c * tiles + t) * 64 + qq * 16 + r) * 4 + u] = wp[((c * NP + t * 16 + r) * 4 + qq) * 4 + u];
+            TG_HIP(n->policy_w_lin.ensure(wl.size() * 4));
+            TG_HIP(hipMemcpy(n->policy_w_lin.p, wl.data(), wl.size() * 4, hipMemcpyHostToDevice));
+        }
         TG_HIP(hipMemcpy(n->policy_b.p, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
     }
     {
@@ -653,9 +666,10 @@ static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const ui
     } else {
         float* stats = n->fc_stats_on ? n->fc_stats.as<float>() + (size_t)pos0 * n->fc_stat_stride * 2 : nullptr;
         const bool gather = !d_policy && pos0 == 0 && n->gather_on && net_gather_ok(e, nb);
+        static const bool lin_src = getenv("TG_FC_PERMUTED_SRC") == nullptr;  // A/B: the ring's LDS-DMA reads the [chunk][column][q] layout (same bits)
         TG_HIP(launch_gemm(st, x, nsq * F, n->policy_w.as<float>(), n->policy_b.as<float>(), logits, nb, nsq * F, n->policy_np,
                            n->policy_np, e->policy_size + (n->value_in_fc ? 1 : 0), !n->s3 && n->fused && n->tower.frag_out,
-                           stats, e->policy_size, gather ? &n->gather : nullptr));
+                           stats, e->policy_size, gather ? &n->gather : nullptr, lin_src ? n->policy_w_lin.as<float>() : nullptr));
         if (d_policy && stats) TG_HIP(launch_softmax_stats(st, logits, n->policy_np, stats, n->fc_stat_blocks, n->fc_stat_stride, e->policy_size, nb, d_policy, d_eval));
         else if (d_policy) TG_HIP(launch_softmax(st, logits, n->policy_np, false, nsq, 0, e->policy_size, nb, d_policy, n->value_in_fc ? d_eval : nullptr));
     }

@@ -967,10 +967,12 @@ constexpr int FC_PLANE = (FC_KSTEP / 16) * FC_CT * 16;  // 832 slots per k-quart
 constexpr int FC_RING = 3;
 constexpr int FC_RING_SLOTS = 4 * FC_PLANE;                                        // f32x4 slots per buffer (3328)
 constexpr size_t FC_RING_LDS = (size_t)FC_RING * FC_RING_SLOTS * 16 + 2 * FC_RING * sizeof(uint32_t);
+// (diagnostic build only — scripts/probes/fc_ring_stamps.hip: stamps of workgroup (0, 0); s_memtime has another base on every XCD)
+#define TG_FC_STAMP(step, slot) do { if (blockIdx.y == 0) { TG_STAMP(step, slot); } } while (0)
 __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, int lda, const float* __restrict__ Wp,
                                                  const float* __restrict__ bias, float* __restrict__ out, int M, int K, int NP,
                                                  int out_stride, int n_valid, int a_frag, float* __restrict__ stats, int n_soft,
-                                                 const FcGather gather) {
+                                                 const FcGather gather, const float* __restrict__ Wlin) {
     extern __shared__ __attribute__((aligned(16))) float fc_ring_lds[];
     f32x4* wl = (f32x4*)fc_ring_lds;                                // [FC_RING][chunk][tile slot][q][r16]
     uint32_t* flags = (uint32_t*)(wl + FC_RING * FC_RING_SLOTS);    // ready[FC_RING], done[FC_RING]
@@ -1003,16 +1005,20 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
     // q·16 + r16 inside it — the lane number of its reader, so the fragment reads are contiguous and conflict free — from
     // the block's 1 KB of the weight matrix (slot r16·4 + q: the permutation is on the source side, 16 cache lines per
     // instruction).  52 blocks per K-step, block i = wave + 8u by this wave (7 for waves 0-3, 6 for waves 4-7).
+    // Wlin (optional): the same weights with every (chunk, tile) block stored in the READER's lane order — slot (chunk·NP/16 + tile)·64 +
+    // q·16 + r16 — so that an LDS-DMA instruction's 64 lanes read 64 consecutive 16-byte slots (the permuted source makes each
+    // quarter-wave touch 16 different cache lines of the block)
+    if (Wlin) wg = (const f32x4*)Wlin;
     uint32_t src0[7];
 #pragma unroll
     for (int u = 0; u < 7; u++) {
         int blk = wave + 8 * u;
         blk = blk < FC_RING_SLOTS / 64 ? blk : FC_RING_SLOTS / 64 - 1;
         const int c = blk / FC_CT, j = blk - c * FC_CT;
-        const int col = (j < FC_MAIN_TILES ? n0 + j * 16 : nx) + r16;
-        src0[u] = (uint32_t)(((size_t)c * NP + col) * 4 + q);
+        const int col0 = j < FC_MAIN_TILES ? n0 + j * 16 : nx;
+        src0[u] = Wlin ? (uint32_t)(((size_t)c * (NP >> 4) + (col0 >> 4)) * 64 + lane) : (uint32_t)(((size_t)c * NP + col0 + r16) * 4 + q);
     }
-    const uint32_t step_slots = (uint32_t)(4 * NP * 4);  // f32x4 slots of the weights per K-step
+    const uint32_t step_slots = (uint32_t)(4 * NP * 4);  // f32x4 slots of the weights per K-step (either layout)
     auto fill = [&](int step, int buf) {
 #pragma unroll
         for (int u = 0; u < 7; u++)
@@ -1071,8 +1077,10 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
         const int buf = step % FC_RING;
         const f32x4* wb = wl + buf * FC_RING_SLOTS;
         // (the flags were read half a chunk ago, under the MFMAs: they normally hold already and nobody waits out a round trip)
+        TG_FC_STAMP(step, 0);  // (diagnostic build only: scripts/probes/fc_ring_stamps.hip)
         if (!(TG_RING_PROBE & (1 | 32)) && (int)__builtin_amdgcn_readfirstlane((int)early_ready) < 8 * (step / FC_RING + 1))
             fc_ring_wait(ready0 + 4 * buf, 8u * (uint32_t)(step / FC_RING + 1));
+        TG_FC_STAMP(step, 1);
         __builtin_amdgcn_sched_barrier(0);
         TG_FC_LOAD(0, 0, FC_H1)
         a2 = aload(step * 4 + 2);
@@ -1090,21 +1098,27 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
         TG_FC_CHUNK(0, a0, true, (void)0)
         TG_FC_CHUNK(1, a1, true, early_done = flag_lds[FC_RING + (step + 2) % FC_RING])
         // the middle of the step: signal the step after this one, refill the buffer of the step before it
+        TG_FC_STAMP(step, 2);
         asm volatile("" : "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1));  // the compiler's own wait for the four loads above …
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // … which, loads returning in order, covers last step's refill too
+        TG_FC_STAMP(step, 3);
         if (!(TG_RING_PROBE & (1 | 32)) && step >= 1 && step + 1 < nsteps) fc_ring_signal(ready0 + 4 * ((step + 1) % FC_RING));
         if (!(TG_RING_PROBE & 1) && step + 2 < nsteps) {
             if (!(TG_RING_PROBE & 32) && (int)__builtin_amdgcn_readfirstlane((int)early_done) < 8 * ((step + 2) / FC_RING))
                 fc_ring_wait(done0 + 4 * ((step + 2) % FC_RING), 8u * (uint32_t)((step + 2) / FC_RING));
+            TG_FC_STAMP(step, 4);
             if (!(TG_RING_PROBE & 16)) fill(step + 2, (step + 2) % FC_RING);
         }
+        TG_FC_STAMP(step, 5);
         __builtin_amdgcn_sched_barrier(0);
         TG_FC_CHUNK(2, a2, true, (void)0)
         TG_FC_CHUNK(3, a3, false, early_ready = flag_lds[(step + 1) % FC_RING])
         if (!(TG_RING_PROBE & (1 | 32))) fc_ring_signal(done0 + 4 * buf);
+        TG_FC_STAMP(step, 6);
         a0 = b0;
         a1 = b1;
     }
+    TG_FC_STAMP(nsteps, 0);
 #undef TG_FC_LOAD
 #undef TG_FC_MFMA
 #undef TG_FC_CHUNK
@@ -1733,7 +1747,8 @@ bool fc_stats_supported(int K, int NP, int out_stride) { return fc_shape_ok(K, N
 bool fc_gather_supported(int M, int K, int NP) { return fc_shape_ok(K, NP) && M > FC_SMALL_ROWS; }
 
 hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp, const float* bias, float* out, int M, int K,
-                       int NP, int out_stride, int n_valid, bool a_frag, float* stats, int n_soft, const FcGatherArgs* gather) {
+                       int NP, int out_stride, int n_valid, bool a_frag, float* stats, int n_soft, const FcGatherArgs* gather,
+                       const float* Wlin) {
     if (a_frag && !fc_frag_supported(K, NP)) return hipErrorInvalidValue;
     if (stats && (!fc_stats_supported(K, NP, out_stride) || n_valid > FC_TILES * 16)) return hipErrorInvalidValue;
     if (gather && (!stats || !fc_gather_supported(M, K, NP))) return hipErrorInvalidValue;
@@ -1753,7 +1768,7 @@ hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp,
         FcGather g{nullptr, nullptr, nullptr, 0};
         if (gather) g = FcGather{gather->child_pidx, gather->leaf_rec, gather->child_logit, gather->stride};
         hipLaunchKernelGGL(k_fc_ring, dim3((M + 127) / 128, FC_MAIN_BLOCKS), dim3(512), FC_RING_LDS, st, A, lda, Wp, bias, gather ? nullptr : out, M, K, NP,
-                           out_stride, n_valid, a_frag ? 1 : 0, stats, n_soft, g);
+                           out_stride, n_valid, a_frag ? 1 : 0, stats, n_soft, g, Wlin);
         return hipGetLastError();
     }
     dim3 grid((M + 127) / 128, NP / 64);

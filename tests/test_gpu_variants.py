@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _digest(cfg, batch, **env):
     e = dict(os.environ)
-    for k in ("TG_NO_HALO_TOWER", "TG_NO_FC_GATHER", "TG_S3_NO_FC_RING", "TG_NO_FRAG_OUT", "TG_PRECISION", "TG_NO_CONST_BIAS", "TG_NO_FC_STATS"):
+    for k in ("TG_NO_HALO_TOWER", "TG_NO_FC_GATHER", "TG_S3_NO_FC_RING", "TG_FC_PERMUTED_SRC", "TG_NO_FRAG_OUT", "TG_PRECISION", "TG_NO_CONST_BIAS", "TG_NO_FC_STATS"):
         e.pop(k, None)
     e.update(env)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "ab_bits.py"), cfg, str(batch)], env=e, check=True,
@@ -30,6 +30,7 @@ def test_launcher_variants_return_identical_bits(cfg, batch):
     assert _digest(cfg, batch, TG_NO_HALO_TOWER="1") == base
     if cfg != "c3":  # FC policy head
         assert _digest(cfg, batch, TG_NO_FRAG_OUT="1") == base  # row-major tower output into the ring FC
+        assert _digest(cfg, batch, TG_FC_PERMUTED_SRC="1") == base  # the ring's LDS-DMA from the [chunk][column][q] weight layout
     # layer 0 with every input plane as data (the order of round 2) is another summation order: other low bits, and ITS
     # halo / plain variants agree with each other
     dense = _digest(cfg, batch, TG_NO_CONST_BIAS="1")

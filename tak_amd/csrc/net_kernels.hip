@@ -964,6 +964,9 @@ constexpr int FC_PLANE = (FC_KSTEP / 16) * FC_CT * 16;  // 832 slots per k-quart
 // s_setprio 1 for waves 4-7 (−1 µs, inside the noise) or for waves 0-3 (0), and waves 4-7 issuing their share of a refill half a
 // step after waves 0-3 so that the two waves of a SIMD never issue LDS-DMA pieces at the same time (+ 11 µs: the older wave of
 // a SIMD runs ahead of the younger one anyway, and the later refill makes the younger one the workgroup's laggard).
+#ifndef TG_RING_PROBE
+#define TG_RING_PROBE 0  // timing probes (wrong results): 1 = no refills and no flags, 2 = no activation stream, 16 = flags only, 32 = refills only
+#endif
 constexpr int FC_RING = 3;
 constexpr int FC_RING_SLOTS = 4 * FC_PLANE;                                        // f32x4 slots per buffer (3328)
 constexpr size_t FC_RING_LDS = (size_t)FC_RING * FC_RING_SLOTS * 16 + 2 * FC_RING * sizeof(uint32_t);
@@ -1004,15 +1007,28 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
     // LDS-DMA: one wave-instruction fills 64 consecutive slots of a buffer (1 KB) = one (chunk, tile slot) block, slot
     // q·16 + r16 inside it — the lane number of its reader, so the fragment reads are contiguous and conflict free — from
     // the block's 1 KB of the weight matrix (slot r16·4 + q: the permutation is on the source side, 16 cache lines per
-    // instruction).  52 blocks per K-step, block i = wave + 8u by this wave (7 for waves 0-3, 6 for waves 4-7).
+    // instruction).  52 blocks per K-step, issued by the filler waves (below).
     // Wlin (optional): the same weights with every (chunk, tile) block stored in the READER's lane order — slot (chunk·NP/16 + tile)·64 +
     // q·16 + r16 — so that an LDS-DMA instruction's 64 lanes read 64 consecutive 16-byte slots (the permuted source makes each
     // quarter-wave touch 16 different cache lines of the block)
     if (Wlin) wg = (const f32x4*)Wlin;
-    uint32_t src0[7];
+    // Who issues the refills: waves 4-7 — the YOUNGER wave of every SIMD — issue all 52 pieces of a K-step (13 each), waves 0-3 none,
+    // and ready[] counts 4 per use.  The older wave of a SIMD wins the matrix pipe and runs ahead; the younger one lags anyway, and
+    // while it spends 2 – 3.5 k cycles per step handing pieces to the memory pipe its partner issues MFMAs undisturbed (measured,
+    // profiles/r04_b_fc_candidates.txt §7: every wave issuing its share 168.9 µs, waves 0-3 all of them 168.5 µs, waves 4-7 all of
+    // them 166.2 µs; TG_FC_ALL_FILL restores the first)
+#ifdef TG_FC_ALL_FILL
+    constexpr int FILLERS = 8, PER = 7;
+    const int fwave = wave;
+#else
+    constexpr int FILLERS = 4, PER = 13;
+    const int fwave = wave - 4;
+#endif
+    constexpr bool HALF_FILL = FILLERS < 8;
+    uint32_t src0[PER];
 #pragma unroll
-    for (int u = 0; u < 7; u++) {
-        int blk = wave + 8 * u;
+    for (int u = 0; u < PER; u++) {
+        int blk = (fwave < 0 ? 0 : fwave) + FILLERS * u;
         blk = blk < FC_RING_SLOTS / 64 ? blk : FC_RING_SLOTS / 64 - 1;
         const int c = blk / FC_CT, j = blk - c * FC_CT;
         const int col0 = j < FC_MAIN_TILES ? n0 + j * 16 : nx;
@@ -1020,15 +1036,13 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
     }
     const uint32_t step_slots = (uint32_t)(4 * NP * 4);  // f32x4 slots of the weights per K-step (either layout)
     auto fill = [&](int step, int buf) {
+        if (HALF_FILL && (fwave < 0 || fwave >= FILLERS)) return;
 #pragma unroll
-        for (int u = 0; u < 7; u++)
-            if (wave + 8 * u < FC_RING_SLOTS / 64)
+        for (int u = 0; u < PER; u++)
+            if (fwave + FILLERS * u < FC_RING_SLOTS / 64)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wg + (size_t)step * step_slots + src0[u]),
-                                                 (__attribute__((address_space(3))) void*)(wl + buf * FC_RING_SLOTS + (wave + 8 * u) * 64), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(wl + buf * FC_RING_SLOTS + (fwave + FILLERS * u) * 64), 16, 0, 0);
     };
-#ifndef TG_RING_PROBE
-#define TG_RING_PROBE 0  // timing probes (wrong results): 1 = no refills and no flags, 2 = no activation stream, 16 = flags only, 32 = refills only
-#endif
     auto aload = [&](int kc) { return ap[(size_t)((TG_RING_PROBE & 2) ? 0 : (kc < nchunks ? kc : nchunks - 1)) * achunk]; };
     if (tid < 2 * FC_RING) flags[tid] = 0u;
     __syncthreads();
@@ -1043,8 +1057,11 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
     // behind a young refill, whose data comes from the MALL or HBM and takes its time.
     f32x4 a0 = aload(0), a1 = aload(1), a2, a3, b0, b1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    fc_ring_signal(ready0);
-    if (nsteps > 1) fc_ring_signal(ready0 + 4);
+    const bool filler = !HALF_FILL || (fwave >= 0 && fwave < FILLERS);
+    if (filler) {
+        fc_ring_signal(ready0);
+        if (nsteps > 1) fc_ring_signal(ready0 + 4);
+    }
     // One chunk: the 13 weight fragments in two halves (7 + 6 tile slots; the 13th only feeds MFMAs in the waves that own a
     // leftover tile); each half is requested while the other half's MFMAs run, across chunk boundaries inside a step (the
     // tower's half-tile pipeline, conv_mainloop.cuh).
@@ -1078,8 +1095,8 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
         const f32x4* wb = wl + buf * FC_RING_SLOTS;
         // (the flags were read half a chunk ago, under the MFMAs: they normally hold already and nobody waits out a round trip)
         TG_FC_STAMP(step, 0);  // (diagnostic build only: scripts/probes/fc_ring_stamps.hip)
-        if (!(TG_RING_PROBE & (1 | 32)) && (int)__builtin_amdgcn_readfirstlane((int)early_ready) < 8 * (step / FC_RING + 1))
-            fc_ring_wait(ready0 + 4 * buf, 8u * (uint32_t)(step / FC_RING + 1));
+        if (!(TG_RING_PROBE & (1 | 32)) && (int)__builtin_amdgcn_readfirstlane((int)early_ready) < FILLERS * (step / FC_RING + 1))
+            fc_ring_wait(ready0 + 4 * buf, (uint32_t)FILLERS * (uint32_t)(step / FC_RING + 1));
         TG_FC_STAMP(step, 1);
         __builtin_amdgcn_sched_barrier(0);
         TG_FC_LOAD(0, 0, FC_H1)
@@ -1102,8 +1119,8 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
         asm volatile("" : "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1));  // the compiler's own wait for the four loads above …
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // … which, loads returning in order, covers last step's refill too
         TG_FC_STAMP(step, 3);
-        if (!(TG_RING_PROBE & (1 | 32)) && step >= 1 && step + 1 < nsteps) fc_ring_signal(ready0 + 4 * ((step + 1) % FC_RING));
-        if (!(TG_RING_PROBE & 1) && step + 2 < nsteps) {
+        if (!(TG_RING_PROBE & (1 | 32)) && step >= 1 && step + 1 < nsteps && filler) fc_ring_signal(ready0 + 4 * ((step + 1) % FC_RING));
+        if (!(TG_RING_PROBE & 1) && step + 2 < nsteps && filler) {
             if (!(TG_RING_PROBE & 32) && (int)__builtin_amdgcn_readfirstlane((int)early_done) < 8 * ((step + 2) / FC_RING))
                 fc_ring_wait(done0 + 4 * ((step + 2) % FC_RING), 8u * (uint32_t)((step + 2) / FC_RING));
             TG_FC_STAMP(step, 4);

@@ -1065,7 +1065,9 @@ constexpr int FSR_BLOCKS = 2 * FSR_CT * 2;                  // 1 KB blocks per K
 constexpr int FSR_SLOTS = FSR_BLOCKS * 64;                  // 3328 slots per buffer
 constexpr int FSR_RING = 3;
 constexpr size_t FSR_LDS = (size_t)FSR_RING * FSR_SLOTS * 16 + 2 * FSR_RING * sizeof(uint32_t);
-constexpr int FSR_PER = (FSR_BLOCKS + FSR_NW - 1) / FSR_NW; // blocks a wave fills per K-step (13)
+constexpr int FSR_FILLERS = FSR_NW;                         // waves that issue the refills: all of them (only the younger wave of every SIMD, as in k_fc_ring: 90 µs instead of 66 —
+                                                            // at the bf16 rate a K-step's MFMAs are no longer than the 13 pieces' issue)
+constexpr int FSR_PER = (FSR_BLOCKS + FSR_FILLERS - 1) / FSR_FILLERS;  // blocks such a wave fills per K-step (13)
 
 __global__ __launch_bounds__(FSR_NW * 64) void k_fc_s3_ring(const u32x4* __restrict__ A, const u32x4* __restrict__ Wr, const float* __restrict__ bias,
                                                             float* __restrict__ out, int M, int K, int out_stride, int n_valid,
@@ -1098,10 +1100,12 @@ __global__ __launch_bounds__(FSR_NW * 64) void k_fc_s3_ring(const u32x4* __restr
     const int nsteps = K / 64, nchunks = nsteps * 2;
     // LDS-DMA: block b = (chunk·13 + tile slot)·2 + hi|lo of a K-step goes to slots b·64 … b·64 + 63 of the buffer; wave w fills
     // blocks w, w + 4, …
+    const int fwave = wave - (FSR_NW - FSR_FILLERS);  // ≥ 0: this wave issues refills (and signals ready[])
+    const bool filler = fwave >= 0;
     uint32_t src0[FSR_PER];
 #pragma unroll
     for (int u = 0; u < FSR_PER; u++) {
-        int b = wave + FSR_NW * u;
+        int b = (filler ? fwave : 0) + FSR_FILLERS * u;
         b = b < FSR_BLOCKS ? b : FSR_BLOCKS - 1;
         const int h = b & 1, cj = b >> 1, c = cj / FSR_CT, j = cj - c * FSR_CT;
         const int tile = j < FC_MAIN_TILES ? cb * FC_MAIN_TILES + j : FC_MAIN_TILES * FC_MAIN_BLOCKS + X.l;
@@ -1111,9 +1115,9 @@ __global__ __launch_bounds__(FSR_NW * 64) void k_fc_s3_ring(const u32x4* __restr
     auto fill = [&](int step, int buf) {
 #pragma unroll
         for (int u = 0; u < FSR_PER; u++)
-            if (wave + FSR_NW * u < FSR_BLOCKS)
+            if (filler && fwave + FSR_FILLERS * u < FSR_BLOCKS)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wr + (size_t)step * step_slots + src0[u]),
-                                                 (__attribute__((address_space(3))) void*)(wl + buf * FSR_SLOTS + (wave + FSR_NW * u) * 64), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(wl + buf * FSR_SLOTS + (fwave + FSR_FILLERS * u) * 64), 16, 0, 0);
     };
     auto aload = [&](int i, int kc, int lo) { return ap[i][(size_t)((TG_FSR_PROBE & 2) ? 0 : (kc < nchunks ? kc : nchunks - 1)) * 8 + 4 * lo]; };
     if (tid < 2 * FSR_RING) flags[tid] = 0u;
@@ -1131,8 +1135,10 @@ __global__ __launch_bounds__(FSR_NW * 64) void k_fc_s3_ring(const u32x4* __restr
 #pragma unroll
     for (int i = 0; i < FSR_RT; i++) { a0[i][0] = aload(i, 0, 0); a0[i][1] = aload(i, 0, 1); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    fc_ring_signal(ready0);
-    if (nsteps > 1) fc_ring_signal(ready0 + 4);
+    if (filler) {
+        fc_ring_signal(ready0);
+        if (nsteps > 1) fc_ring_signal(ready0 + 4);
+    }
     constexpr int H1 = 7;
     u32x4 wh[FSR_CT], wo[FSR_CT];
 #define TG_FS_LOAD(C, J0, J1) _Pragma("unroll") for (int j = J0; j < J1; j++) { wh[j] = wb[(((C) * FSR_CT + j) * 2 + 0) * 64 + lane]; if (!(TG_FSR_PROBE & 4)) wo[j] = wb[(((C) * FSR_CT + j) * 2 + 1) * 64 + lane]; else wo[j] = wh[j]; }
@@ -1172,8 +1178,8 @@ __global__ __launch_bounds__(FSR_NW * 64) void k_fc_s3_ring(const u32x4* __restr
     for (int step = 0; step < nsteps; step++) {
         const int buf = step % FSR_RING;
         const u32x4* wb = wl + buf * FSR_SLOTS;
-        if (!(TG_FSR_PROBE & 1) && (int)__builtin_amdgcn_readfirstlane((int)early_ready) < FSR_NW * (step / FSR_RING + 1))
-            fc_ring_wait(ready0 + 4 * buf, (uint32_t)FSR_NW * (uint32_t)(step / FSR_RING + 1));
+        if (!(TG_FSR_PROBE & 1) && (int)__builtin_amdgcn_readfirstlane((int)early_ready) < FSR_FILLERS * (step / FSR_RING + 1))
+            fc_ring_wait(ready0 + 4 * buf, (uint32_t)FSR_FILLERS * (uint32_t)(step / FSR_RING + 1));
         __builtin_amdgcn_sched_barrier(0);
         TG_FS_LOAD(0, 0, H1)
 #pragma unroll
@@ -1197,8 +1203,8 @@ __global__ __launch_bounds__(FSR_NW * 64) void k_fc_s3_ring(const u32x4* __restr
 #pragma unroll
         for (int i = 0; i < FSR_RT; i++) asm volatile("" : "+v"(a1[i][0]), "+v"(a1[i][1]), "+v"(b0[i][0]), "+v"(b0[i][1]));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (step >= 1 && step + 1 < nsteps) fc_ring_signal(ready0 + 4 * ((step + 1) % FSR_RING));
-        if (!(TG_FSR_PROBE & 1) && step + 2 < nsteps) {
+        if (filler && step >= 1 && step + 1 < nsteps) fc_ring_signal(ready0 + 4 * ((step + 1) % FSR_RING));
+        if (!(TG_FSR_PROBE & 1) && filler && step + 2 < nsteps) {
             if ((int)__builtin_amdgcn_readfirstlane((int)early_done) < FSR_NW * ((step + 2) / FSR_RING))
                 fc_ring_wait(done0 + 4 * ((step + 2) % FSR_RING), (uint32_t)FSR_NW * (uint32_t)((step + 2) / FSR_RING));
             fill(step + 2, (step + 2) % FSR_RING);

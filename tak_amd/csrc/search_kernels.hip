@@ -17,7 +17,10 @@
 
 namespace tg {
 
-constexpr int WPB = 4;  // waves (games) per 256-thread block
+#ifndef TG_WPB
+#define TG_WPB 4
+#endif
+constexpr int WPB = TG_WPB;  // waves (games) per block (4: 256 threads; other values: scripts/probes/tree_wpb_probe.sh)
 
 __device__ inline int game_of_wave() { return (int)(blockIdx.x * WPB + (threadIdx.x >> 6)); }
 __device__ inline void flag(const SearchDev& S, uint32_t bit) { atomicOr(S.err, bit); }
@@ -380,7 +383,7 @@ __device__ __forceinline__ void select_pass(const SearchDev& S, const uint8_t* _
 // the wave's own stores ordered before its later loads (s_waitcnt: a wave's accesses go through one in-order, write-through
 // L1 path; an agent-scope fence would write back the whole L2 per wave and cost more than the launches it replaces).
 template <int NB>
-__global__ __launch_bounds__(256) void k_select(SearchDev S, const uint8_t* __restrict__ active) {
+__global__ __launch_bounds__(WPB * 64) void k_select(SearchDev S, const uint8_t* __restrict__ active) {
     __shared__ uint32_t path_lds[WPB][MAX_DEPTH];
     __shared__ uint16_t mv_lds[WPB][EX_MOVES];
     const int g = game_of_wave();
@@ -487,7 +490,7 @@ __device__ __forceinline__ void backup_pass(const SearchDev& S, const int g, con
 
 // S.pass as in k_select: one de-virtualisation, or all of the iteration's in rollout order
 template <int NB>
-__global__ __launch_bounds__(256) void k_backup(SearchDev S) {
+__global__ __launch_bounds__(WPB * 64) void k_backup(SearchDev S) {
     const int g = game_of_wave();
     if (g >= S.G) return;
     const int p0 = S.pass < 0 ? 0 : S.pass, p1 = S.pass < 0 ? S.batch : S.pass + 1;
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(256) void k_backup(SearchDev S) {
 // few nodes of the same tree from the same wave, so the second finds them in cache and one kernel boundary per iteration
 // disappears.  Same device functions as the separate kernels → same trees.
 template <int NB>
-__global__ __launch_bounds__(256) void k_backup_select(SearchDev S) {
+__global__ __launch_bounds__(WPB * 64) void k_backup_select(SearchDev S) {
     __shared__ uint32_t path_lds[WPB][MAX_DEPTH];
     __shared__ uint16_t mv_lds[WPB][EX_MOVES];
     const int g = game_of_wave();
@@ -694,7 +697,7 @@ __global__ __launch_bounds__(64) void k_root_stats(SearchDev S, uint16_t* moves,
 }
 
 // tg_search_play: find the child for a caller-chosen move, play it on the root state
-__global__ __launch_bounds__(256) void k_play_move(SearchDev S, const uint16_t* __restrict__ moves, const uint8_t* __restrict__ active,
+__global__ __launch_bounds__(WPB * 64) void k_play_move(SearchDev S, const uint16_t* __restrict__ moves, const uint8_t* __restrict__ active,
                                                    int32_t* __restrict__ op) {
     const int g = game_of_wave();
     if (g >= S.G) return;
@@ -730,7 +733,7 @@ __global__ __launch_bounds__(256) void k_play_move(SearchDev S, const uint16_t* 
 
 // (a) opening, :110-116.  "a1", then one of the two far corners (reference hard-codes the 6×6 names
 // a6 / f6; generalised to (0, N-1) / (N-1, N-1)).
-__global__ __launch_bounds__(256) void k_sp_opening(SearchDev S) {
+__global__ __launch_bounds__(WPB * 64) void k_sp_opening(SearchDev S) {
     const int g = game_of_wave();
     if (g >= S.G) return;
     if (!S.alive[g]) return;
@@ -766,7 +769,7 @@ __device__ inline void stage_example(const SearchDev& S, const SelfPlayDev& P, i
 }
 
 // (b) instant-win scan, :119-171
-__global__ __launch_bounds__(256) void k_sp_instant_win(SearchDev S, SelfPlayDev P) {
+__global__ __launch_bounds__(WPB * 64) void k_sp_instant_win(SearchDev S, SelfPlayDev P) {
     __shared__ uint16_t mv_lds[WPB][EX_MOVES];
     __shared__ uint8_t win_lds[WPB][EX_MOVES];
     const int g = game_of_wave();
@@ -858,7 +861,7 @@ __global__ __launch_bounds__(1024) void k_sp_finish_scan(SearchDev S, SelfPlayDe
 }
 
 // complete the finished games' examples (:158-169, :245-256), reset tree and game (or retire the slot)
-__global__ __launch_bounds__(256) void k_sp_finish_apply(SearchDev S, SelfPlayDev P, int32_t* __restrict__ op) {
+__global__ __launch_bounds__(WPB * 64) void k_sp_finish_apply(SearchDev S, SelfPlayDev P, int32_t* __restrict__ op) {
     const int g = game_of_wave();
     if (g >= S.G) return;
     const int lane = lane_id();
@@ -905,7 +908,7 @@ __global__ void k_sp_noise_mask(SearchDev S, SelfPlayDev P) {
 }
 
 // (e) pick_move (play.rs:49-67), example (:222-225), play (:227-228), result (:230)
-__global__ __launch_bounds__(256) void k_sp_pick(SearchDev S, SelfPlayDev P, int32_t* __restrict__ op) {
+__global__ __launch_bounds__(WPB * 64) void k_sp_pick(SearchDev S, SelfPlayDev P, int32_t* __restrict__ op) {
     const int g = game_of_wave();
     if (g >= S.G) return;
     const int lane = lane_id();
@@ -999,9 +1002,9 @@ static inline dim3 wgrid(int G) { return dim3((G + WPB - 1) / WPB); }
 static const bool g_runtime_n = getenv("TG_RUNTIME_N") != nullptr;  // A/B: the generic instantiation for every size (same results)
 #define TG_BY_BOARD(KERNEL, ...)                                                                          \
     do {                                                                                                  \
-        if (S.n == 5 && !g_runtime_n) hipLaunchKernelGGL(KERNEL<5>, wgrid(S.G), dim3(256), 0, st, __VA_ARGS__);      \
-        else if (S.n == 6 && !g_runtime_n) hipLaunchKernelGGL(KERNEL<6>, wgrid(S.G), dim3(256), 0, st, __VA_ARGS__); \
-        else hipLaunchKernelGGL(KERNEL<0>, wgrid(S.G), dim3(256), 0, st, __VA_ARGS__);                    \
+        if (S.n == 5 && !g_runtime_n) hipLaunchKernelGGL(KERNEL<5>, wgrid(S.G), dim3(WPB * 64), 0, st, __VA_ARGS__);      \
+        else if (S.n == 6 && !g_runtime_n) hipLaunchKernelGGL(KERNEL<6>, wgrid(S.G), dim3(WPB * 64), 0, st, __VA_ARGS__); \
+        else hipLaunchKernelGGL(KERNEL<0>, wgrid(S.G), dim3(WPB * 64), 0, st, __VA_ARGS__);                    \
     } while (0)
 void launch_select(hipStream_t st, const SearchDev& S, const uint8_t* active) { TG_BY_BOARD(k_select, S, active); }
 void launch_backup(hipStream_t st, const SearchDev& S) { TG_BY_BOARD(k_backup, S); }
@@ -1021,21 +1024,21 @@ void launch_root_stats(hipStream_t st, const SearchDev& S, uint16_t* moves, uint
     hipLaunchKernelGGL(k_root_stats, dim3(S.G), dim3(64), 0, st, S, moves, visits, prior, q, counts, root_visits, root_q);
 }
 void launch_play_move(hipStream_t st, const SearchDev& S, const uint16_t* moves, const uint8_t* active, int32_t* op) {
-    hipLaunchKernelGGL(k_play_move, wgrid(S.G), dim3(256), 0, st, S, moves, active, op);
+    hipLaunchKernelGGL(k_play_move, wgrid(S.G), dim3(WPB * 64), 0, st, S, moves, active, op);
 }
-void launch_sp_opening(hipStream_t st, const SearchDev& S) { hipLaunchKernelGGL(k_sp_opening, wgrid(S.G), dim3(256), 0, st, S); }
+void launch_sp_opening(hipStream_t st, const SearchDev& S) { hipLaunchKernelGGL(k_sp_opening, wgrid(S.G), dim3(WPB * 64), 0, st, S); }
 void launch_sp_instant_win(hipStream_t st, const SearchDev& S, const SelfPlayDev& P) {
-    hipLaunchKernelGGL(k_sp_instant_win, wgrid(S.G), dim3(256), 0, st, S, P);
+    hipLaunchKernelGGL(k_sp_instant_win, wgrid(S.G), dim3(WPB * 64), 0, st, S, P);
 }
 void launch_sp_finish(hipStream_t st, const SearchDev& S, const SelfPlayDev& P, int32_t* op) {
     hipLaunchKernelGGL(k_sp_finish_scan, dim3(1), dim3(1024), 0, st, S, P);
-    hipLaunchKernelGGL(k_sp_finish_apply, wgrid(S.G), dim3(256), 0, st, S, P, op);
+    hipLaunchKernelGGL(k_sp_finish_apply, wgrid(S.G), dim3(WPB * 64), 0, st, S, P, op);
 }
 void launch_sp_noise_mask(hipStream_t st, const SearchDev& S, const SelfPlayDev& P) {
     hipLaunchKernelGGL(k_sp_noise_mask, dim3((S.G + 255) / 256), dim3(256), 0, st, S, P);
 }
 void launch_sp_pick(hipStream_t st, const SearchDev& S, const SelfPlayDev& P, int32_t* op) {
-    hipLaunchKernelGGL(k_sp_pick, wgrid(S.G), dim3(256), 0, st, S, P, op);
+    hipLaunchKernelGGL(k_sp_pick, wgrid(S.G), dim3(WPB * 64), 0, st, S, P, op);
 }
 void launch_sp_count_ply(hipStream_t st, const SelfPlayDev& P) { hipLaunchKernelGGL(k_sp_count_ply, dim3(1), dim3(1), 0, st, P); }
 

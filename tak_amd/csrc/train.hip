@@ -111,8 +111,13 @@ struct Trainer {
     // heads
     DevBuf logits, dlogits, logp, eval, dpre, loss_p_rows, loss_z_rows, loss_sums;
     // backward
-    DevBuf d_a, d_b, dz, gskip, stats, mean_g, mean_gx, zero_bias;
+    DevBuf d_a, d_b, dz, dz2, gskip, stats, mean_g, mean_gx, zero_bias;
     DevBuf part_d, part_w;
+    // Round 4: the weight gradients run on a stream of their own beside the data-gradient chain (backward_train): dz alternates
+    // between two buffers, ev_dz[k] = "dz buffer k holds this layer's dz" (engine stream), ev_wg[k] = "the weight gradient has
+    // read dz buffer k" (weight-gradient stream)
+    hipStream_t wg_stream = nullptr;
+    hipEvent_t ev_dz[2] = {nullptr, nullptr}, ev_wg[2] = {nullptr, nullptr}, ev_head = nullptr;
     bool packed = false;
     uint64_t adam_t = 0;
     int chunk_num = 0;
@@ -136,6 +141,10 @@ struct Trainer {
     DevBuf err_flag;  // one float: the ranks agree on an argument error before the first chunk of tg_train
     ~Trainer() {
         for (hipEvent_t ev : ar_ev) if (ev) (void)hipEventDestroy(ev);
+        for (hipEvent_t ev : ev_dz) if (ev) (void)hipEventDestroy(ev);
+        for (hipEvent_t ev : ev_wg) if (ev) (void)hipEventDestroy(ev);
+        if (ev_head) (void)hipEventDestroy(ev_head);
+        if (wg_stream) (void)hipStreamDestroy(wg_stream);
         if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
     }
 };
@@ -260,19 +269,34 @@ int backward_train(TgEngine* e, int B) {
     const float* s = t->convs.back().y.as<float>();
     float* dcur = t->d_a.as<float>();
     float* dtmp = t->d_b.as<float>();
-    float* dz = t->dz.as<float>();
+    float* dzb[2] = {t->dz.as<float>(), t->dz2.as<float>()};
     float* gskip = t->gskip.as<float>();
     const float* zero_bias = t->zero_bias.as<float>();
+    // Round 4: two streams.  A layer's weight gradient (dz ⊗ x) and its data gradient (dz ∗ wᵀ, then the BatchNorm backward of the
+    // layer below) only share their INPUT, so the weight gradients — the policy head's first — run on `wg` while the chain
+    // heads → BatchNorm backward → data gradient → … stays on the engine stream: the HBM-bound passes of the chain (BatchNorm
+    // backward 47 µs, split-K reduction 19 µs per layer) and every launch's ramp and tail pass under the other stream's MFMA kernel
+    // instead of standing alone.  Same kernels on the same operands, every gradient tensor still written by one launch → the
+    // same bits as the single-stream order (TG_TRAIN_ONE_STREAM=1; tests/test_gpu_train.py).  dz alternates between two buffers;
+    // the workspaces are per stream (part_w: weight gradients only, part_d: the chain only).
+    static const bool one_stream = getenv("TG_TRAIN_ONE_STREAM") != nullptr;
+    hipStream_t wg = one_stream ? st : t->wg_stream;
+    const bool two = wg != st;
+    bool wg_pending[2] = {false, false};
+    if (two) {  // everything the forward pass left on the engine stream precedes the first weight gradient
+        TG_HIP(hipEventRecord(t->ev_head, st));
+        TG_HIP(hipStreamWaitEvent(wg, t->ev_head, 0));
+    }
     // ---- heads: dS = d(policy) + d(value) ----
     if (t->conv_head) {
         TrainConv& c = t->pol;
         const float* dl = t->dlogits.as<float>();
-        TG_HIP(launch_wgrad_conv(st, s, F, F, dl, c.OP, c.O, B, N, part_w, G + c.w));
+        TG_HIP(launch_wgrad_conv(wg, s, F, F, dl, c.OP, c.O, B, N, part_w, G + c.w));
         TG_HIP(launch_colsum_acc(st, dl, M, c.OP, c.O, part_d, G + c.b));
         TG_HIP(launch_conv3x3(st, dl, c.wb.as<float>(), zero_bias, nullptr, dcur, M, N, c.OP, round_up(F, 64), F, F, false));
     } else {
         const float* dl = t->dlogits.as<float>();
-        TG_HIP(launch_wgrad_fc(st, s, nsq * F, dl, t->NP, e->policy_size, B, F, nsq, part_w, G + t->fc_w));
+        TG_HIP(launch_wgrad_fc(wg, s, nsq * F, dl, t->NP, e->policy_size, B, F, nsq, part_w, G + t->fc_w));
         TG_HIP(launch_colsum_acc(st, dl, B, t->NP, e->policy_size, part_d, G + t->fc_b));
         TG_HIP(launch_gemm(st, dl, t->NP, t->fc_wb.as<float>(), zero_bias, dcur, B, t->Pp, t->KP, nsq * F, nsq * F));
     }
@@ -287,12 +311,23 @@ int backward_train(TgEngine* e, int B) {
         TrainConv& c = t->convs[l];
         float* mean = stats + (size_t)c.bn * 2 * F;
         float* invstd = mean + F;
+        const int k = l & 1;
+        float* dz = dzb[two ? k : 0];
         const bool block_end = l >= 2 && (l % 2) == 0;  // conv2: its masked gradient also flows into the skip
+        if (two && wg_pending[k]) TG_HIP(hipStreamWaitEvent(st, t->ev_wg[k], 0));  // layer l + 2's weight gradient has read this buffer
         TG_HIP(launch_bn_bwd(st, dcur, c.y.as<float>(), c.z.as<float>(), mean, invstd, P + c.gamma, M, F, part_d, t->mean_g.as<double>(),
                              t->mean_gx.as<double>(), G + c.gamma, G + c.beta, dz, block_end ? gskip : nullptr, G + c.b, sums_in_part));
         sums_in_part = 0;
+        if (two) {
+            TG_HIP(hipEventRecord(t->ev_dz[k], st));
+            TG_HIP(hipStreamWaitEvent(wg, t->ev_dz[k], 0));
+        }
         const float* x = l == 0 ? t->planes.as<float>() : t->convs[l - 1].y.as<float>();
-        TG_HIP(launch_wgrad_conv(st, x, c.in_stride, c.I, dz, F, c.O, B, N, part_w, G + c.w));
+        TG_HIP(launch_wgrad_conv(wg, x, c.in_stride, c.I, dz, F, c.O, B, N, part_w, G + c.w));
+        if (two) {
+            TG_HIP(hipEventRecord(t->ev_wg[k], wg));
+            wg_pending[k] = true;
+        }
         if (l == 0) break;
         // conv1 (odd l) closes the block: its data gradient joins the gradient that went through the skip
         const bool block_begin = (l % 2) == 1;
@@ -304,6 +339,10 @@ int backward_train(TgEngine* e, int B) {
                               fuse_sums ? part_d : nullptr, fuse_sums ? &sums_in_part : nullptr, fuse_sums ? &bnb : nullptr));
         if (block_end) std::swap(dcur, dtmp);
     }
+    // the engine stream continues (loss sums, optimiser step, the next chunk's forward pass) behind the last weight gradients
+    if (two)
+        for (int k = 0; k < 2; k++)
+            if (wg_pending[k]) TG_HIP(hipStreamWaitEvent(st, t->ev_wg[k], 0));
     return TG_OK;
 }
 
@@ -575,6 +614,13 @@ int tg_train_create(TgEngine* e, const TgTrainConfig* cfg) {
     TG_HIP(t->d_a.ensure(M * F * 4));
     TG_HIP(t->d_b.ensure(M * F * 4));
     TG_HIP(t->dz.ensure(M * F * 4));
+    TG_HIP(t->dz2.ensure(M * F * 4));
+    TG_HIP(hipStreamCreateWithFlags(&t->wg_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) {
+        TG_HIP(hipEventCreateWithFlags(&t->ev_dz[k], hipEventDisableTiming));
+        TG_HIP(hipEventCreateWithFlags(&t->ev_wg[k], hipEventDisableTiming));
+    }
+    TG_HIP(hipEventCreateWithFlags(&t->ev_head, hipEventDisableTiming));
     TG_HIP(t->gskip.ensure(M * F * 4));
     TG_HIP(t->stats.ensure((size_t)bn * 2 * F * 4));
     TG_HIP(t->mean_g.ensure((size_t)F * 8));

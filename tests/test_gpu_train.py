@@ -486,6 +486,10 @@ def test_full_batch_training_kernels_return_identical_bits(cfg):
     assert digest(TG_NO_HALO_CONV="1", **plain) == base
     assert digest(TG_NO_HALO_WGRAD="1", **plain) == base
     assert digest(TG_NO_HALO_CONV="1", TG_NO_HALO_WGRAD="1", **plain) == base
+    # round 4: the weight gradients run on a stream of their own beside the data-gradient chain (dz in two alternating buffers) —
+    # the same launches in another interleaving: same bits as the single-stream order, with the default kernels too
+    assert digest(TG_TRAIN_ONE_STREAM="1", **plain) == base
+    assert digest(TG_TRAIN_ONE_STREAM="1") == digest()
 
 
 BN_STATS_DUMP = r"""

@@ -18,6 +18,7 @@ def main():
     import tak_amd
 
     chunks = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    driver = "--driver" in sys.argv  # through tg_train (chunks in flight on two lanes) instead of one tg_train_chunk after the other
     n, blocks, filters, cs = 5, 10, 128, 500
     e = tak_amd.Engine(n, res_blocks=blocks, filters=filters, max_batch=4096)
     e.init_random(seed=0)
@@ -43,13 +44,20 @@ def main():
     for _ in range(2):
         e.train_chunk(st, counts.astype(np.int32), moves, visits, results)
     e.sync()
-    t0 = time.perf_counter()
-    for _ in range(chunks):
-        lp, lz, _ = e.train_chunk(st, counts.astype(np.int32), moves, visits, results)
+    if driver:
+        rep = lambda a: np.concatenate([a] * chunks)
+        big = (rep(st), rep(counts.astype(np.int32)), rep(moves), rep(visits), rep(results))
+        e.train(*big, seed=1)
+        t0 = time.perf_counter()
+        lp, lz, _ = e.train(*big, seed=2)
+    else:
+        t0 = time.perf_counter()
+        for _ in range(chunks):
+            lp, lz, _ = e.train_chunk(st, counts.astype(np.int32), moves, visits, results)
     e.sync()
     dt = (time.perf_counter() - t0) / chunks
     pos = cs * 8
-    print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("TG_")}, "ms_per_chunk": round(dt * 1e3, 3),
+    print(json.dumps({"through": "tg_train" if driver else "tg_train_chunk", "env": {k: v for k, v in os.environ.items() if k.startswith("TG_")}, "ms_per_chunk": round(dt * 1e3, 3),
                       "positions_per_s": round(pos / dt), "frac_of_f32_mfma_peak": round(pos / dt * 3 * 161_689_600 / 157.3e12, 4),
                       "loss_p": lp, "loss_z": lz}), flush=True)
     e.close()

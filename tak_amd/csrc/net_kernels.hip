@@ -710,7 +710,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restri
                                                            const float* __restrict__ bias, const float* __restrict__ res,
                                                            float* __restrict__ out, const uint32_t* __restrict__ slotmap, int B, int PW,
                                                            int PS, int CTW, int out_stride, int cout_valid, int relu,
-                                                           double* __restrict__ stats_part, const ConvBnBwdIn bnb) {
+                                                           double* __restrict__ stats_part, const ConvBnBwdIn bnb, const ConvInFuse fuse) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     f32x4* lds4 = (f32x4*)lds;
     constexpr int n = NB, nsq = NB * NB, RS = NB + 1, LEAD = NB + 2, F4 = 4 * CH, P4 = 4 * CH + 1;
@@ -738,9 +738,15 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restri
         if (o >= n * RS || o % RS == n) lds4[idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
     // … and the squares' rows from global (row-major [row][16·CH]), 8 loads in flight per lane
-    if (!(TG_CONV_PROBE & 2)) {
-        const f32x4* src = (const f32x4*)(in + (size_t)pos0 * nsq * (16 * CH));
-        const int total = rows * F4;
+    auto halo_cell = [&](int idx) {
+        const int r = idx / F4, v = idx - r * F4;
+        const int p = r / nsq, sq = r - p * nsq, y = sq / n, x = sq - y * n;
+        return (LEAD + p * PS + y * RS + x) * P4 + v;
+    };
+    const f32x4* src = (const f32x4*)(in + (size_t)pos0 * nsq * (16 * CH));
+    const int total = rows * F4;
+    if (TG_CONV_PROBE & 2) {
+    } else if (fuse.mode == 0) {
         constexpr int UNR = 8;
         for (int base = 0; base < total; base += NWAVES * 64 * UNR) {
             f32x4 tmp[UNR];
@@ -752,11 +758,92 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restri
 #pragma unroll
             for (int u = 0; u < UNR; u++) {
                 const int idx = base + u * NWAVES * 64 + tid;
-                if (idx < total) {
-                    const int r = idx / F4, v = idx - r * F4;
-                    const int p = r / nsq, sq = r - p * nsq, y = sq / n, x = sq - y * n;
-                    lds4[(LEAD + p * PS + y * RS + x) * P4 + v] = tmp[u];
+                if (idx < total) lds4[halo_cell(idx)] = tmp[u];
+            }
+        }
+    } else {
+        // Round 4 (training step): a BatchNorm pass over the rows being staged — kernels.h, ConvInFuse.  A thread stages the same four
+        // channels in every row (the block size is a multiple of the row's float4 count), so the per-channel constants sit in registers.
+        static_assert((NWAVES * 64) % F4 == 0 && (F4 == 16 || F4 == 32), "fused staging: one channel quad per thread");
+        const int cv = tid % F4;
+        const size_t g0 = (size_t)pos0 * nsq * F4;  // the workgroup's first row in the [rows][F] tensors, in float4
+        const f32x4 mu = ((const f32x4*)fuse.mean)[cv], is = ((const f32x4*)fuse.invstd)[cv], ga = ((const f32x4*)fuse.gamma)[cv];
+        constexpr int UNR = 4;
+        if (fuse.mode == 1) {
+            const f32x4 be = ((const f32x4*)fuse.beta)[cv];
+            const f32x4* sk = fuse.skip ? (const f32x4*)fuse.skip + g0 : src;
+            const bool has_skip = fuse.skip != nullptr;
+            f32x4* yo = (f32x4*)fuse.out_act + g0;
+            for (int base = 0; base < total; base += NWAVES * 64 * UNR) {
+                f32x4 a[UNR], b[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; u++) {
+                    const int idx = base + u * NWAVES * 64 + tid, ic = idx < total ? idx : total - 1;
+                    a[u] = src[ic];
+                    b[u] = sk[ic];
                 }
+#pragma unroll
+                for (int u = 0; u < UNR; u++) {
+                    const int idx = base + u * NWAVES * 64 + tid;
+                    if (idx < total) {
+                        f32x4 v = (a[u] - mu) * is * ga + be;  // k_bn_fwd_apply's expression, term for term
+                        if (has_skip) v += b[u];
+                        v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f);
+                        yo[idx] = v;
+                        lds4[halo_cell(idx)] = v;
+                    }
+                }
+            }
+        } else {
+            double mg[4], mgx[4], gi[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) { mg[t] = fuse.mean_g[4 * cv + t]; mgx[t] = fuse.mean_gx[4 * cv + t]; gi[t] = (double)(ga[t] * is[t]); }
+            const f32x4* yy = (const f32x4*)fuse.y + g0;
+            const f32x4* zz = (const f32x4*)fuse.z + g0;
+            f32x4* dzo = (f32x4*)fuse.out_act + g0;
+            f32x4* gso = fuse.out_gskip ? (f32x4*)fuse.out_gskip + g0 : nullptr;
+            f32x4 s1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int base = 0; base < total; base += NWAVES * 64 * UNR) {
+                f32x4 a[UNR], b[UNR], c[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; u++) {
+                    const int idx = base + u * NWAVES * 64 + tid, ic = idx < total ? idx : total - 1;
+                    a[u] = src[ic];
+                    b[u] = yy[ic];
+                    c[u] = zz[ic];
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; u++) {
+                    const int idx = base + u * NWAVES * 64 + tid;
+                    if (idx < total) {
+                        f32x4 g, o;
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {  // k_bn_bwd_apply_sum's expression, term for term
+                            g[t] = b[u][t] > 0.0f ? a[u][t] : 0.0f;
+                            const float xh = (c[u][t] - mu[t]) * is[t];
+                            const double centred = (double)g[t] - mg[t] - (double)xh * mgx[t];
+                            o[t] = (float)(gi[t] * centred);
+                        }
+                        dzo[idx] = o;
+                        if (gso) gso[idx] = g;
+                        s1 += o;
+                        lds4[halo_cell(idx)] = o;
+                    }
+                }
+            }
+            // dz's column sums: a thread's rows in f32 (as the pass it replaces), then doubles over the lanes of the wave that hold the
+            // same channels; one partial row per wave
+            double d[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                d[t] = (double)s1[t];
+                d[t] += __shfl_xor(d[t], 32);
+                if (F4 == 16) d[t] += __shfl_xor(d[t], 16);
+            }
+            if ((tid & 63) < F4) {
+                double* dst = fuse.colsum_part + ((size_t)(blockIdx.x * NWAVES + (tid >> 6)) * 2) * (4 * F4) + 4 * cv;
+#pragma unroll
+                for (int t = 0; t < 4; t++) dst[t] = d[t];
             }
         }
     }
@@ -1510,7 +1597,7 @@ static const uint32_t* conv_halo_slotmap(int n, int F, int pw, int ps) {
 template <int RTW, int NWAVES, int CH, int NB, int COT, int PSC>
 static hipError_t launch_conv_halo_t(hipStream_t st, const float* in, const float* Wp, const float* bias, const float* res, float* out,
                                      const uint32_t* slotmap, int B, int PW, int PS, int CTW, int out_stride, int cout_valid, bool relu,
-                                     double* stats_part, int* stats_blocks, const ConvBnBwdIn* bnb) {
+                                     double* stats_part, int* stats_blocks, const ConvBnBwdIn* bnb, ConvInFuse* fuse) {
     if (PS != PSC) return hipErrorInvalidValue;
     const size_t lds = (size_t)(NB + 2 + PW * PS + 1) * (16 * CH + 4) * sizeof(float);
     static LdsAttr lds_attr;
@@ -1520,30 +1607,46 @@ static hipError_t launch_conv_halo_t(hipStream_t st, const float* in, const floa
     ConvBnBwdIn bn{nullptr, nullptr, nullptr, nullptr};
     if (bnb && stats_part && out_stride == 16 * COT) bn = *bnb;  // (y and z share the output's row layout)
     else if (bnb) stats_part = nullptr;
+    ConvInFuse fz{};
+    if (fuse) {  // (a second workgroup column would stage — and write — the same rows again)
+        if (grid.y != 1 || fuse->mode < 1 || fuse->mode > 2) return hipErrorInvalidValue;
+        fuse->colsum_rows = fuse->mode == 2 ? (int)grid.x * NWAVES : 0;
+        fz = *fuse;
+    }
     hipLaunchKernelGGL((k_conv_halo<RTW, NWAVES, CH, NB, COT, PSC>), grid, dim3(NWAVES * 64), lds, st, in, Wp, bias, res, out, slotmap, B, PW, PS,
-                       CTW, out_stride, cout_valid, relu ? 1 : 0, stats_part, bn);
+                       CTW, out_stride, cout_valid, relu ? 1 : 0, stats_part, bn, fz);
     if (stats_blocks) *stats_blocks = stats_part ? (int)grid.x * (NWAVES / CTW) : 0;
     return hipGetLastError();
 }
 
+// the shapes launch_conv3x3 hands to k_conv_halo with ONE workgroup column (ConvInFuse: the staging of a second column would repeat the pass)
+bool conv3x3_fuses_input(int M, int n, int Cpad, int CoutP) {
+    static const bool off = getenv("TG_NO_HALO_CONV") != nullptr;
+    int pw, ps;
+    if (off || M / (n * n) < 1024 || !tower_halo_geometry(n, Cpad, &pw, &ps)) return false;
+    return (n == 5 && Cpad == 64 && CoutP == 64) || (n == 5 && Cpad == 128 && CoutP == 128) || (n == 6 && Cpad == 128 && CoutP == 128);
+}
+
 hipError_t launch_conv3x3(hipStream_t st, const float* in, const float* Wp, const float* bias, const float* res, float* out,
                           int M, int n, int Cpad, int CoutP, int out_stride, int cout_valid, bool relu, double* stats_part,
-                          int* stats_blocks, const ConvBnBwdIn* bnb) {
+                          int* stats_blocks, const ConvBnBwdIn* bnb, ConvInFuse* fuse) {
     const int B = M / (n * n);
     if (stats_blocks) *stats_blocks = 0;
+    if (fuse && !conv3x3_fuses_input(M, n, Cpad, CoutP)) return hipErrorInvalidValue;
     {   // F → F (and F → 2F) layers of the BASELINE topologies at full batches: the halo image (k_conv_halo), same bits as k_conv_pos
         static const bool off = getenv("TG_NO_HALO_CONV") != nullptr;
         int pw, ps;
         if (!off && B >= 1024 && tower_halo_geometry(n, Cpad, &pw, &ps)) {
             const uint32_t* map = conv_halo_slotmap(n, Cpad, pw, ps);
             if (map) {
-                if (n == 5 && Cpad == 64 && CoutP == 64) return launch_conv_halo_t<13, 8, 4, 5, 4, 36>(st, in, Wp, bias, res, out, map, B, pw, ps, 4, out_stride, cout_valid, relu, stats_part, stats_blocks, bnb);
-                if (n == 5 && Cpad == 128 && CoutP == 128) return launch_conv_halo_t<13, 8, 8, 5, 8, 37>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu, stats_part, stats_blocks, bnb);
-                if (n == 6 && Cpad == 128 && CoutP == 128) return launch_conv_halo_t<9, 8, 8, 6, 8, 51>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu, stats_part, stats_blocks, bnb);
-                if (n == 6 && Cpad == 128 && CoutP == 256) return launch_conv_halo_t<9, 8, 8, 6, 16, 51>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu, stats_part, stats_blocks, bnb);
+                if (n == 5 && Cpad == 64 && CoutP == 64) return launch_conv_halo_t<13, 8, 4, 5, 4, 36>(st, in, Wp, bias, res, out, map, B, pw, ps, 4, out_stride, cout_valid, relu, stats_part, stats_blocks, bnb, fuse);
+                if (n == 5 && Cpad == 128 && CoutP == 128) return launch_conv_halo_t<13, 8, 8, 5, 8, 37>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu, stats_part, stats_blocks, bnb, fuse);
+                if (n == 6 && Cpad == 128 && CoutP == 128) return launch_conv_halo_t<9, 8, 8, 6, 8, 51>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu, stats_part, stats_blocks, bnb, fuse);
+                if (n == 6 && Cpad == 128 && CoutP == 256) return launch_conv_halo_t<9, 8, 8, 6, 16, 51>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu, stats_part, stats_blocks, bnb, fuse);
             }
         }
     }
+    if (fuse) return hipErrorInvalidValue;  // (only the halo kernel stages through ConvInFuse)
     // whole-positions kernel where the shape divides evenly (the BASELINE configs); generic tiles otherwise
     // small batches take fewer positions per workgroup (shorter critical path, same bits — see launch_tower)
 #define TG_CONV_POS(RTW, NW, PW, CTW) \

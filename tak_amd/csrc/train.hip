@@ -41,7 +41,43 @@ struct TrainConv {
     size_t w = 0, b = 0, gamma = 0, beta = 0;  // offsets into params / grads
     size_t rmean = 0, rvar = 0;                // offsets into the BN buffer
     DevBuf wf, wb, bias_pad;                   // forward fragments, data-gradient fragments, padded bias
-    DevBuf z, y;                               // conv output, activation after BN/ReLU(/skip)
+};
+
+// Everything ONE chunk in flight owns (round 4): its inputs and targets, z / y of every layer, the heads' buffers, the backward
+// pass's scratch and workspaces, its two streams.  tg_train keeps two chunks in flight, one per lane; tg_train_chunk and
+// tg_train_forward use lane 0.
+struct Lane {
+    hipStream_t st = nullptr, wg = nullptr;  // the chain's stream (lane 0: the engine stream) and the weight gradients' stream
+    bool own_st = false;
+    // chunk inputs / targets
+    DevBuf ex_states, ex_nmoves, ex_moves, ex_visits, states_aug, pi, zt, planes;
+    std::vector<DevBuf> z, y;  // per conv layer: conv output, activation after BN / ReLU (/ skip)
+    // heads
+    DevBuf logits, dlogits, logp, eval, dpre, loss_p_rows, loss_z_rows, loss_sums;
+    // backward: dz alternates between two buffers (the weight gradient of layer l reads one while the chain fills the other)
+    DevBuf d_a, d_b, dz, dz2, gskip, stats, mean_g, mean_gx;
+    DevBuf part_d, part_w;  // workspaces: the chain's double partials, the weight gradients' split-K partials
+    DevBuf part_b[2];       // dz's column sums out of the data-gradient convolution's staging (ConvInFuse), alternating like dz
+    // ev_dz[k]: dz buffer k holds this layer's dz (chain → weight gradients); ev_head: the forward pass is complete.
+    // Per layer (index = layer; convs.size() = the heads), recorded behind the kernels of this lane's chunk that UPDATE state shared
+    // by all chunks — the other lane's next chunk waits for them before its own update of the same state, so every running
+    // statistic and every gradient tensor sees the chunks in their order, whatever the interleaving:
+    //   ev_fwd[l]   BatchNorm l's running statistics (forward),   ev_chain[l]  BatchNorm l's γ, β and the conv bias gradient
+    //   (index heads: policy bias, value weight / bias),           ev_wgl[l]    conv l's weight gradient (heads: the policy weights)
+    hipEvent_t ev_dz[2] = {nullptr, nullptr}, ev_head = nullptr;
+    std::vector<hipEvent_t> ev_fwd, ev_chain, ev_wgl;
+    // the chunk in flight (tg_train): issued, not yet collected
+    bool in_flight = false, wait_step = false;
+    int B_flight = 0, did_step = 0;
+    Lane* other = nullptr;  // the lane whose chunk was issued just before this lane's current one (null: this lane itself, or none)
+    ~Lane() {
+        for (hipEvent_t ev : ev_dz) if (ev) (void)hipEventDestroy(ev);
+        if (ev_head) (void)hipEventDestroy(ev_head);
+        for (auto* v : {&ev_fwd, &ev_chain, &ev_wgl})
+            for (hipEvent_t ev : *v) if (ev) (void)hipEventDestroy(ev);
+        if (wg) (void)hipStreamDestroy(wg);
+        if (own_st && st) (void)hipStreamDestroy(st);
+    }
 };
 
 // ---- RCCL through dlopen: self-play users never load it -----------------------------------------
@@ -106,18 +142,12 @@ struct Trainer {
     // value head
     size_t val_w = 0, val_b = 0;
     DevBuf wv;
-    // chunk inputs / targets
-    DevBuf ex_states, ex_nmoves, ex_moves, ex_visits, states_aug, pi, zt, planes;
-    // heads
-    DevBuf logits, dlogits, logp, eval, dpre, loss_p_rows, loss_z_rows, loss_sums;
-    // backward
-    DevBuf d_a, d_b, dz, dz2, gskip, stats, mean_g, mean_gx, zero_bias;
-    DevBuf part_d, part_w;
-    // Round 4: the weight gradients run on a stream of their own beside the data-gradient chain (backward_train): dz alternates
-    // between two buffers, ev_dz[k] = "dz buffer k holds this layer's dz" (engine stream), ev_wg[k] = "the weight gradient has
-    // read dz buffer k" (weight-gradient stream)
-    hipStream_t wg_stream = nullptr;
-    hipEvent_t ev_dz[2] = {nullptr, nullptr}, ev_wg[2] = {nullptr, nullptr}, ev_head = nullptr;
+    // two chunks in flight (TG_TRAIN_ONE_LANE=1: one)
+    Lane lane[2];
+    int n_lanes = 1;
+    Lane* prev = nullptr;          // the lane of the chunk issued last: the next chunk orders its updates behind that one's
+    hipEvent_t ev_step = nullptr;  // parameters updated and re-packed (recorded on the stream that ran the optimiser step)
+    DevBuf zero_bias;
     bool packed = false;
     uint64_t adam_t = 0;
     int chunk_num = 0;
@@ -141,10 +171,7 @@ struct Trainer {
     DevBuf err_flag;  // one float: the ranks agree on an argument error before the first chunk of tg_train
     ~Trainer() {
         for (hipEvent_t ev : ar_ev) if (ev) (void)hipEventDestroy(ev);
-        for (hipEvent_t ev : ev_dz) if (ev) (void)hipEventDestroy(ev);
-        for (hipEvent_t ev : ev_wg) if (ev) (void)hipEventDestroy(ev);
-        if (ev_head) (void)hipEventDestroy(ev_head);
-        if (wg_stream) (void)hipStreamDestroy(wg_stream);
+        if (ev_step) (void)hipEventDestroy(ev_step);
         if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
     }
 };
@@ -180,10 +207,9 @@ void add_bn(Trainer* t, TrainConv& c, const std::string& bn, int F, int bn_index
     c.rvar = add_info(t, bn + ".running_var", F, true);
 }
 
-int pack_params(TgEngine* e) {
+int pack_params(TgEngine* e, hipStream_t st) {
     Trainer* t = e->trainer;
     if (t->packed) return TG_OK;
-    hipStream_t st = e->stream;
     const float* P = t->params.as<float>();
     const int F = e->cfg.filters, nsq = e->g.nsq;
     auto pack_conv = [&](TrainConv& c, bool need_bwd) -> hipError_t {
@@ -203,169 +229,252 @@ int pack_params(TgEngine* e) {
     }
     TG_HIP(launch_pack_value(st, P + t->val_w, F, nsq, t->wv.as<float>()));
     t->packed = true;
+    // the packed copies are shared by the lanes: the others read them behind this event
+    TG_HIP(hipEventRecord(t->ev_step, st));
+    for (int i = 0; i < t->n_lanes; i++) t->lane[i].wait_step = t->lane[i].st != st;
+    return TG_OK;
+}
+
+// A chunk starts on lane w: behind the last optimiser step / re-packing if another stream ran it.  w.other = the lane whose chunk
+// was issued just before this one, when that is not w itself (same streams: already ordered) — see Lane's events.
+int lane_begin(TgEngine* e, Lane& w) {
+    Trainer* t = e->trainer;
+    if (w.wait_step) {
+        TG_HIP(hipStreamWaitEvent(w.st, t->ev_step, 0));
+        w.wait_step = false;
+    }
+    w.other = (t->prev && t->prev != &w) ? t->prev : nullptr;
+    t->prev = &w;
     return TG_OK;
 }
 
 // forward in training mode from the NHWC planes of B positions; fills z/y of every layer, logits, eval
-int forward_train(TgEngine* e, int B, bool with_targets, float* d_logp) {
+int forward_train(TgEngine* e, Lane& w, int B, bool with_targets, float* d_logp) {
     Trainer* t = e->trainer;
-    hipStream_t st = e->stream;
+    hipStream_t st = w.st;
     const int F = e->cfg.filters, nsq = e->g.nsq, N = e->g.n, M = B * nsq;
     float* P = t->params.as<float>();
     float* BN = t->bnbuf.as<float>();
-    float* stats = t->stats.as<float>();
-    int rc = pack_params(e);
+    float* stats = w.stats.as<float>();
+    int rc = lane_begin(e, w);
     if (rc) return rc;
-    const float* in = t->planes.as<float>();
-    for (size_t l = 0; l < t->convs.size(); l++) {
+    Lane* other = w.other;
+    rc = pack_params(e, st);
+    if (rc) return rc;
+    // TG_BN_FOLD=1 (round 4, built and measured, off by default): BatchNorm's apply pass y = relu(γ·x̂ + β (+ skip)) of layer l runs inside
+    // the staging of convolution l + 1 (the halo kernel at full chunks; ConvInFuse mode 1: same expression → same y, written out by the
+    // staging threads for the backward pass) instead of a launch of its own between two convolutions.  Bit-identical
+    // (tests/test_gpu_train.py) and no faster: 18.43 against 18.51 ms per chunk with two chunks in flight, 19.16 against 19.11 ms one
+    // chunk at a time — the workgroup's staging phase, which nothing on its CU overlaps (the halo image fills the LDS), grows by what
+    // the 21 µs pass took.  The last layer keeps its pass in either case (the heads read y).
+    static const bool fold = getenv("TG_BN_FOLD") != nullptr && atoi(getenv("TG_BN_FOLD")) != 0;
+    const size_t L = t->convs.size();
+    auto apply_in_next = [&](size_t l) { return fold && l + 1 < L && conv3x3_fuses_input(M, N, t->convs[l + 1].in_stride, t->convs[l + 1].OP); };
+    for (size_t l = 0; l < L; l++) {
         TrainConv& c = t->convs[l];
+        float* z = w.z[l].as<float>();
+        const float* in = l == 0 ? w.planes.as<float>() : w.y[l - 1].as<float>();
+        ConvInFuse fz{};
+        const bool fused_in = l >= 1 && apply_in_next(l - 1);
+        if (fused_in) {
+            const TrainConv& b = t->convs[l - 1];
+            float* mean_b = stats + (size_t)b.bn * 2 * F;
+            fz.mode = 1;
+            fz.mean = mean_b; fz.invstd = mean_b + F; fz.gamma = P + b.gamma; fz.beta = P + b.beta;
+            fz.skip = (l - 1 >= 2 && ((l - 1) % 2) == 0) ? w.y[l - 3].as<float>() : nullptr;  // conv2 of a block adds the block input
+            fz.out_act = w.y[l - 1].as<float>();
+            in = w.z[l - 1].as<float>();
+        }
         // the halo kernel (F → F layers at full chunks) hands out BatchNorm's column sums with the convolution; elsewhere two
         // reduction passes over z follow
         int stat_blocks = 0;
         static const bool conv_stats = getenv("TG_NO_CONV_STATS") == nullptr;
-        TG_HIP(launch_conv3x3(st, in, c.wf.as<float>(), c.bias_pad.as<float>(), nullptr, c.z.as<float>(), M, N, c.in_stride, c.OP, F, F, false,
-                              (c.OP == F && conv_stats) ? t->part_d.as<double>() : nullptr, &stat_blocks));
+        TG_HIP(launch_conv3x3(st, in, c.wf.as<float>(), c.bias_pad.as<float>(), nullptr, z, M, N, c.in_stride, c.OP, F, F, false,
+                              (c.OP == F && conv_stats) ? w.part_d.as<double>() : nullptr, &stat_blocks, nullptr, fused_in ? &fz : nullptr));
         float* mean = stats + (size_t)c.bn * 2 * F;
         float* invstd = mean + F;
+        if (other) TG_HIP(hipStreamWaitEvent(st, other->ev_fwd[l], 0));  // the running statistics see the chunks in order
         if (stat_blocks > 0)
-            TG_HIP(launch_bn_stats_from_partials(st, t->part_d.as<double>(), stat_blocks, M, F, t->cfg.bn_eps, t->cfg.bn_momentum, mean, invstd,
+            TG_HIP(launch_bn_stats_from_partials(st, w.part_d.as<double>(), stat_blocks, M, F, t->cfg.bn_eps, t->cfg.bn_momentum, mean, invstd,
                                                  BN + c.rmean, BN + c.rvar));
         else
-            TG_HIP(launch_bn_stats(st, c.z.as<float>(), M, F, t->cfg.bn_eps, t->cfg.bn_momentum, t->part_d.as<double>(), mean, invstd,
-                                   BN + c.rmean, BN + c.rvar));
-        // conv2 of block i (l = 2, 4, …) adds the block input: y of layer l-2
-        const float* skip = (l >= 2 && (l % 2) == 0) ? t->convs[l - 2].y.as<float>() : nullptr;
-        TG_HIP(launch_bn_fwd_apply(st, c.z.as<float>(), mean, invstd, P + c.gamma, P + c.beta, skip, c.y.as<float>(), M, F));
-        in = c.y.as<float>();
+            TG_HIP(launch_bn_stats(st, z, M, F, t->cfg.bn_eps, t->cfg.bn_momentum, w.part_d.as<double>(), mean, invstd, BN + c.rmean,
+                                   BN + c.rvar));
+        TG_HIP(hipEventRecord(w.ev_fwd[l], st));
+        if (!apply_in_next(l)) {
+            // conv2 of block i (l = 2, 4, …) adds the block input: y of layer l-2
+            const float* skip = (l >= 2 && (l % 2) == 0) ? w.y[l - 2].as<float>() : nullptr;
+            TG_HIP(launch_bn_fwd_apply(st, z, mean, invstd, P + c.gamma, P + c.beta, skip, w.y[l].as<float>(), M, F));
+        }
     }
-    const float* s = t->convs.back().y.as<float>();
+    const float* s = w.y.back().as<float>();
     const float inv_b = 1.0f / (float)B;
-    const float* pi = with_targets ? t->pi.as<float>() : nullptr;
+    const float* pi = with_targets ? w.pi.as<float>() : nullptr;
     if (t->conv_head) {
         TrainConv& c = t->pol;
-        TG_HIP(launch_conv3x3(st, s, c.wf.as<float>(), c.bias_pad.as<float>(), nullptr, t->logits.as<float>(), M, N, F, c.OP, c.OP, c.O, false));
-        TG_HIP(launch_policy_loss(st, t->logits.as<float>(), nsq * c.OP, true, nsq, c.OP, e->policy_size, B, pi, inv_b,
-                                  t->dlogits.as<float>(), d_logp, t->loss_p_rows.as<float>()));
+        TG_HIP(launch_conv3x3(st, s, c.wf.as<float>(), c.bias_pad.as<float>(), nullptr, w.logits.as<float>(), M, N, F, c.OP, c.OP, c.O, false));
+        TG_HIP(launch_policy_loss(st, w.logits.as<float>(), nsq * c.OP, true, nsq, c.OP, e->policy_size, B, pi, inv_b,
+                                  w.dlogits.as<float>(), d_logp, w.loss_p_rows.as<float>()));
     } else {
-        TG_HIP(launch_gemm(st, s, nsq * F, t->fc_wf.as<float>(), t->fc_bias.as<float>(), t->logits.as<float>(), B, nsq * F, t->NP, t->NP,
+        TG_HIP(launch_gemm(st, s, nsq * F, t->fc_wf.as<float>(), t->fc_bias.as<float>(), w.logits.as<float>(), B, nsq * F, t->NP, t->NP,
                            e->policy_size));
-        TG_HIP(launch_policy_loss(st, t->logits.as<float>(), t->NP, false, nsq, 0, e->policy_size, B, pi, inv_b, t->dlogits.as<float>(),
-                                  d_logp, t->loss_p_rows.as<float>()));
+        TG_HIP(launch_policy_loss(st, w.logits.as<float>(), t->NP, false, nsq, 0, e->policy_size, B, pi, inv_b, w.dlogits.as<float>(),
+                                  d_logp, w.loss_p_rows.as<float>()));
     }
-    TG_HIP(launch_value_train(st, s, t->wv.as<float>(), P + t->val_b, B, nsq * F, with_targets ? t->zt.as<float>() : nullptr, inv_b,
-                              t->eval.as<float>(), t->dpre.as<float>(), t->loss_z_rows.as<float>()));
+    TG_HIP(launch_value_train(st, s, t->wv.as<float>(), P + t->val_b, B, nsq * F, with_targets ? w.zt.as<float>() : nullptr, inv_b,
+                              w.eval.as<float>(), w.dpre.as<float>(), w.loss_z_rows.as<float>()));
     return TG_OK;
 }
 
-int backward_train(TgEngine* e, int B) {
+// (behind forward_train on the same lane)
+int backward_train(TgEngine* e, Lane& w, int B) {
     Trainer* t = e->trainer;
-    hipStream_t st = e->stream;
+    Lane* other = w.other;
+    hipStream_t st = w.st;
     const int F = e->cfg.filters, nsq = e->g.nsq, N = e->g.n, M = B * nsq;
+    const int L = (int)t->convs.size();
     float* P = t->params.as<float>();
     float* G = t->grads.as<float>();
-    float* stats = t->stats.as<float>();
-    double* part_d = t->part_d.as<double>();
-    float* part_w = t->part_w.as<float>();
-    const float* s = t->convs.back().y.as<float>();
-    float* dcur = t->d_a.as<float>();
-    float* dtmp = t->d_b.as<float>();
-    float* dzb[2] = {t->dz.as<float>(), t->dz2.as<float>()};
-    float* gskip = t->gskip.as<float>();
+    float* stats = w.stats.as<float>();
+    double* part_d = w.part_d.as<double>();
+    float* part_w = w.part_w.as<float>();
+    const float* s = w.y.back().as<float>();
+    float* dcur = w.d_a.as<float>();
+    float* dtmp = w.d_b.as<float>();
+    float* dzb[2] = {w.dz.as<float>(), w.dz2.as<float>()};
+    float* gskip = w.gskip.as<float>();
     const float* zero_bias = t->zero_bias.as<float>();
     // Round 4: two streams.  A layer's weight gradient (dz ⊗ x) and its data gradient (dz ∗ wᵀ, then the BatchNorm backward of the
     // layer below) only share their INPUT, so the weight gradients — the policy head's first — run on `wg` while the chain
-    // heads → BatchNorm backward → data gradient → … stays on the engine stream: the HBM-bound passes of the chain (BatchNorm
+    // heads → BatchNorm backward → data gradient → … stays on the lane's stream: the HBM-bound passes of the chain (BatchNorm
     // backward 47 µs, split-K reduction 19 µs per layer) and every launch's ramp and tail pass under the other stream's MFMA kernel
     // instead of standing alone.  Same kernels on the same operands, every gradient tensor still written by one launch → the
     // same bits as the single-stream order (TG_TRAIN_ONE_STREAM=1; tests/test_gpu_train.py).  dz alternates between two buffers;
     // the workspaces are per stream (part_w: weight gradients only, part_d: the chain only).
     static const bool one_stream = getenv("TG_TRAIN_ONE_STREAM") != nullptr;
-    hipStream_t wg = one_stream ? st : t->wg_stream;
+    hipStream_t wg = one_stream ? st : w.wg;
     const bool two = wg != st;
-    bool wg_pending[2] = {false, false};
-    if (two) {  // everything the forward pass left on the engine stream precedes the first weight gradient
-        TG_HIP(hipEventRecord(t->ev_head, st));
-        TG_HIP(hipStreamWaitEvent(wg, t->ev_head, 0));
+    if (two) {  // everything the forward pass left on the lane's stream precedes the first weight gradient
+        TG_HIP(hipEventRecord(w.ev_head, st));
+        TG_HIP(hipStreamWaitEvent(wg, w.ev_head, 0));
     }
     // ---- heads: dS = d(policy) + d(value) ----
+    if (other) {
+        TG_HIP(hipStreamWaitEvent(wg, other->ev_wgl[L], 0));
+        TG_HIP(hipStreamWaitEvent(st, other->ev_chain[L], 0));
+    }
     if (t->conv_head) {
         TrainConv& c = t->pol;
-        const float* dl = t->dlogits.as<float>();
+        const float* dl = w.dlogits.as<float>();
         TG_HIP(launch_wgrad_conv(wg, s, F, F, dl, c.OP, c.O, B, N, part_w, G + c.w));
         TG_HIP(launch_colsum_acc(st, dl, M, c.OP, c.O, part_d, G + c.b));
         TG_HIP(launch_conv3x3(st, dl, c.wb.as<float>(), zero_bias, nullptr, dcur, M, N, c.OP, round_up(F, 64), F, F, false));
     } else {
-        const float* dl = t->dlogits.as<float>();
+        const float* dl = w.dlogits.as<float>();
         TG_HIP(launch_wgrad_fc(wg, s, nsq * F, dl, t->NP, e->policy_size, B, F, nsq, part_w, G + t->fc_w));
         TG_HIP(launch_colsum_acc(st, dl, B, t->NP, e->policy_size, part_d, G + t->fc_b));
         TG_HIP(launch_gemm(st, dl, t->NP, t->fc_wb.as<float>(), zero_bias, dcur, B, t->Pp, t->KP, nsq * F, nsq * F));
     }
-    TG_HIP(launch_value_bwd(st, s, t->dpre.as<float>(), t->wv.as<float>(), B, F, nsq, dcur, part_d, G + t->val_w, G + t->val_b));
+    TG_HIP(hipEventRecord(w.ev_wgl[L], wg));
+    TG_HIP(launch_value_bwd(st, s, w.dpre.as<float>(), t->wv.as<float>(), B, F, nsq, dcur, part_d, G + t->val_w, G + t->val_b));
+    TG_HIP(hipEventRecord(w.ev_chain[L], st));
     // ---- tower, last layer first ----
     // Round 4: the data-gradient convolution of layer l produces dy of layer l − 1 — its epilogue also takes that layer's
     // BatchNorm-backward sums Σg, Σg·x̂ while dy is in registers (halo kernel, full chunks), and the pass over dy, y and z that took
     // them (k_col_reduce, 27 µs per layer) is skipped; TG_NO_BWD_SUMS_FUSION restores it (other summation order: other low bits)
     static const bool fuse_sums = getenv("TG_NO_BWD_SUMS_FUSION") == nullptr;
+    // TG_BN_FOLD=1 (see forward_train; off by default): BatchNorm's backward apply pass dz = γ·invstd·(g − mean(g) − x̂·mean(g·x̂)) of layer l
+    // runs inside the staging of that layer's data-gradient convolution (ConvInFuse mode 2: same expression → same dz, written out for
+    // the weight gradient, with g for the skip path and dz's column sums for the conv bias gradient); the weight gradient of layer l
+    // then follows the convolution that wrote its dz, beside the convolution of layer l − 1.  Layer 0 (no data gradient) keeps the pass.
+    static const bool fold = getenv("TG_BN_FOLD") != nullptr && atoi(getenv("TG_BN_FOLD")) != 0;
     int sums_in_part = 0;
-    for (int l = (int)t->convs.size() - 1; l >= 0; l--) {
+    for (int l = L - 1; l >= 0; l--) {
         TrainConv& c = t->convs[l];
         float* mean = stats + (size_t)c.bn * 2 * F;
         float* invstd = mean + F;
-        const int k = l & 1;
-        float* dz = dzb[two ? k : 0];
+        const int k = two ? (l & 1) : 0;
+        float* dz = dzb[k];
         const bool block_end = l >= 2 && (l % 2) == 0;  // conv2: its masked gradient also flows into the skip
-        if (two && wg_pending[k]) TG_HIP(hipStreamWaitEvent(st, t->ev_wg[k], 0));  // layer l + 2's weight gradient has read this buffer
-        TG_HIP(launch_bn_bwd(st, dcur, c.y.as<float>(), c.z.as<float>(), mean, invstd, P + c.gamma, M, F, part_d, t->mean_g.as<double>(),
-                             t->mean_gx.as<double>(), G + c.gamma, G + c.beta, dz, block_end ? gskip : nullptr, G + c.b, sums_in_part));
-        sums_in_part = 0;
-        if (two) {
-            TG_HIP(hipEventRecord(t->ev_dz[k], st));
-            TG_HIP(hipStreamWaitEvent(wg, t->ev_dz[k], 0));
+        const bool block_begin = (l % 2) == 1;          // conv1 closes the block: its data gradient joins the gradient that went through the skip
+        const bool in_staging = fold && l >= 1 && conv3x3_fuses_input(M, N, F, round_up(c.I, 64));
+        if (two && l + 2 < L) TG_HIP(hipStreamWaitEvent(st, w.ev_wgl[l + 2], 0));  // layer l + 2's weight gradient has read this dz buffer
+        if (other) TG_HIP(hipStreamWaitEvent(st, other->ev_chain[l], 0));
+        const float* x = l == 0 ? w.planes.as<float>() : w.y[l - 1].as<float>();
+        if (!in_staging) {
+            TG_HIP(launch_bn_bwd(st, dcur, w.y[l].as<float>(), w.z[l].as<float>(), mean, invstd, P + c.gamma, M, F, part_d, w.mean_g.as<double>(),
+                                 w.mean_gx.as<double>(), G + c.gamma, G + c.beta, dz, block_end ? gskip : nullptr, G + c.b, sums_in_part));
+            sums_in_part = 0;
+            TG_HIP(hipEventRecord(w.ev_chain[l], st));
+            if (two) {
+                TG_HIP(hipEventRecord(w.ev_dz[k], st));
+                TG_HIP(hipStreamWaitEvent(wg, w.ev_dz[k], 0));
+            }
+            if (other) TG_HIP(hipStreamWaitEvent(wg, other->ev_wgl[l], 0));
+            TG_HIP(launch_wgrad_conv(wg, x, c.in_stride, c.I, dz, F, c.O, B, N, part_w, G + c.w));
+            TG_HIP(hipEventRecord(w.ev_wgl[l], wg));
+            if (l == 0) break;
+        } else {
+            TG_HIP(launch_bn_bwd_sums(st, dcur, w.y[l].as<float>(), w.z[l].as<float>(), mean, invstd, M, F, part_d, w.mean_g.as<double>(),
+                                      w.mean_gx.as<double>(), G + c.gamma, G + c.beta, sums_in_part));
+            sums_in_part = 0;
+            TG_HIP(hipEventRecord(w.ev_chain[l], st));
         }
-        const float* x = l == 0 ? t->planes.as<float>() : t->convs[l - 1].y.as<float>();
-        TG_HIP(launch_wgrad_conv(wg, x, c.in_stride, c.I, dz, F, c.O, B, N, part_w, G + c.w));
-        if (two) {
-            TG_HIP(hipEventRecord(t->ev_wg[k], wg));
-            wg_pending[k] = true;
-        }
-        if (l == 0) break;
-        // conv1 (odd l) closes the block: its data gradient joins the gradient that went through the skip
-        const bool block_begin = (l % 2) == 1;
         float* dst = block_end ? dtmp : dcur;
         const TrainConv& below = t->convs[l - 1];
         const float* mean_b = stats + (size_t)below.bn * 2 * F;
-        const ConvBnBwdIn bnb{below.y.as<float>(), below.z.as<float>(), mean_b, mean_b + F};
-        TG_HIP(launch_conv3x3(st, dz, c.wb.as<float>(), zero_bias, block_begin ? gskip : nullptr, dst, M, N, F, round_up(c.I, 64), F, F, false,
-                              fuse_sums ? part_d : nullptr, fuse_sums ? &sums_in_part : nullptr, fuse_sums ? &bnb : nullptr));
+        const ConvBnBwdIn bnb{w.y[l - 1].as<float>(), w.z[l - 1].as<float>(), mean_b, mean_b + F};
+        ConvInFuse fz{};
+        if (in_staging) {
+            fz.mode = 2;
+            fz.mean = mean; fz.invstd = invstd; fz.gamma = P + c.gamma;
+            fz.y = w.y[l].as<float>(); fz.z = w.z[l].as<float>();
+            fz.mean_g = w.mean_g.as<double>(); fz.mean_gx = w.mean_gx.as<double>();
+            fz.out_act = dz; fz.out_gskip = block_end ? gskip : nullptr;
+            fz.colsum_part = w.part_b[k].as<double>();
+        }
+        // (in place where dst = dcur: a workgroup reads the rows of its own positions and writes them after its last read)
+        TG_HIP(launch_conv3x3(st, in_staging ? dcur : dz, c.wb.as<float>(), zero_bias, block_begin ? gskip : nullptr, dst, M, N, F,
+                              round_up(c.I, 64), F, F, false, fuse_sums ? part_d : nullptr, fuse_sums ? &sums_in_part : nullptr,
+                              fuse_sums ? &bnb : nullptr, in_staging ? &fz : nullptr));
+        if (in_staging) {  // the weight gradient (and the conv bias gradient, from the staging's column sums) behind the convolution
+            if (two) {
+                TG_HIP(hipEventRecord(w.ev_dz[k], st));
+                TG_HIP(hipStreamWaitEvent(wg, w.ev_dz[k], 0));
+            }
+            if (other) TG_HIP(hipStreamWaitEvent(wg, other->ev_wgl[l], 0));
+            TG_HIP(launch_colsum_finalize(wg, w.part_b[k].as<double>(), fz.colsum_rows, F, F, G + c.b));
+            TG_HIP(launch_wgrad_conv(wg, x, c.in_stride, c.I, dz, F, c.O, B, N, part_w, G + c.w));
+            TG_HIP(hipEventRecord(w.ev_wgl[l], wg));
+        }
         if (block_end) std::swap(dcur, dtmp);
     }
-    // the engine stream continues (loss sums, optimiser step, the next chunk's forward pass) behind the last weight gradients
-    if (two)
-        for (int k = 0; k < 2; k++)
-            if (wg_pending[k]) TG_HIP(hipStreamWaitEvent(st, t->ev_wg[k], 0));
+    // the lane's stream continues (loss sums, optimiser step, this lane's next chunk) behind its last weight gradient
+    if (two) TG_HIP(hipStreamWaitEvent(st, w.ev_wgl[0], 0));
     return TG_OK;
 }
 
-// Sum a device buffer over the ranks, in place, ordered on the engine stream: the caller's hook if one is set, else RCCL.
+// Sum a device buffer over the ranks, in place, ordered on `st`: the caller's hook if one is set, else RCCL.
 // Returns false through *reduced when the trainer is single-rank (nothing to do).
-static int all_reduce_sum(TgEngine* e, float* d_buf, size_t count, const char* what, bool* reduced) {
+static int all_reduce_sum(TgEngine* e, hipStream_t st, float* d_buf, size_t count, const char* what, bool* reduced) {
     Trainer* t = e->trainer;
     *reduced = false;
     if (t->hook) {
-        int rc = t->hook(t->hook_ctx, d_buf, count, (void*)e->stream);
+        int rc = t->hook(t->hook_ctx, d_buf, count, (void*)st);
         if (rc) return fail(TG_ERR_STATE, std::string("all-reduce hook failed (") + what + "), code " + std::to_string(rc));
         *reduced = true;
     } else if (t->comm) {
-        int rc = g_rccl.AllReduce(d_buf, d_buf, count, NCCL_FLOAT32, NCCL_SUM, t->comm, e->stream);
+        int rc = g_rccl.AllReduce(d_buf, d_buf, count, NCCL_FLOAT32, NCCL_SUM, t->comm, st);
         if (rc) return fail(TG_ERR_HIP, std::string("ncclAllReduce (") + what + "): " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
         *reduced = true;
     }
     return TG_OK;
 }
 
-int optimizer_step(TgEngine* e) {
+// on `st`, behind every chunk of the step: the chunk that completes a step runs it on its lane's stream, which has waited for its
+// own weight gradients, and every update of that chunk stands behind the same update of the chunk before (Lane's events)
+int optimizer_step(TgEngine* e, hipStream_t st) {
     Trainer* t = e->trainer;
-    hipStream_t st = e->stream;
     float gscale = 1.0f;
     {
         bool reduced;
@@ -378,7 +487,7 @@ int optimizer_step(TgEngine* e) {
             }
             TG_HIP(hipEventRecord(t->ar_ev[0], st));
         }
-        int rc = all_reduce_sum(e, t->grads.as<float>(), t->n_params, "gradients", &reduced);
+        int rc = all_reduce_sum(e, st, t->grads.as<float>(), t->n_params, "gradients", &reduced);
         if (timed) t->ar_pending = hipEventRecord(t->ar_ev[1], st) == hipSuccess;
         if (rc) return rc;
         if (reduced) gscale = 1.0f / (float)t->world;
@@ -391,7 +500,7 @@ int optimizer_step(TgEngine* e) {
                        t->cfg.learning_rate, t->cfg.beta1, t->cfg.beta2, t->cfg.eps, t->cfg.weight_decay, bc1, bc2s, gscale));
     TG_HIP(hipMemsetAsync(t->grads.p, 0, t->n_params * 4, st));
     t->packed = false;
-    return TG_OK;
+    return pack_params(e, st);  // here, not in the next forward pass: the lanes share the packed copies (ev_step)
 }
 
 int need_trainer(TgEngine* e) {
@@ -402,37 +511,55 @@ int need_trainer(TgEngine* e) {
     return TG_OK;
 }
 
-// one chunk already resident on the device: ex_* buffers hold n examples, zt the 8n value targets
-int train_chunk_dev(TgEngine* e, int n, float* loss_p, float* loss_z, int32_t* stepped) {
+// One chunk already resident on the device (the lane's ex_* buffers hold n examples, zt the 8n value targets): everything up
+// to and including an optimiser step that falls due is ISSUED on the lane's streams; chunk_collect waits for it and reads the losses.
+int chunk_issue(TgEngine* e, Lane& w, int n) {
     Trainer* t = e->trainer;
-    hipStream_t st = e->stream;
+    hipStream_t st = w.st;
     const int B = n * 8;
-    TG_HIP(hipMemsetAsync(t->pi.p, 0, (size_t)B * e->policy_size * 4, st));
-    launch_augment(st, t->ex_states.as<uint8_t>(), t->ex_nmoves.as<int32_t>(), t->ex_moves.as<uint16_t>(), t->ex_visits.as<uint32_t>(), n,
-                   e->g.n, e->policy_size, e->legacy5, e->lut5.as<int16_t>(), t->states_aug.as<uint8_t>(), t->pi.as<float>());
+    TG_HIP(hipMemsetAsync(w.pi.p, 0, (size_t)B * e->policy_size * 4, st));
+    launch_augment(st, w.ex_states.as<uint8_t>(), w.ex_nmoves.as<int32_t>(), w.ex_moves.as<uint16_t>(), w.ex_visits.as<uint32_t>(), n,
+                   e->g.n, e->policy_size, e->legacy5, e->lut5.as<int16_t>(), w.states_aug.as<uint8_t>(), w.pi.as<float>());
     TG_HIP(hipGetLastError());
-    launch_encode_nhwc(st, t->states_aug.as<uint8_t>(), B, e->g.n, t->planes.as<float>(), e->cin_pad);
+    launch_encode_nhwc(st, w.states_aug.as<uint8_t>(), B, e->g.n, w.planes.as<float>(), e->cin_pad);
     TG_HIP(hipGetLastError());
-    int rc = forward_train(e, B, true, nullptr);
+    int rc = forward_train(e, w, B, true, nullptr);
     if (rc) return rc;
-    rc = backward_train(e, B);
+    rc = backward_train(e, w, B);
     if (rc) return rc;
-    TG_HIP(launch_sum_rows(st, t->loss_p_rows.as<float>(), B, t->loss_sums.as<double>()));
-    TG_HIP(launch_sum_rows(st, t->loss_z_rows.as<float>(), B, t->loss_sums.as<double>() + 1));
-    int did = 0;
+    TG_HIP(launch_sum_rows(st, w.loss_p_rows.as<float>(), B, w.loss_sums.as<double>()));
+    TG_HIP(launch_sum_rows(st, w.loss_z_rows.as<float>(), B, w.loss_sums.as<double>() + 1));
+    w.did_step = 0;
+    w.B_flight = B;
+    w.in_flight = true;
     t->chunk_num++;
     if (t->chunk_num % t->cfg.chunks_in_step == 0) {  // network.rs:92
-        rc = optimizer_step(e);
+        rc = optimizer_step(e, st);
         if (rc) return rc;
-        did = 1;
+        w.did_step = 1;
     }
-    double sums[2];
-    TG_HIP(hipMemcpyAsync(sums, t->loss_sums.p, 16, hipMemcpyDeviceToHost, st));
-    TG_HIP(hipStreamSynchronize(st));
-    if (loss_p) *loss_p = (float)(sums[0] / B);
-    if (loss_z) *loss_z = (float)(sums[1] / B);
-    if (stepped) *stepped = did;
     return TG_OK;
+}
+int chunk_collect(TgEngine* e, Lane& w, float* loss_p, float* loss_z, int32_t* stepped) {
+    (void)e;
+    if (!w.in_flight) return fail(TG_ERR_STATE, "internal: no chunk in flight on this lane");
+    w.in_flight = false;
+    double sums[2];
+    TG_HIP(hipMemcpyAsync(sums, w.loss_sums.p, 16, hipMemcpyDeviceToHost, w.st));
+    TG_HIP(hipStreamSynchronize(w.st));  // the lane's stream stands behind its weight-gradient stream (backward_train)
+    if (loss_p) *loss_p = (float)(sums[0] / w.B_flight);
+    if (loss_z) *loss_z = (float)(sums[1] / w.B_flight);
+    if (stepped) *stepped = w.did_step;
+    return TG_OK;
+}
+// after an error in the middle of a pipeline: nothing of this trainer is left running
+void lanes_drain(Trainer* t) {
+    for (int i = 0; i < t->n_lanes; i++) {
+        Lane& w = t->lane[i];
+        if (w.wg) (void)hipStreamSynchronize(w.wg);
+        if (w.st) (void)hipStreamSynchronize(w.st);
+        w.in_flight = false;
+    }
 }
 
 // The complete host-side check of ONE example (index s of the caller's arrays), used by tg_train_chunk's upload and by
@@ -449,10 +576,9 @@ int validate_example(const TgEngine* e, int s, const uint8_t* states, const int3
 }
 
 // validated = the caller (tg_train) has already checked every example
-int upload_chunk(TgEngine* e, int n, const uint8_t* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
+int upload_chunk(TgEngine* e, Lane& w, int n, const uint8_t* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
                  const float* results, const int* order, bool validated = false) {
-    Trainer* t = e->trainer;
-    hipStream_t st = e->stream;
+    hipStream_t st = w.st;
     const size_t sb = e->g.bytes;
     std::vector<float> z8((size_t)n * 8);
     for (int i = 0; i < n; i++) {
@@ -482,11 +608,11 @@ int upload_chunk(TgEngine* e, int n, const uint8_t* states, const int32_t* n_mov
         }
         states = g_states.data(); n_moves = g_nm.data(); moves = g_moves.data(); visits = g_visits.data();
     }
-    TG_HIP(hipMemcpyAsync(t->ex_states.p, states, (size_t)n * sb, hipMemcpyHostToDevice, st));
-    TG_HIP(hipMemcpyAsync(t->ex_nmoves.p, n_moves, (size_t)n * 4, hipMemcpyHostToDevice, st));
-    TG_HIP(hipMemcpyAsync(t->ex_moves.p, moves, (size_t)n * TG_MAX_MOVES * 2, hipMemcpyHostToDevice, st));
-    TG_HIP(hipMemcpyAsync(t->ex_visits.p, visits, (size_t)n * TG_MAX_MOVES * 4, hipMemcpyHostToDevice, st));
-    TG_HIP(hipMemcpyAsync(t->zt.p, z8.data(), z8.size() * 4, hipMemcpyHostToDevice, st));
+    TG_HIP(hipMemcpyAsync(w.ex_states.p, states, (size_t)n * sb, hipMemcpyHostToDevice, st));
+    TG_HIP(hipMemcpyAsync(w.ex_nmoves.p, n_moves, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    TG_HIP(hipMemcpyAsync(w.ex_moves.p, moves, (size_t)n * TG_MAX_MOVES * 2, hipMemcpyHostToDevice, st));
+    TG_HIP(hipMemcpyAsync(w.ex_visits.p, visits, (size_t)n * TG_MAX_MOVES * 4, hipMemcpyHostToDevice, st));
+    TG_HIP(hipMemcpyAsync(w.zt.p, z8.data(), z8.size() * 4, hipMemcpyHostToDevice, st));
     TG_HIP(hipStreamSynchronize(st));  // the staging vectors (and the caller's buffers) may go away
     return TG_OK;
 }
@@ -560,8 +686,6 @@ int tg_train_create(TgEngine* e, const TgTrainConfig* cfg) {
         TG_HIP(c.wf.ensure((size_t)9 * c.in_stride * c.OP * 4));
         TG_HIP(c.bias_pad.ensure((size_t)c.OP * 4));
         if (l > 0) TG_HIP(c.wb.ensure((size_t)9 * c.out_stride * round_up(c.I, 64) * 4));
-        TG_HIP(c.z.ensure(M * F * 4));
-        TG_HIP(c.y.ensure(M * F * 4));
         part_w_floats = std::max(part_w_floats, wgrad_conv_workspace((int)B, N, c.I, c.O));
     }
     size_t logit_row;
@@ -592,50 +716,72 @@ int tg_train_create(TgEngine* e, const TgTrainConfig* cfg) {
     TG_HIP(t->wv.ensure((size_t)F * nsq * 4));
     TG_HIP(t->zero_bias.ensure((size_t)max_op * 4));
     TG_HIP(hipMemset(t->zero_bias.p, 0, (size_t)max_op * 4));
-    TG_HIP(t->ex_states.ensure((size_t)cfg->chunk_size * e->g.bytes));
-    TG_HIP(t->ex_nmoves.ensure((size_t)cfg->chunk_size * 4));
-    TG_HIP(t->ex_moves.ensure((size_t)cfg->chunk_size * TG_MAX_MOVES * 2));
-    TG_HIP(t->ex_visits.ensure((size_t)cfg->chunk_size * TG_MAX_MOVES * 4));
-    TG_HIP(hipMemset(t->ex_moves.p, 0, (size_t)cfg->chunk_size * TG_MAX_MOVES * 2));
-    TG_HIP(hipMemset(t->ex_visits.p, 0, (size_t)cfg->chunk_size * TG_MAX_MOVES * 4));
-    TG_HIP(t->states_aug.ensure(B * e->g.bytes));
-    TG_HIP(t->pi.ensure(B * P * 4));
-    TG_HIP(t->zt.ensure(B * 4));
-    TG_HIP(t->planes.ensure(M * e->cin_pad * 4));
-    TG_HIP(t->logits.ensure(B * logit_row * 4));
-    TG_HIP(t->dlogits.ensure(B * logit_row * 4));
-    TG_HIP(hipMemset(t->dlogits.p, 0, B * logit_row * 4));  // padding columns stay zero
-    TG_HIP(t->logp.ensure(B * P * 4));
-    TG_HIP(t->eval.ensure(B * 4));
-    TG_HIP(t->dpre.ensure(B * 4));
-    TG_HIP(t->loss_p_rows.ensure(B * 4));
-    TG_HIP(t->loss_z_rows.ensure(B * 4));
-    TG_HIP(t->loss_sums.ensure(16));
-    TG_HIP(t->d_a.ensure(M * F * 4));
-    TG_HIP(t->d_b.ensure(M * F * 4));
-    TG_HIP(t->dz.ensure(M * F * 4));
-    TG_HIP(t->dz2.ensure(M * F * 4));
-    TG_HIP(hipStreamCreateWithFlags(&t->wg_stream, hipStreamNonBlocking));
-    for (int k = 0; k < 2; k++) {
-        TG_HIP(hipEventCreateWithFlags(&t->ev_dz[k], hipEventDisableTiming));
-        TG_HIP(hipEventCreateWithFlags(&t->ev_wg[k], hipEventDisableTiming));
-    }
-    TG_HIP(hipEventCreateWithFlags(&t->ev_head, hipEventDisableTiming));
-    TG_HIP(t->gskip.ensure(M * F * 4));
-    TG_HIP(t->stats.ensure((size_t)bn * 2 * F * 4));
-    TG_HIP(t->mean_g.ensure((size_t)F * 8));
-    TG_HIP(t->mean_gx.ensure((size_t)F * 8));
-    // double partials: column reductions over up to max(F, logit columns) channels, value weight gradient
-    {
+    // ---- the lanes: what a chunk in flight owns ----
+    size_t part_d_bytes;
+    {   // double partials: column reductions over up to max(F, logit columns) channels, value weight gradient
         int rpb;
         size_t a = (size_t)col_reduce_blocks((int)M, F, &rpb) * 2 * F;
         if (t->conv_head) a = std::max(a, (size_t)col_reduce_blocks((int)M, t->pol.OP, &rpb) * 2 * t->pol.OP);
         else a = std::max(a, (size_t)32 * 2 * t->NP);
         a = std::max(a, (size_t)(2 * ((size_t)B + 16)) * 2 * F);  // the conv kernels' partial rows: ≤ 2 per position
         size_t b = (size_t)32 * ((size_t)F * nsq + 1);
-        TG_HIP(t->part_d.ensure(std::max(a, b) * 8));
+        part_d_bytes = std::max(a, b) * 8;
     }
-    TG_HIP(t->part_w.ensure(part_w_floats * 4));
+    TG_HIP(hipEventCreateWithFlags(&t->ev_step, hipEventDisableTiming));
+    t->n_lanes = getenv("TG_TRAIN_ONE_LANE") ? 1 : 2;
+    const size_t L = t->convs.size();
+    for (int li = 0; li < t->n_lanes; li++) {
+        Lane& w = t->lane[li];
+        if (li == 0) w.st = e->stream;
+        else {
+            TG_HIP(hipStreamCreateWithFlags(&w.st, hipStreamNonBlocking));
+            w.own_st = true;
+        }
+        // (stream priorities — the weight gradients below the chains, one lane below the other — were measured: 1 – 12 % slower)
+        TG_HIP(hipStreamCreateWithFlags(&w.wg, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) TG_HIP(hipEventCreateWithFlags(&w.ev_dz[k], hipEventDisableTiming));
+        TG_HIP(hipEventCreateWithFlags(&w.ev_head, hipEventDisableTiming));
+        for (auto* v : {&w.ev_fwd, &w.ev_chain, &w.ev_wgl}) {
+            v->assign(L + 1, nullptr);
+            for (hipEvent_t& ev : *v) TG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        }
+        w.z.resize(L);
+        w.y.resize(L);
+        for (size_t l = 0; l < L; l++) {
+            TG_HIP(w.z[l].ensure(M * F * 4));
+            TG_HIP(w.y[l].ensure(M * F * 4));
+        }
+        TG_HIP(w.ex_states.ensure((size_t)cfg->chunk_size * e->g.bytes));
+        TG_HIP(w.ex_nmoves.ensure((size_t)cfg->chunk_size * 4));
+        TG_HIP(w.ex_moves.ensure((size_t)cfg->chunk_size * TG_MAX_MOVES * 2));
+        TG_HIP(w.ex_visits.ensure((size_t)cfg->chunk_size * TG_MAX_MOVES * 4));
+        TG_HIP(hipMemset(w.ex_moves.p, 0, (size_t)cfg->chunk_size * TG_MAX_MOVES * 2));
+        TG_HIP(hipMemset(w.ex_visits.p, 0, (size_t)cfg->chunk_size * TG_MAX_MOVES * 4));
+        TG_HIP(w.states_aug.ensure(B * e->g.bytes));
+        TG_HIP(w.pi.ensure(B * P * 4));
+        TG_HIP(w.zt.ensure(B * 4));
+        TG_HIP(w.planes.ensure(M * e->cin_pad * 4));
+        TG_HIP(w.logits.ensure(B * logit_row * 4));
+        TG_HIP(w.dlogits.ensure(B * logit_row * 4));
+        TG_HIP(hipMemset(w.dlogits.p, 0, B * logit_row * 4));  // padding columns stay zero
+        TG_HIP(w.logp.ensure(B * P * 4));
+        TG_HIP(w.eval.ensure(B * 4));
+        TG_HIP(w.dpre.ensure(B * 4));
+        TG_HIP(w.loss_p_rows.ensure(B * 4));
+        TG_HIP(w.loss_z_rows.ensure(B * 4));
+        TG_HIP(w.loss_sums.ensure(16));
+        TG_HIP(w.d_a.ensure(M * F * 4));
+        TG_HIP(w.d_b.ensure(M * F * 4));
+        TG_HIP(w.dz.ensure(M * F * 4));
+        TG_HIP(w.dz2.ensure(M * F * 4));
+        TG_HIP(w.gskip.ensure(M * F * 4));
+        TG_HIP(w.stats.ensure((size_t)bn * 2 * F * 4));
+        TG_HIP(w.mean_g.ensure((size_t)F * 8));
+        TG_HIP(w.mean_gx.ensure((size_t)F * 8));
+        TG_HIP(w.part_d.ensure(part_d_bytes));
+        TG_HIP(w.part_w.ensure(part_w_floats * 4));
+        for (int k = 0; k < 2; k++) TG_HIP(w.part_b[k].ensure(((size_t)B / 4 + 2) * 8 * 2 * F * 8));  // ≤ 8 partial rows per workgroup of ≥ 4 positions
+    }
     delete e->trainer;
     e->trainer = t.release();
     return TG_OK;
@@ -647,9 +793,15 @@ int tg_train_chunk(TgEngine* e, int n, const void* states, const int32_t* n_move
     if (rc) return rc;
     if (n <= 0 || n > e->trainer->cfg.chunk_size || !states || !n_moves || !moves || !visits || !results)
         return fail(TG_ERR_INVALID_ARG, "tg_train_chunk: bad arguments (1 ≤ n ≤ chunk_size)");
-    rc = upload_chunk(e, n, (const uint8_t*)states, n_moves, moves, visits, results, nullptr);
+    Lane& w = e->trainer->lane[0];
+    rc = upload_chunk(e, w, n, (const uint8_t*)states, n_moves, moves, visits, results, nullptr);
     if (rc) return rc;
-    return train_chunk_dev(e, n, loss_p, loss_z, stepped);
+    rc = chunk_issue(e, w, n);
+    if (rc) {
+        lanes_drain(e->trainer);
+        return rc;
+    }
+    return chunk_collect(e, w, loss_p, loss_z, stepped);
 }
 
 int tg_train(TgEngine* e, int n, const void* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
@@ -669,7 +821,7 @@ int tg_train(TgEngine* e, int n, const void* states, const int32_t* n_moves, con
         const float mine[4] = {bad ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f};
         TG_HIP(hipMemcpyAsync(t->err_flag.p, mine, 16, hipMemcpyHostToDevice, e->stream));
         bool reduced;
-        rc = all_reduce_sum(e, t->err_flag.as<float>(), 4, "argument check", &reduced);
+        rc = all_reduce_sum(e, e->stream, t->err_flag.as<float>(), 4, "argument check", &reduced);
         if (rc) return rc;
         float all[4];
         TG_HIP(hipMemcpyAsync(all, t->err_flag.p, 16, hipMemcpyDeviceToHost, e->stream));
@@ -697,14 +849,32 @@ int tg_train(TgEngine* e, int n, const void* states, const int32_t* n_moves, con
     const int cs = t->cfg.chunk_size;
     double sp = 0.0, sz = 0.0;
     int chunks = 0, nsteps = 0;
-    for (int off = 0; off + cs <= n; off += cs) {  // chunks_exact: the remainder is dropped
-        rc = upload_chunk(e, cs, (const uint8_t*)states, n_moves, moves, visits, results, order.data() + off, true);
-        if (rc) return rc;
+    // Two chunks in flight, one per lane: while the GPU works on chunk k the host collects chunk k − 1's losses from the other lane,
+    // uploads chunk k + 1 there and issues it — its forward pass runs beside chunk k's backward pass, HBM-bound passes of the one under
+    // the MFMA kernels of the other.  Every update of shared state (running statistics, gradient tensors, the optimiser step)
+    // stays in chunk order through the lanes' events: the same bits as one chunk after the other (TG_TRAIN_ONE_LANE=1).
+    auto collect = [&](Lane& w) -> int {
         float lp, lz;
         int32_t did;
-        rc = train_chunk_dev(e, cs, &lp, &lz, &did);
-        if (rc) return rc;
+        int crc = chunk_collect(e, w, &lp, &lz, &did);
+        if (crc) return crc;
         sp += lp; sz += lz; chunks++; nsteps += did;
+        return TG_OK;
+    };
+    int issued = 0;
+    for (int off = 0; off + cs <= n && rc == TG_OK; off += cs, issued++) {  // chunks_exact: the remainder is dropped
+        Lane& w = t->lane[issued % t->n_lanes];
+        if (w.in_flight) rc = collect(w);
+        if (rc == TG_OK) rc = upload_chunk(e, w, cs, (const uint8_t*)states, n_moves, moves, visits, results, order.data() + off, true);
+        if (rc == TG_OK) rc = chunk_issue(e, w, cs);
+    }
+    for (int k = 0; k < t->n_lanes && rc == TG_OK; k++) {  // oldest first
+        Lane& w = t->lane[(issued + k) % t->n_lanes];
+        if (w.in_flight) rc = collect(w);
+    }
+    if (rc) {
+        lanes_drain(t);
+        return rc;
     }
     if (mean_loss_p) *mean_loss_p = chunks ? (float)(sp / chunks) : 0.0f;
     if (mean_loss_z) *mean_loss_z = chunks ? (float)(sz / chunks) : 0.0f;
@@ -715,7 +885,7 @@ int tg_train(TgEngine* e, int n, const void* states, const int32_t* n_moves, con
 int tg_train_step(TgEngine* e) {
     int rc = need_trainer(e);
     if (rc) return rc;
-    rc = optimizer_step(e);
+    rc = optimizer_step(e, e->stream);
     if (rc) return rc;
     TG_HIP(hipStreamSynchronize(e->stream));
     return TG_OK;
@@ -726,14 +896,15 @@ int tg_train_forward(TgEngine* e, int n, const void* states, float* logp, float*
     if (rc) return rc;
     Trainer* t = e->trainer;
     if (n <= 0 || n > t->Bmax || !states || !logp || !eval) return fail(TG_ERR_INVALID_ARG, "tg_train_forward: bad arguments (1 ≤ n ≤ 8·chunk_size)");
-    hipStream_t st = e->stream;
-    TG_HIP(hipMemcpyAsync(t->states_aug.p, states, (size_t)n * e->g.bytes, hipMemcpyHostToDevice, st));
-    launch_encode_nhwc(st, t->states_aug.as<uint8_t>(), n, e->g.n, t->planes.as<float>(), e->cin_pad);
+    Lane& w = t->lane[0];
+    hipStream_t st = w.st;
+    TG_HIP(hipMemcpyAsync(w.states_aug.p, states, (size_t)n * e->g.bytes, hipMemcpyHostToDevice, st));
+    launch_encode_nhwc(st, w.states_aug.as<uint8_t>(), n, e->g.n, w.planes.as<float>(), e->cin_pad);
     TG_HIP(hipGetLastError());
-    rc = forward_train(e, n, false, t->logp.as<float>());
+    rc = forward_train(e, w, n, false, w.logp.as<float>());
     if (rc) return rc;
-    TG_HIP(hipMemcpyAsync(logp, t->logp.p, (size_t)n * e->policy_size * 4, hipMemcpyDeviceToHost, st));
-    TG_HIP(hipMemcpyAsync(eval, t->eval.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    TG_HIP(hipMemcpyAsync(logp, w.logp.p, (size_t)n * e->policy_size * 4, hipMemcpyDeviceToHost, st));
+    TG_HIP(hipMemcpyAsync(eval, w.eval.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     TG_HIP(hipStreamSynchronize(st));
     return TG_OK;
 }
@@ -762,7 +933,7 @@ int tg_train_commit(TgEngine* e) {
     Trainer* t = e->trainer;
     bool averaged = false;
     if (t->n_buffers) {  // data parallel: every rank normalised with its own batches → average the running statistics
-        rc = all_reduce_sum(e, t->bnbuf.as<float>(), t->n_buffers, "BatchNorm running statistics", &averaged);
+        rc = all_reduce_sum(e, e->stream, t->bnbuf.as<float>(), t->n_buffers, "BatchNorm running statistics", &averaged);
         if (rc) return rc;
     }
     TG_HIP(hipStreamSynchronize(e->stream));

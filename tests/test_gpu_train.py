@@ -492,6 +492,61 @@ def test_full_batch_training_kernels_return_identical_bits(cfg):
     assert digest(TG_TRAIN_ONE_STREAM="1") == digest()
 
 
+TRAIN_DIGEST = r"""
+import hashlib, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+import numpy as np
+import tak_amd, torch_ref
+from oracle import oracle as orc
+import test_gpu_train as T
+n, blocks, filters, head, cs, chunks, per_step = {cfg!r}
+net = torch_ref.make_net(n, blocks, filters, head, seed=3)
+e = T._engine(n, blocks, filters, head)
+tensors = torch_ref.abi_tensors(net)
+e.load_state_dict(tensors)
+e.train_create(learning_rate=1e-3, chunk_size=cs, chunks_in_step=per_step)
+ex = T._examples(orc, n, cs * chunks + 3, seed=11)
+h = hashlib.sha256()
+for rnd in range(2):   # the second call starts on trained parameters, behind a pipeline that has drained
+    lp, lz, steps = e.train(*ex, seed=5 + rnd)
+    assert steps == chunks // per_step
+    h.update(np.float32([lp, lz]).tobytes())
+    for name, a in sorted(tensors.items()):
+        h.update(e.train_get_tensor(name, a.shape).tobytes())     # parameters and running statistics
+    for name, shape in sorted(T._shapes(net).items()):
+        h.update(e.train_get_grad(name, shape).tobytes())          # what the incomplete last step left behind
+print("DIGEST", h.hexdigest())
+"""
+
+
+@pytest.mark.parametrize("cfg", [(5, 2, 64, "fc5", 128, 7, 3), (5, 1, 128, "fc5", 128, 4, 1), (6, 1, 128, "conv", 32, 5, 2)])
+def test_chunk_pipeline_returns_the_bits_of_one_chunk_after_the_other(cfg):
+    """tg_train keeps two chunks in flight (two lanes of two streams each); every update of state the chunks share — BatchNorm's
+    running statistics, every gradient tensor, the optimiser step and the re-packed weights — is ordered by events, so losses,
+    parameters, running statistics and left-over gradients are those of one chunk after the other on one stream, bit for bit:
+    steps falling on either lane (3 chunks per step), a step after every chunk, a left-over chunk behind the last step."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def digest(**env):
+        e = {k: v for k, v in os.environ.items() if not k.startswith("TG_")}
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", TRAIN_DIGEST.format(root=root, cfg=cfg)], env=e, check=True, capture_output=True,
+                             text=True, timeout=600).stdout
+        return [l for l in out.splitlines() if l.startswith("DIGEST")][-1].split()[1]
+
+    base = digest(TG_TRAIN_ONE_LANE="1", TG_TRAIN_ONE_STREAM="1")
+    assert digest(TG_TRAIN_ONE_LANE="1") == base
+    assert digest(TG_TRAIN_ONE_STREAM="1") == base
+    assert digest() == base
+    # the opt-in fold of BatchNorm's apply passes into the convolutions' staging moves a layer's weight gradient behind its
+    # data-gradient convolution: another event graph, the same guarantee
+    assert digest(TG_BN_FOLD="1") == digest(TG_BN_FOLD="1", TG_TRAIN_ONE_LANE="1", TG_TRAIN_ONE_STREAM="1")
+
+
 BN_STATS_DUMP = r"""
 import sys
 sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
@@ -567,6 +622,19 @@ def test_batchnorm_statistics_from_the_conv_accumulators_by_value(orc, tmp_path)
                 continue  # zero true gradient: rounding noise on both sides
             nrm = np.linalg.norm(c[k].astype(np.float64))
             assert np.linalg.norm(a[k].astype(np.float64) - c[k].astype(np.float64)) <= 1e-5 * nrm, (name, "fused backward sums")
+    # round 4, opt-in (TG_BN_FOLD=1; built, bit-identical, not faster — train.hip): BatchNorm's apply passes (forward y, backward dz) inside
+    # the staging of the next halo convolution against the kernels of their own: the same expressions on the same operands → identical losses, statistics and gradients, bit for bit — except the bias
+    # gradients of the convolutions in front of a BatchNorm (true value 0), whose column sums of dz are taken in another order:
+    # those agree to the rounding of the sums
+    d = run("bn_passes_folded", TG_BN_FOLD="1")
+    assert np.array_equal(a["loss"], d["loss"])
+    for k in a:
+        name = k[5:]
+        if k.startswith("grad/") and name.endswith(".bias") and "conv" in name and not name.startswith("policy"):
+            scale = np.abs(a["grad/" + name.replace(".bias", ".weight")]).max()
+            assert np.abs(a[k] - d[k]).max() <= 1e-6 * scale, (name, "conv bias gradient from the staging's column sums")
+        else:
+            assert np.array_equal(a[k], d[k]), (k, "folded BatchNorm passes")
     # the batch statistics PyTorch (fp64) sees, for the scale of each layer and as a third opinion
     net = _net_with_shifted_layers(n, blocks, filters, head).double().train()
     for m in net.modules():

@@ -1062,7 +1062,7 @@ constexpr size_t FC_RING_LDS = (size_t)FC_RING * FC_RING_SLOTS * 16 + 2 * FC_RIN
 __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, int lda, const float* __restrict__ Wp,
                                                  const float* __restrict__ bias, float* __restrict__ out, int M, int K, int NP,
                                                  int out_stride, int n_valid, int a_frag, float* __restrict__ stats, int n_soft,
-                                                 const FcGather gather, const float* __restrict__ Wlin) {
+                                                 const FcGather gather, const float* __restrict__ Wlin, int mb) {
     extern __shared__ __attribute__((aligned(16))) float fc_ring_lds[];
     f32x4* wl = (f32x4*)fc_ring_lds;                                // [FC_RING][chunk][tile slot][q][r16]
     uint32_t* flags = (uint32_t*)(wl + FC_RING * FC_RING_SLOTS);    // ready[FC_RING], done[FC_RING]
@@ -1072,13 +1072,16 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r16 = lane & 15, q = lane >> 4;
     const int cb = blockIdx.y;
-    const FcExtra X = fc_extra(cb);
+    // mb = main blocks = gridDim.y: 8 for the policy head (99 tiles: fc_extra deals the 3 leftover tiles); 2x for a matrix of 25x tiles
+    // (round 4: the training step's FC data gradient, 200 tiles = 16 × 12 + 8) — leftover tile cb / 2 for row tiles 0 … 3 (even cb) or
+    // 4 … 7 (odd cb), in waves 0 … 3: every SIMD carries 12 + 13 tile chains, no tile is padding
+    const FcExtra X = mb == FC_MAIN_BLOCKS ? fc_extra(cb) : FcExtra{cb >> 1, 4 * (cb & 1), 4};
     const bool has13 = wave < X.ne;                    // this wave also computes the leftover tile for its rows (wave-uniform)
     const int rt = (wave + X.s) & 7;                   // row tile of the row block owned by this wave
     const int row = blockIdx.x * 128 + rt * 16 + r16;
     const bool row_ok = row < M;
     const int n0 = cb * (FC_MAIN_TILES * 16);          // first column of the main tiles
-    const int nx = (FC_MAIN_TILES * FC_MAIN_BLOCKS + X.l) * 16;  // first column of the leftover tile
+    const int nx = (FC_MAIN_TILES * mb + X.l) * 16;               // first column of the leftover tile
     // loads are unconditional (rows past the end read a valid row and are never stored): hipcc puts s_waitcnt vmcnt(0)
     // right behind an exec-masked global load.  Activations: row-major (one 16-B slot of its row per lane and chunk), or
     // fragment-major (TowerParams.frag_out: the wave's 16 rows × 16 k of a chunk are one contiguous KB)
@@ -1889,7 +1892,17 @@ hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp,
         FcGather g{nullptr, nullptr, nullptr, 0};
         if (gather) g = FcGather{gather->child_pidx, gather->leaf_rec, gather->child_logit, gather->stride};
         hipLaunchKernelGGL(k_fc_ring, dim3((M + 127) / 128, FC_MAIN_BLOCKS), dim3(512), FC_RING_LDS, st, A, lda, Wp, bias, gather ? nullptr : out, M, K, NP,
-                           out_stride, n_valid, a_frag ? 1 : 0, stats, n_soft, g, Wlin);
+                           out_stride, n_valid, a_frag ? 1 : 0, stats, n_soft, g, Wlin, FC_MAIN_BLOCKS);
+        return hipGetLastError();
+    }
+    // Round 4: plain row-major GEMMs whose 25x output tiles split into 2x blocks of 12 + x leftover tiles take the ring too — the FC
+    // head's data gradient in the training step (dlogits[4000 × 1600] · Wᵀ → 3200 columns = 200 tiles): 465 µs in k_gemm below
+    static const bool ring_gemm = getenv("TG_NO_RING_GEMM") == nullptr;
+    if (ring_gemm && K % FC_KSTEP == 0 && NP % 400 == 0 && NP / 200 != FC_MAIN_BLOCKS && M > FC_SMALL_ROWS && !a_frag && !stats && !gather) {
+        static LdsAttr lds_attr;
+        if (hipError_t e = lds_attr.ensure((const void*)k_fc_ring, FC_RING_LDS); e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_fc_ring, dim3((M + 127) / 128, NP / 200), dim3(512), FC_RING_LDS, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid, 0,
+                           nullptr, 0, FcGather{nullptr, nullptr, nullptr, 0}, nullptr, NP / 200);
         return hipGetLastError();
     }
     dim3 grid((M + 127) / 128, NP / 64);

@@ -184,7 +184,8 @@ hipError_t launch_bn_fwd_apply(hipStream_t st, const float* z, const float* mean
 hipError_t launch_bn_bwd(hipStream_t st, const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
                          const float* gamma, int M, int F, double* part, double* mean_g, double* mean_gx, float* grad_gamma,
                          float* grad_beta, float* dz, float* gskip, float* grad_conv_bias = nullptr,  // grad_conv_bias += column sums of dz
-                         int sums_in_part = 0);  // > 0: Σg, Σg·x̂ already in `part` (that many partial rows, from launch_conv3x3's ConvBnBwdIn)
+                         int sums_in_part = 0,   // > 0: Σg, Σg·x̂ already in `part` (that many partial rows, from launch_conv3x3's ConvBnBwdIn)
+                         double* colsum_part = nullptr, int* colsum_rows = nullptr);  // dz's column-sum partials go there, not finalised
 hipError_t launch_bn_bwd_sums(hipStream_t st, const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
                               int M, int F, double* part, double* mean_g, double* mean_gx, float* grad_gamma, float* grad_beta,
                               int sums_in_part);
@@ -195,7 +196,7 @@ hipError_t launch_policy_loss(hipStream_t st, const float* logits, int row_strid
 hipError_t launch_value_train(hipStream_t st, const float* act, const float* wv, const float* bv, int B, int len, const float* zt,
                               float inv_b, float* eval, float* dpre, float* loss_rows);
 hipError_t launch_value_bwd(hipStream_t st, const float* act, const float* dpre, const float* wv, int B, int F, int nsq, float* ds,
-                            double* part, float* grad_w, float* grad_b);
+                            double* part, float* grad_w, float* grad_b, hipStream_t st_grad = nullptr);
 size_t wgrad_conv_workspace(int B, int n, int I, int O);
 hipError_t launch_wgrad_conv(hipStream_t st, const float* X, int xs, int I, const float* G, int gs, int O, int B, int n, float* part,
                              float* grad);

@@ -57,6 +57,7 @@ struct Lane {
     // backward: dz alternates between two buffers (the weight gradient of layer l reads one while the chain fills the other)
     DevBuf d_a, d_b, dz, dz2, gskip, stats, mean_g, mean_gx;
     DevBuf part_d, part_w;  // workspaces: the chain's double partials, the weight gradients' split-K partials
+    DevBuf part_h;          // two halves: the heads' bias / value gradients' partials (weight gradients' stream)
     DevBuf part_b[2];       // dz's column sums out of the data-gradient convolution's staging (ConvInFuse), alternating like dz
     // ev_dz[k]: dz buffer k holds this layer's dz (chain → weight gradients); ev_head: the forward pass is complete.
     // Per layer (index = layer; convs.size() = the heads), recorded behind the kernels of this lane's chunk that UPDATE state shared
@@ -359,24 +360,28 @@ int backward_train(TgEngine* e, Lane& w, int B) {
         TG_HIP(hipStreamWaitEvent(wg, w.ev_head, 0));
     }
     // ---- heads: dS = d(policy) + d(value) ----
+    // (the heads' own gradients — policy weights and bias, value weights and bias — all on the weight gradients' stream, with workspaces
+    // of their own: the chain starts with the data gradient the tower waits for)
     if (other) {
         TG_HIP(hipStreamWaitEvent(wg, other->ev_wgl[L], 0));
         TG_HIP(hipStreamWaitEvent(st, other->ev_chain[L], 0));
     }
+    double* part_h0 = w.part_h.as<double>();
+    double* part_h1 = (double*)((char*)w.part_h.p + w.part_h.bytes / 2);
     if (t->conv_head) {
         TrainConv& c = t->pol;
         const float* dl = w.dlogits.as<float>();
-        TG_HIP(launch_wgrad_conv(wg, s, F, F, dl, c.OP, c.O, B, N, part_w, G + c.w));
-        TG_HIP(launch_colsum_acc(st, dl, M, c.OP, c.O, part_d, G + c.b));
         TG_HIP(launch_conv3x3(st, dl, c.wb.as<float>(), zero_bias, nullptr, dcur, M, N, c.OP, round_up(F, 64), F, F, false));
+        TG_HIP(launch_wgrad_conv(wg, s, F, F, dl, c.OP, c.O, B, N, part_w, G + c.w));
+        TG_HIP(launch_colsum_acc(wg, dl, M, c.OP, c.O, part_h0, G + c.b));
     } else {
         const float* dl = w.dlogits.as<float>();
-        TG_HIP(launch_wgrad_fc(wg, s, nsq * F, dl, t->NP, e->policy_size, B, F, nsq, part_w, G + t->fc_w));
-        TG_HIP(launch_colsum_acc(st, dl, B, t->NP, e->policy_size, part_d, G + t->fc_b));
         TG_HIP(launch_gemm(st, dl, t->NP, t->fc_wb.as<float>(), zero_bias, dcur, B, t->Pp, t->KP, nsq * F, nsq * F));
+        TG_HIP(launch_wgrad_fc(wg, s, nsq * F, dl, t->NP, e->policy_size, B, F, nsq, part_w, G + t->fc_w));
+        TG_HIP(launch_colsum_acc(wg, dl, B, t->NP, e->policy_size, part_h0, G + t->fc_b));
     }
+    TG_HIP(launch_value_bwd(st, s, w.dpre.as<float>(), t->wv.as<float>(), B, F, nsq, dcur, part_h1, G + t->val_w, G + t->val_b, wg));
     TG_HIP(hipEventRecord(w.ev_wgl[L], wg));
-    TG_HIP(launch_value_bwd(st, s, w.dpre.as<float>(), t->wv.as<float>(), B, F, nsq, dcur, part_d, G + t->val_w, G + t->val_b));
     TG_HIP(hipEventRecord(w.ev_chain[L], st));
     // ---- tower, last layer first ----
     // Round 4: the data-gradient convolution of layer l produces dy of layer l − 1 — its epilogue also takes that layer's
@@ -402,8 +407,11 @@ int backward_train(TgEngine* e, Lane& w, int B) {
         if (other) TG_HIP(hipStreamWaitEvent(st, other->ev_chain[l], 0));
         const float* x = l == 0 ? w.planes.as<float>() : w.y[l - 1].as<float>();
         if (!in_staging) {
+            // (the conv bias gradient — dz's column sums — is finalised on the weight gradients' stream: one launch less in the chain)
+            int colsum_rows = 0;
             TG_HIP(launch_bn_bwd(st, dcur, w.y[l].as<float>(), w.z[l].as<float>(), mean, invstd, P + c.gamma, M, F, part_d, w.mean_g.as<double>(),
-                                 w.mean_gx.as<double>(), G + c.gamma, G + c.beta, dz, block_end ? gskip : nullptr, G + c.b, sums_in_part));
+                                 w.mean_gx.as<double>(), G + c.gamma, G + c.beta, dz, block_end ? gskip : nullptr, G + c.b, sums_in_part,
+                                 w.part_b[k].as<double>(), &colsum_rows));
             sums_in_part = 0;
             TG_HIP(hipEventRecord(w.ev_chain[l], st));
             if (two) {
@@ -411,6 +419,7 @@ int backward_train(TgEngine* e, Lane& w, int B) {
                 TG_HIP(hipStreamWaitEvent(wg, w.ev_dz[k], 0));
             }
             if (other) TG_HIP(hipStreamWaitEvent(wg, other->ev_wgl[l], 0));
+            TG_HIP(launch_colsum_finalize(wg, w.part_b[k].as<double>(), colsum_rows, F, F, G + c.b));
             TG_HIP(launch_wgrad_conv(wg, x, c.in_stride, c.I, dz, F, c.O, B, N, part_w, G + c.w));
             TG_HIP(hipEventRecord(w.ev_wgl[l], wg));
             if (l == 0) break;
@@ -780,7 +789,8 @@ int tg_train_create(TgEngine* e, const TgTrainConfig* cfg) {
         TG_HIP(w.mean_gx.ensure((size_t)F * 8));
         TG_HIP(w.part_d.ensure(part_d_bytes));
         TG_HIP(w.part_w.ensure(part_w_floats * 4));
-        for (int k = 0; k < 2; k++) TG_HIP(w.part_b[k].ensure(((size_t)B / 4 + 2) * 8 * 2 * F * 8));  // ≤ 8 partial rows per workgroup of ≥ 4 positions
+        for (int k = 0; k < 2; k++) TG_HIP(w.part_b[k].ensure(std::max(part_d_bytes, ((size_t)B / 4 + 2) * 8 * 2 * F * 8)));  // ConvInFuse: ≤ 8 partial rows per workgroup of ≥ 4 positions
+        TG_HIP(w.part_h.ensure(2 * ((part_d_bytes + 255) / 256 * 256)));
     }
     delete e->trainer;
     e->trainer = t.release();

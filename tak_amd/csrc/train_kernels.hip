@@ -862,16 +862,20 @@ hipError_t launch_colsum_finalize(hipStream_t st, const double* part, int rows, 
 }
 hipError_t launch_bn_bwd(hipStream_t st, const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
                          const float* gamma, int M, int F, double* part, double* mean_g, double* mean_gx, float* grad_gamma,
-                         float* grad_beta, float* dz, float* gskip, float* grad_conv_bias, int sums_in_part) {
+                         float* grad_beta, float* dz, float* gskip, float* grad_conv_bias, int sums_in_part, double* colsum_part,
+                         int* colsum_rows) {
     int rpb, nblk = col_reduce_blocks(M, F, &rpb);
     // sums_in_part > 0: Σg and Σg·x̂ already sit in `part`, that many partial rows — left there by the epilogue of the convolution
     // that produced dy (launch_conv3x3 with ConvBnBwdIn); else a pass over dy, y and z takes them
     if (sums_in_part <= 0) hipLaunchKernelGGL((k_col_reduce<RED_BNBWD>), dim3(nblk), dim3(256), 0, st, dy, y, z, mean, invstd, M, F, rpb, part);
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(F), dim3(256), 0, st, part, sums_in_part > 0 ? sums_in_part : nblk, F, M, mean_g, mean_gx, grad_gamma, grad_beta);
     if (grad_conv_bias) {  // dz and its column sums in one pass (the bias gradient of the convolution in front)
+        // colsum_part: the partial rows go there and the caller finalises them (launch_colsum_finalize) where it suits it — the training
+        // step does it on the weight gradients' stream, off the chain of kernels the next convolution waits for
         hipLaunchKernelGGL(k_bn_bwd_apply_sum, dim3(nblk), dim3(256), 0, st, dy, y, z, mean, invstd, gamma, mean_g, mean_gx, dz, gskip, M, F,
-                           rpb, part);
-        hipLaunchKernelGGL(k_colsum_finalize, dim3(F), dim3(256), 0, st, part, nblk, F, F, grad_conv_bias);
+                           rpb, colsum_part ? colsum_part : part);
+        if (colsum_part) *colsum_rows = nblk;
+        else hipLaunchKernelGGL(k_colsum_finalize, dim3(F), dim3(256), 0, st, part, nblk, F, F, grad_conv_bias);
         return hipGetLastError();
     }
     size_t total4 = (size_t)M * F / 4;
@@ -904,14 +908,17 @@ hipError_t launch_value_train(hipStream_t st, const float* act, const float* wv,
     return hipGetLastError();
 }
 hipError_t launch_value_bwd(hipStream_t st, const float* act, const float* dpre, const float* wv, int B, int F, int nsq, float* ds,
-                            double* part, float* grad_w, float* grad_b) {
+                            double* part, float* grad_w, float* grad_b, hipStream_t st_grad) {
+    // ds += dpre ⊗ wv on `st`; the head's own gradients (Σ_b dpre·act, Σ_b dpre) on `st_grad` (null: st) — the training step puts them
+    // on the weight gradients' stream with a workspace of that stream, off the chain the first data-gradient convolution waits for
     const int len = F * nsq;
     size_t total4 = (size_t)B * len / 4;
+    if (!st_grad) st_grad = st;
     hipLaunchKernelGGL(k_value_bwd_ds, dim3(blocks_for(total4)), dim3(256), 0, st, ds, dpre, wv, total4, len / 4);
     const int splits = 32;
     int rps = (B + splits - 1) / splits;
-    hipLaunchKernelGGL(k_value_wgrad, dim3((len + 1 + 255) / 256, splits), dim3(256), 0, st, act, dpre, B, len, rps, part);
-    hipLaunchKernelGGL(k_value_wgrad_finalize, dim3((len + 1 + 255) / 256), dim3(256), 0, st, part, splits, F, nsq, grad_w, grad_b);
+    hipLaunchKernelGGL(k_value_wgrad, dim3((len + 1 + 255) / 256, splits), dim3(256), 0, st_grad, act, dpre, B, len, rps, part);
+    hipLaunchKernelGGL(k_value_wgrad_finalize, dim3((len + 1 + 255) / 256), dim3(256), 0, st_grad, part, splits, F, nsq, grad_w, grad_b);
     return hipGetLastError();
 }
 

@@ -434,10 +434,10 @@ int tg_train_chunk(TgEngine* e, int n, const void* states, const int32_t* n_move
  * others in a collective.  All ranks must therefore call tg_train together.  tg_train_chunk validates only its own chunk — a
  * data-parallel caller of tg_train_chunk must agree on errors across ranks itself before the chunk that completes an
  * optimiser step.
- * Execution (round 4): two chunks are in flight at a time, each on its own activations and streams; every update of state they
- * share (BatchNorm running statistics, each gradient tensor, the optimiser step) is ordered in chunk order, so the result is that
- * of tg_train_chunk on one chunk after the other, bit for bit.  Environment: TG_TRAIN_ONE_LANE=1 — one chunk at a time (half the
- * activation memory), TG_TRAIN_ONE_STREAM=1 — weight gradients on the chain's stream. */
+ * Execution (round 4): the weight gradients of a chunk run on a stream of their own beside the data-gradient chain
+ * (TG_TRAIN_ONE_STREAM=1: on the chain's stream); with TG_TRAIN_LANES=2 two chunks are in flight at a time, each on its own
+ * activations and streams, every update of state they share (BatchNorm running statistics, each gradient tensor, the optimiser
+ * step) in chunk order.  Either way the result is that of tg_train_chunk on one chunk after the other, bit for bit. */
 int tg_train(TgEngine* e, int n, const void* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
              const float* results, uint64_t seed, float* mean_loss_p, float* mean_loss_z, int32_t* steps);
 /* opt.step(); opt.zero_grad() now (network.rs:92-96), whatever the chunk counter says */
@@ -458,8 +458,8 @@ int tg_train_comm_init(TgEngine* e, int rank, int world_size, const void* id128)
 /* The same reduction through a caller-supplied function instead of RCCL — ranks that share one GPU (RCCL refuses duplicate
  * devices), a host transport (gloo, MPI, a socket from Rust), or a test.  The optimiser step calls
  * fn(ctx, d_buf, count, stream) with the flat gradient buffer (device memory, `count` floats); on return — or, if fn only
- * enqueues work, in the order of `stream` (a hipStream_t of the engine: the one the step runs on, not always the same — tg_train
- * keeps two chunks in flight on two sets of streams) — d_buf must hold the SUM over all world_size ranks.
+ * enqueues work, in the order of `stream` (a hipStream_t of the engine: the one the step runs on — with TG_TRAIN_LANES=2 not
+ * always the same) — d_buf must hold the SUM over all world_size ranks.
  * The step then applies Adam to d_buf / world_size, so every rank that saw the same sum ends with bit-identical parameters.
  * tg_train_commit reduces the BatchNorm running statistics through the same function.  fn returns 0 or an error code
  * (→ TG_ERR_STATE).  fn = NULL removes the hook.  Mutually exclusive with tg_train_comm_init. */

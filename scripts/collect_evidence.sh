@@ -13,8 +13,12 @@ step "bench.py, default flags"
 ( time python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err ) 2> $O/bench_default.time
 step "kernel trace of bench.py --no-extras --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_bench -o kt -- python3 $R/bench.py --no-extras --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/kt_bench.err
-step "kernel trace of the training step"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_train -o kt -- python3 $R/scripts/train_step_ab.py 10 > $O/train_step.json 2> $O/kt_train.err
+step "kernel trace of the training step: on one stream (the kernels' own durations), then as it runs (what overlaps)"
+TG_TRAIN_ONE_STREAM=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_train -o kt -- python3 $R/scripts/train_step_ab.py 10 > $O/train_step_one_stream_under_rocprof.json 2> $O/kt_train.err
+rocprofv3 --kernel-trace --output-format csv -d $O/kt_train2 -o kt -- python3 $R/scripts/train_step_ab.py 12 --driver > /dev/null 2> $O/kt_train2.err
+python3 $R/scripts/probes/train_overlap.py $(find $O/kt_train2 -name '*kernel_trace.csv' | head -1) > $O/train_overlap_default.txt 2>&1
+step "training step timings (no profiler): tg_train, tg_train_chunk, one stream"
+{ python3 $R/scripts/train_step_ab.py 40 --driver; python3 $R/scripts/train_step_ab.py 40; TG_TRAIN_LANES=2 python3 $R/scripts/train_step_ab.py 40 --driver; TG_TRAIN_ONE_STREAM=1 python3 $R/scripts/train_step_ab.py 40 --driver; } > $O/train_step.jsonl 2>> $O/kt_train.err
 step "HBM traffic counters, forward C2"
 rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_WRREQ --output-format csv -d $O/pmc_traffic -o p -- python3 $R/scripts/ab_forward.py c2 > $O/ab_forward_c2_under_pmc.json 2> $O/pmc_traffic.err
 step "HBM traffic counters, policy FC inside the search loop (gather epilogue)"
@@ -50,6 +54,6 @@ $P $R/scripts/pmc_traffic.py $(find $O/pmc_board_t6 -name '*counter_collection.c
 cp $(find $O/kt_bench -name '*kernel_stats.csv' | head -1) $O/kernel_stats_bench.csv 2>/dev/null
 cp $(find $O/kt_train -name '*kernel_stats.csv' | head -1) $O/kernel_stats_train_step.csv 2>/dev/null
 # the raw traces are large: keep the summaries only
-rm -rf $O/kt_bench $O/kt_train $O/pmc_traffic $O/pmc_traffic_bench $O/pmc_sq1 $O/pmc_sq2 $O/pmc_tree $O/pmc_board $O/pmc_board6 $O/pmc_board_t5 $O/pmc_board_t6
+rm -rf $O/kt_bench $O/kt_train $O/kt_train2 $O/pmc_traffic $O/pmc_traffic_bench $O/pmc_sq1 $O/pmc_sq2 $O/pmc_tree $O/pmc_board $O/pmc_board6 $O/pmc_board_t5 $O/pmc_board_t6
 ls -la $O
 step "done"

@@ -1059,10 +1059,11 @@ constexpr int FC_RING_SLOTS = 4 * FC_PLANE;                                     
 constexpr size_t FC_RING_LDS = (size_t)FC_RING * FC_RING_SLOTS * 16 + 2 * FC_RING * sizeof(uint32_t);
 // (diagnostic build only — scripts/probes/fc_ring_stamps.hip: stamps of workgroup (0, 0); s_memtime has another base on every XCD)
 #define TG_FC_STAMP(step, slot) do { if (blockIdx.y == 0) { TG_STAMP(step, slot); } } while (0)
+template <int GEOM>  // 0: the policy head's 99 tiles (8 blocks + 3 leftover tiles, fc_extra); 1: 25x tiles as 2x blocks + x leftover tiles
 __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, int lda, const float* __restrict__ Wp,
                                                  const float* __restrict__ bias, float* __restrict__ out, int M, int K, int NP,
                                                  int out_stride, int n_valid, int a_frag, float* __restrict__ stats, int n_soft,
-                                                 const FcGather gather, const float* __restrict__ Wlin, int mb) {
+                                                 const FcGather gather, const float* __restrict__ Wlin) {
     extern __shared__ __attribute__((aligned(16))) float fc_ring_lds[];
     f32x4* wl = (f32x4*)fc_ring_lds;                                // [FC_RING][chunk][tile slot][q][r16]
     uint32_t* flags = (uint32_t*)(wl + FC_RING * FC_RING_SLOTS);    // ready[FC_RING], done[FC_RING]
@@ -1072,10 +1073,11 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r16 = lane & 15, q = lane >> 4;
     const int cb = blockIdx.y;
-    // mb = main blocks = gridDim.y: 8 for the policy head (99 tiles: fc_extra deals the 3 leftover tiles); 2x for a matrix of 25x tiles
-    // (round 4: the training step's FC data gradient, 200 tiles = 16 × 12 + 8) — leftover tile cb / 2 for row tiles 0 … 3 (even cb) or
-    // 4 … 7 (odd cb), in waves 0 … 3: every SIMD carries 12 + 13 tile chains, no tile is padding
-    const FcExtra X = mb == FC_MAIN_BLOCKS ? fc_extra(cb) : FcExtra{cb >> 1, 4 * (cb & 1), 4};
+    // GEOM 1 (round 4: the training step's FC data gradient, 200 tiles = 16 × 12 + 8): gridDim.y = 2x blocks; leftover tile cb / 2 for
+    // row tiles 0 … 3 (even cb) or 4 … 7 (odd cb), in waves 0 … 3 — every SIMD carries 12 + 13 tile chains, no tile is padding.  (A template
+    // parameter: the block count as a kernel argument cost the policy head 2.7 µs, 167.5 against 164.8 µs.)
+    const int mb = GEOM == 0 ? FC_MAIN_BLOCKS : (int)gridDim.y;
+    const FcExtra X = GEOM == 0 ? fc_extra(cb) : FcExtra{cb >> 1, 4 * (cb & 1), 4};
     const bool has13 = wave < X.ne;                    // this wave also computes the leftover tile for its rows (wave-uniform)
     const int rt = (wave + X.s) & 7;                   // row tile of the row block owned by this wave
     const int row = blockIdx.x * 128 + rt * 16 + r16;
@@ -1888,21 +1890,21 @@ hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp,
     }
     if (fc) {
         static LdsAttr lds_attr;
-        if (hipError_t e = lds_attr.ensure((const void*)k_fc_ring, FC_RING_LDS); e != hipSuccess) return e;
+        if (hipError_t e = lds_attr.ensure((const void*)k_fc_ring<0>, FC_RING_LDS); e != hipSuccess) return e;
         FcGather g{nullptr, nullptr, nullptr, 0};
         if (gather) g = FcGather{gather->child_pidx, gather->leaf_rec, gather->child_logit, gather->stride};
-        hipLaunchKernelGGL(k_fc_ring, dim3((M + 127) / 128, FC_MAIN_BLOCKS), dim3(512), FC_RING_LDS, st, A, lda, Wp, bias, gather ? nullptr : out, M, K, NP,
-                           out_stride, n_valid, a_frag ? 1 : 0, stats, n_soft, g, Wlin, FC_MAIN_BLOCKS);
+        hipLaunchKernelGGL(k_fc_ring<0>, dim3((M + 127) / 128, FC_MAIN_BLOCKS), dim3(512), FC_RING_LDS, st, A, lda, Wp, bias, gather ? nullptr : out, M, K, NP,
+                           out_stride, n_valid, a_frag ? 1 : 0, stats, n_soft, g, Wlin);
         return hipGetLastError();
     }
     // Round 4: plain row-major GEMMs whose 25x output tiles split into 2x blocks of 12 + x leftover tiles take the ring too — the FC
     // head's data gradient in the training step (dlogits[4000 × 1600] · Wᵀ → 3200 columns = 200 tiles): 465 µs in k_gemm below
     static const bool ring_gemm = getenv("TG_NO_RING_GEMM") == nullptr;
-    if (ring_gemm && K % FC_KSTEP == 0 && NP % 400 == 0 && NP / 200 != FC_MAIN_BLOCKS && M > FC_SMALL_ROWS && !a_frag && !stats && !gather) {
+    if (ring_gemm && K % FC_KSTEP == 0 && NP % 400 == 0 && M > FC_SMALL_ROWS && !a_frag && !stats && !gather) {
         static LdsAttr lds_attr;
-        if (hipError_t e = lds_attr.ensure((const void*)k_fc_ring, FC_RING_LDS); e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_fc_ring, dim3((M + 127) / 128, NP / 200), dim3(512), FC_RING_LDS, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid, 0,
-                           nullptr, 0, FcGather{nullptr, nullptr, nullptr, 0}, nullptr, NP / 200);
+        if (hipError_t e = lds_attr.ensure((const void*)k_fc_ring<1>, FC_RING_LDS); e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_fc_ring<1>, dim3((M + 127) / 128, NP / 200), dim3(512), FC_RING_LDS, st, A, lda, Wp, bias, out, M, K, NP, out_stride, n_valid, 0,
+                           nullptr, 0, FcGather{nullptr, nullptr, nullptr, 0}, nullptr);
         return hipGetLastError();
     }
     dim3 grid((M + 127) / 128, NP / 64);

@@ -143,7 +143,7 @@ struct Trainer {
     // value head
     size_t val_w = 0, val_b = 0;
     DevBuf wv;
-    // two chunks in flight (TG_TRAIN_ONE_LANE=1: one)
+    // chunks in flight: one lane by default, TG_TRAIN_LANES=2: two (built, bit-identical, no consistent gain: tg_train's comment)
     Lane lane[2];
     int n_lanes = 1;
     Lane* prev = nullptr;          // the lane of the chunk issued last: the next chunk orders its updates behind that one's
@@ -737,7 +737,7 @@ int tg_train_create(TgEngine* e, const TgTrainConfig* cfg) {
         part_d_bytes = std::max(a, b) * 8;
     }
     TG_HIP(hipEventCreateWithFlags(&t->ev_step, hipEventDisableTiming));
-    t->n_lanes = getenv("TG_TRAIN_ONE_LANE") ? 1 : 2;
+    t->n_lanes = (getenv("TG_TRAIN_LANES") && atoi(getenv("TG_TRAIN_LANES")) == 2) ? 2 : 1;
     const size_t L = t->convs.size();
     for (int li = 0; li < t->n_lanes; li++) {
         Lane& w = t->lane[li];
@@ -859,10 +859,13 @@ int tg_train(TgEngine* e, int n, const void* states, const int32_t* n_moves, con
     const int cs = t->cfg.chunk_size;
     double sp = 0.0, sz = 0.0;
     int chunks = 0, nsteps = 0;
-    // Two chunks in flight, one per lane: while the GPU works on chunk k the host collects chunk k − 1's losses from the other lane,
-    // uploads chunk k + 1 there and issues it — its forward pass runs beside chunk k's backward pass, HBM-bound passes of the one under
-    // the MFMA kernels of the other.  Every update of shared state (running statistics, gradient tensors, the optimiser step)
-    // stays in chunk order through the lanes' events: the same bits as one chunk after the other (TG_TRAIN_ONE_LANE=1).
+    // TG_TRAIN_LANES=2 (round 4; built and measured, off by default): two chunks in flight, one per lane — while the GPU works on chunk k
+    // the host collects chunk k − 1's losses from the other lane, uploads chunk k + 1 there and issues it; its forward pass runs beside
+    // chunk k's backward pass.  Every update of shared state (running statistics, gradient tensors, the optimiser step) stays in chunk
+    // order through the lanes' events: the same bits as one chunk after the other (tests/test_gpu_train.py).  What it buys once the
+    // weight gradients have their own stream: − 0.15 ms per chunk on one box, + 0.2 ms on another, nothing on a third — kernels that
+    // share the machine end together and their HBM-bound passes then run at once (profiles/r04_g_train_overlap.txt), so the second
+    // lane mostly hides the host's time between two chunks, for twice the activation memory.
     auto collect = [&](Lane& w) -> int {
         float lp, lz;
         int32_t did;

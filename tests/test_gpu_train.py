@@ -521,7 +521,7 @@ print("DIGEST", h.hexdigest())
 
 @pytest.mark.parametrize("cfg", [(5, 2, 64, "fc5", 128, 7, 3), (5, 1, 128, "fc5", 128, 4, 1), (6, 1, 128, "conv", 32, 5, 2)])
 def test_chunk_pipeline_returns_the_bits_of_one_chunk_after_the_other(cfg):
-    """tg_train keeps two chunks in flight (two lanes of two streams each); every update of state the chunks share — BatchNorm's
+    """With TG_TRAIN_LANES=2 tg_train keeps two chunks in flight (two lanes of two streams each); every update of state the chunks share — BatchNorm's
     running statistics, every gradient tensor, the optimiser step and the re-packed weights — is ordered by events, so losses,
     parameters, running statistics and left-over gradients are those of one chunk after the other on one stream, bit for bit:
     steps falling on either lane (3 chunks per step), a step after every chunk, a left-over chunk behind the last step."""
@@ -538,13 +538,13 @@ def test_chunk_pipeline_returns_the_bits_of_one_chunk_after_the_other(cfg):
                              text=True, timeout=600).stdout
         return [l for l in out.splitlines() if l.startswith("DIGEST")][-1].split()[1]
 
-    base = digest(TG_TRAIN_ONE_LANE="1", TG_TRAIN_ONE_STREAM="1")
-    assert digest(TG_TRAIN_ONE_LANE="1") == base
-    assert digest(TG_TRAIN_ONE_STREAM="1") == base
+    base = digest(TG_TRAIN_ONE_STREAM="1")
     assert digest() == base
+    assert digest(TG_TRAIN_LANES="2") == base
+    assert digest(TG_TRAIN_LANES="2", TG_TRAIN_ONE_STREAM="1") == base
     # the opt-in fold of BatchNorm's apply passes into the convolutions' staging moves a layer's weight gradient behind its
     # data-gradient convolution: another event graph, the same guarantee
-    assert digest(TG_BN_FOLD="1") == digest(TG_BN_FOLD="1", TG_TRAIN_ONE_LANE="1", TG_TRAIN_ONE_STREAM="1")
+    assert digest(TG_BN_FOLD="1", TG_TRAIN_LANES="2") == digest(TG_BN_FOLD="1", TG_TRAIN_ONE_STREAM="1")
 
 
 BN_STATS_DUMP = r"""

@@ -1583,19 +1583,19 @@ static hipError_t launch_conv_pos_t(hipStream_t st, const float* in, const float
 // slot table of the halo image for (n, F) on the current device, built on first use (launch_conv3x3's halo path; the fused
 // tower carries its own copy in TowerParams)
 static const uint32_t* conv_halo_slotmap(int n, int F, int pw, int ps) {
-    struct Entry { int dev, n, F; uint32_t* d; };
+    struct Entry { int dev, n, F, pw; uint32_t* d; };
     static std::vector<Entry> cache;
     static std::mutex guard;  // trainers of several engines may run on several host threads (data-parallel tests)
     std::lock_guard<std::mutex> lock(guard);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    for (const Entry& e : cache) if (e.dev == dev && e.n == n && e.F == F) return e.d;
+    for (const Entry& e : cache) if (e.dev == dev && e.n == n && e.F == F && e.pw == pw) return e.d;
     std::vector<uint32_t> map((size_t)((pw * n * n + 15) / 16) * 16);
     tower_halo_slotmap(n, pw, ps, map.data());
     uint32_t* d = nullptr;
     if (hipMalloc((void**)&d, map.size() * 4) != hipSuccess) return nullptr;
     if (hipMemcpy(d, map.data(), map.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
-    cache.push_back({dev, n, F, d});
+    cache.push_back({dev, n, F, pw, d});
     return d;
 }
 

@@ -347,11 +347,13 @@ int backward_train(TgEngine* e, Lane& w, int B) {
     const float* zero_bias = t->zero_bias.as<float>();
     // Round 4: two streams.  A layer's weight gradient (dz ⊗ x) and its data gradient (dz ∗ wᵀ, then the BatchNorm backward of the
     // layer below) only share their INPUT, so the weight gradients — the policy head's first — run on `wg` while the chain
-    // heads → BatchNorm backward → data gradient → … stays on the lane's stream: the HBM-bound passes of the chain (BatchNorm
-    // backward 47 µs, split-K reduction 19 µs per layer) and every launch's ramp and tail pass under the other stream's MFMA kernel
-    // instead of standing alone.  Same kernels on the same operands, every gradient tensor still written by one launch → the
+    // heads → BatchNorm backward → data gradient → … stays on the lane's stream, and with them everything else that only produces
+    // gradients (conv bias finalisation, the heads' bias and value gradients): 19.3 – 19.6 → 18.1 – 18.5 ms per chunk of the C5 network.
+    // What is gained is every launch's ramp and tail and the split-K reductions beside the other stream's kernel; the two MFMA kernels
+    // of a layer share the machine and end together, so the chain's HBM-bound BatchNorm passes still run between them, not under them
+    // (profiles/r04_g_train_overlap.txt).  Same kernels on the same operands, every gradient tensor still written by one launch → the
     // same bits as the single-stream order (TG_TRAIN_ONE_STREAM=1; tests/test_gpu_train.py).  dz alternates between two buffers;
-    // the workspaces are per stream (part_w: weight gradients only, part_d: the chain only).
+    // the workspaces are per stream (part_w, part_h, part_b: weight gradients' stream, part_d: the chain).
     static const bool one_stream = getenv("TG_TRAIN_ONE_STREAM") != nullptr;
     hipStream_t wg = one_stream ? st : w.wg;
     const bool two = wg != st;

@@ -488,8 +488,9 @@ def test_full_batch_training_kernels_return_identical_bits(cfg):
     assert digest(TG_NO_HALO_CONV="1", TG_NO_HALO_WGRAD="1", **plain) == base
     # round 4: the weight gradients run on a stream of their own beside the data-gradient chain (dz in two alternating buffers) —
     # the same launches in another interleaving: same bits as the single-stream order, with the default kernels too
-    assert digest(TG_TRAIN_ONE_STREAM="1", **plain) == base
-    assert digest(TG_TRAIN_ONE_STREAM="1") == digest()
+    if cfg[2] == 128 and cfg[3] == "fc5":  # (one configuration: each variant is a process of its own)
+        assert digest(TG_TRAIN_ONE_STREAM="1", **plain) == base
+        assert digest(TG_TRAIN_ONE_STREAM="1") == digest()
 
 
 TRAIN_DIGEST = r"""
@@ -539,12 +540,13 @@ def test_chunk_pipeline_returns_the_bits_of_one_chunk_after_the_other(cfg):
         return [l for l in out.splitlines() if l.startswith("DIGEST")][-1].split()[1]
 
     base = digest(TG_TRAIN_ONE_STREAM="1")
-    assert digest() == base
     assert digest(TG_TRAIN_LANES="2") == base
-    assert digest(TG_TRAIN_LANES="2", TG_TRAIN_ONE_STREAM="1") == base
-    # the opt-in fold of BatchNorm's apply passes into the convolutions' staging moves a layer's weight gradient behind its
-    # data-gradient convolution: another event graph, the same guarantee
-    assert digest(TG_BN_FOLD="1", TG_TRAIN_LANES="2") == digest(TG_BN_FOLD="1", TG_TRAIN_ONE_STREAM="1")
+    if cfg[6] == 3:  # (one configuration for the rest: each variant is a process of its own)
+        assert digest() == base
+        assert digest(TG_TRAIN_LANES="2", TG_TRAIN_ONE_STREAM="1") == base
+        # the opt-in fold of BatchNorm's apply passes into the convolutions' staging moves a layer's weight gradient behind its
+        # data-gradient convolution: another event graph, the same guarantee
+        assert digest(TG_BN_FOLD="1", TG_TRAIN_LANES="2") == digest(TG_BN_FOLD="1", TG_TRAIN_ONE_STREAM="1")
 
 
 BN_STATS_DUMP = r"""

@@ -1072,7 +1072,19 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r16 = lane & 15, q = lane >> 4;
-    const int cb = blockIdx.y;
+    // Which (row block, column block) this workgroup computes.  Workgroups go to the 8 XCDs round robin by their linear index, so with
+    // (row block, column block) = blockIdx every XCD's L2 fetches ALL the weights (8 × 10.1 MB) and its quarter of the rows once: 107 MB.
+    // An XCD that computes a column blocks × 32 / a row blocks fetches 10.1 a + 210 / a MB: least at a = 4 — XCD c gets column blocks
+    // 4 (c & 1) … + 3 and every fourth row block from c >> 1 on.  Measured (scripts/probes/fc_xcd_map.sh): memory-side traffic 134.0 →
+    // 120.5 MB with logits rows (3.64 → 3.27 × algorithmic), the launch time unchanged (166.3 – 166.6 µs either way: L2 misses that hit
+    // the Infinity Cache were never what it waited for).  The same results by other workgroups: nothing changes in the output.
+    int rbx = (int)blockIdx.x, cbx = (int)blockIdx.y;
+    if (GEOM == 0 && (gridDim.x & 7) == 0) {
+        const int xcd = rbx & 7, j = (rbx >> 3) + (int)(gridDim.x >> 3) * cbx;
+        cbx = 4 * (xcd & 1) + (j & 3);
+        rbx = (xcd >> 1) + 4 * (j >> 2);
+    }
+    const int cb = cbx;
     // GEOM 1 (round 4: the training step's FC data gradient, 200 tiles = 16 × 12 + 8): gridDim.y = 2x blocks; leftover tile cb / 2 for
     // row tiles 0 … 3 (even cb) or 4 … 7 (odd cb), in waves 0 … 3 — every SIMD carries 12 + 13 tile chains, no tile is padding.  (A template
     // parameter: the block count as a kernel argument cost the policy head 2.7 µs, 167.5 against 164.8 µs.)
@@ -1080,7 +1092,7 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
     const FcExtra X = GEOM == 0 ? fc_extra(cb) : FcExtra{cb >> 1, 4 * (cb & 1), 4};
     const bool has13 = wave < X.ne;                    // this wave also computes the leftover tile for its rows (wave-uniform)
     const int rt = (wave + X.s) & 7;                   // row tile of the row block owned by this wave
-    const int row = blockIdx.x * 128 + rt * 16 + r16;
+    const int row = rbx * 128 + rt * 16 + r16;
     const bool row_ok = row < M;
     const int n0 = cb * (FC_MAIN_TILES * 16);          // first column of the main tiles
     const int nx = (FC_MAIN_TILES * mb + X.l) * 16;               // first column of the leftover tile
@@ -1088,7 +1100,7 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
     // right behind an exec-masked global load.  Activations: row-major (one 16-B slot of its row per lane and chunk), or
     // fragment-major (TowerParams.frag_out: the wave's 16 rows × 16 k of a chunk are one contiguous KB)
     const int last_tile = (M - 1) >> 4;
-    const int my_tile = min(blockIdx.x * 8 + rt, last_tile);
+    const int my_tile = min(rbx * 8 + rt, last_tile);
     const f32x4* ap = a_frag ? (const f32x4*)A + (size_t)my_tile * (K >> 4) * 64 + r16 * 4 + q
                              : (const f32x4*)(A + (size_t)(row_ok ? row : M - 1) * lda) + q;
     const size_t achunk = a_frag ? 64 : 4;
@@ -1197,7 +1209,7 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
         b0 = aload(step * 4 + 4);
         b1 = aload(step * 4 + 5);
         if (gather.child_logit && step == nsteps - 1) {  // (no refill follows in the last step: these loads wait for nobody)
-            const int tile_row0 = blockIdx.x * 128 + rt * 16;
+            const int tile_row0 = rbx * 128 + rt * 16;
             g_cnt = gather.leaf_rec[2 * (size_t)min(tile_row0 + r16, M - 1) + 1];
 #pragma unroll
             for (int r = 0; r < 16; r++)
@@ -1279,7 +1291,7 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
             for (int j = 0; j < FC_CT; j++) *(f32x4*)&dst[j * 16] = v[j];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own parked rows, now read by other lanes of the same wave
-        const int tile_row0 = blockIdx.x * 128 + rt * 16;
+        const int tile_row0 = rbx * 128 + rt * 16;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int grow = min(tile_row0 + r, M - 1);

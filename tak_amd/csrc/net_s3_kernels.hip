@@ -1081,7 +1081,15 @@ __global__ __launch_bounds__(FSR_NW * 64) void k_fc_s3_ring(const u32x4* __restr
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r16 = lane & 15, q = lane >> 4;
-    const int cb = blockIdx.y;
+    // (row block, column block) by XCD as in k_fc_ring (net_kernels.hip): an XCD computes 4 column blocks × every fourth row block, so its
+    // L2 fetches half of the weights and a quarter of the rows twice instead of all the weights and a quarter of the rows once
+    int rbx = (int)blockIdx.x, cbx = (int)blockIdx.y;
+    if ((gridDim.x & 7) == 0) {
+        const int xcd = rbx & 7, j = (rbx >> 3) + (int)(gridDim.x >> 3) * cbx;
+        cbx = 4 * (xcd & 1) + (j & 3);
+        rbx = (xcd >> 1) + 4 * (j >> 2);
+    }
+    const int cb = cbx;
     const FcExtra X = fc_extra(cb);
     const bool has13 = wave < X.ne;                 // this wave also computes the leftover tile, for its row tile 0 (wave-uniform)
     const int n0 = cb * (FC_MAIN_TILES * 16);
@@ -1093,7 +1101,7 @@ __global__ __launch_bounds__(FSR_NW * 64) void k_fc_s3_ring(const u32x4* __restr
 #pragma unroll
     for (int i = 0; i < FSR_RT; i++) {
         rt[i] = (wave + i * FSR_NW + X.s) & 7;      // row tile 0 of waves 0 … ne − 1 are the rows that need the leftover tile
-        row[i] = blockIdx.x * 128 + rt[i] * 16 + r16;
+        row[i] = rbx * 128 + rt[i] * 16 + r16;
         row_ok[i] = row[i] < M;
         ap[i] = A + (size_t)(row_ok[i] ? row[i] : M - 1) * rpitch + q;  // rows past the end load a valid row; never stored
     }
@@ -1190,7 +1198,7 @@ __global__ __launch_bounds__(FSR_NW * 64) void k_fc_s3_ring(const u32x4* __restr
         if (gather.child_logit && step == nsteps - 1) {  // (no refill follows in the last step: these loads wait for nobody)
 #pragma unroll
             for (int i = 0; i < FSR_RT; i++) {
-                const int tile_row0 = blockIdx.x * 128 + rt[i] * 16;
+                const int tile_row0 = rbx * 128 + rt[i] * 16;
                 g_cnt[i] = gather.leaf_rec[2 * (size_t)min(tile_row0 + r16, M - 1) + 1];
 #pragma unroll
                 for (int r = 0; r < 16; r++)
@@ -1273,7 +1281,7 @@ __global__ __launch_bounds__(FSR_NW * 64) void k_fc_s3_ring(const u32x4* __restr
                 for (int j = 0; j < FSR_CT; j++) *(f32x4*)&dst[j * 16] = v[j];
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own parked rows, now read by other lanes of the same wave
-            const int tile_row0 = blockIdx.x * 128 + rt[i] * 16;
+            const int tile_row0 = rbx * 128 + rt[i] * 16;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int grow = min(tile_row0 + r, M - 1);

@@ -1,5 +1,9 @@
 // board_pass_probe.hip — times k_board_pass (play → result → movegen count → encode) on 2^20 positions reached by
 // pseudo-random play on the device, with components removed (-DBOARD_PROBE bit mask: 1 no result, 2 no movegen, 4 no encode).
+// (round 5: the BOARD_PROBE masks were removed from the product kernel — commit 6da8f61 has them; this program now times the shipped kernel)
+#ifndef BOARD_PROBE
+#define BOARD_PROBE 0
+#endif
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include "../../tak_amd/csrc/board_kernels.hip"

@@ -1,6 +1,10 @@
 // One stand-alone 3×3 layer of the training step (k_conv_halo, 128 → 128 on 5×5, 4000 positions) with parts removed:
 // -DTG_CONV_PROBE=mask (1 = no main loop, 2 = no input rows, 4 = no output) shows what the single workgroup per CU cannot hide.
 // hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DTG_CONV_PROBE=0 -I../../tak_amd/csrc conv_halo_probe.hip -o _bin/conv_halo_probe
+// (round 5: the TG_CONV_PROBE masks were removed from the product kernel — commit 6da8f61 has them; this program now times the shipped kernel)
+#ifndef TG_CONV_PROBE
+#define TG_CONV_PROBE 0
+#endif
 #include <cstdio>
 #include <vector>
 #include <algorithm>

@@ -1,6 +1,6 @@
 #!/bin/bash
-# k_fc_ring with parts removed or reduced (-DTG_RING_PROBE=mask, wrong results): what each candidate change of the policy FC is
-# worth before it is built.  Builds one libtakgpu per mask into scripts/probes/_bin/, runs scripts/ab_forward.py c2 on each under
+# Library variants of net_kernels.hip built with -D flags (EXTRA_DEFS / PROBE_MACRO=value; round 4 used the TG_RING_PROBE masks that
+# commit 6da8f61 still carried — removed from the product in round 5): what each candidate change of the policy FC is worth.  Builds one libtakgpu per mask into scripts/probes/_bin/, runs scripts/ab_forward.py c2 on each under
 # rocprofv3 --kernel-trace --stats and prints the average k_fc_ring launch.  Run on the GPU box:
 #   bash scripts/probes/fc_ring_probe.sh "0 64 128 192"
 set -u

@@ -1,5 +1,9 @@
 // fc_s3_probe.hip — times k_fc_s3b (split-bf16 policy FC, C2 shape: 4096 x 1600 -> 1575) with parts removed.
 //   -DFC_PROBE: 0 normal · 1 no MFMAs · 2 no activation loads · 3 no weight staging (LDS written once) · 4 = 1 + 2 + 3
+// (round 5: the FC_PROBE masks were removed from the product kernel — commit 6da8f61 has them; this program now times the shipped kernel)
+#ifndef FC_PROBE
+#define FC_PROBE 0
+#endif
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include "../../tak_amd/csrc/net_s3_kernels.hip"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # k_fc_s3_ring (split-bf16 policy FC, LDS-DMA ring) with parts removed / other wave counts: builds libtakgpu variants of
 # net_s3_kernels.hip with the given -D flags and times the FC under rocprofv3 (scripts/ab_forward.py c2, TG_PRECISION=bf16x3).
-#   bash scripts/probes/s3_fc_ab.sh "-DTG_FSR_PROBE=1" "-DTG_FSR_NW=4" ...      ("" = the product build)
+#   bash scripts/probes/s3_fc_ab.sh "" "-DTG_FSR_NW=4" ...      ("" = the product build; the TG_FSR_PROBE masks of round 4 lived in commit 6da8f61)
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 B=$R/scripts/probes/_bin; O=$R/gpurun_out/s3ab; mkdir -p $B $O

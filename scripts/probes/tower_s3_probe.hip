@@ -3,6 +3,10 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DS3_PROBE=<v> -I tak_amd/csrc scripts/probes/tower_s3_probe.hip -o /tmp/p<v>
 // variants: 0 normal · 1 no epilogue store/skip (image untouched) · 2 weights of chunk 0 reused (no weight stream)
 //           3 activations of one LDS slot reused (no per-chunk ds_read) · 4 no MFMAs · 5 = 4 + 2 · 6 = 4 + 2 + 3
+// (round 5: the S3_PROBE masks were removed from the product kernel — commit 6da8f61 has them; this program now times the shipped kernel)
+#ifndef S3_PROBE
+#define S3_PROBE 0
+#endif
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

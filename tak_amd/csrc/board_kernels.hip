@@ -119,18 +119,13 @@ __global__ __launch_bounds__(256) void k_board_pass(const uint8_t* __restrict__ 
     WState s;
     ws_load(s, states + (size_t)gi * g.bytes, g);
     ws_play(s, uni((uint32_t)moves[gi]), g);
-#ifndef BOARD_PROBE
-#define BOARD_PROBE 0  // scripts/probes/board_pass_probe.hip: bit 0 no result, bit 1 no movegen count, bit 2 no encode
-#endif
-    uint32_t r = (BOARD_PROBE & 1) ? (uint32_t)TG_ONGOING : ws_result(s, g);
-    int c = (r == TG_ONGOING && !(BOARD_PROBE & 2)) ? ws_movegen(s, g, 0, [](int, uint32_t) {}) : 0;
+    uint32_t r = ws_result(s, g);
+    int c = r == TG_ONGOING ? ws_movegen(s, g, 0, [](int, uint32_t) {}) : 0;
     ws_store(s, out_states + (size_t)gi * g.bytes, g);
     // CS: the planes' row stride as a constant (the launcher instantiates the unpadded row of the micro-benchmark, 72 / 92
     // channels, and the 16-channel-padded one the per-layer conv kernels read)
-    if (!(BOARD_PROBE & 4)) {
-        if (CS) ws_encode<true, CS>(s, g, planes + (size_t)gi * CS * g.nsq, CS);
-        else ws_encode<true>(s, g, planes + (size_t)gi * cstride * g.nsq, cstride);
-    }
+    if (CS) ws_encode<true, CS>(s, g, planes + (size_t)gi * CS * g.nsq, CS);
+    else ws_encode<true>(s, g, planes + (size_t)gi * cstride * g.nsq, cstride);
     if (lane_id() == 0) { results[gi] = (uint8_t)r; counts[gi] = c; }
 }
 

@@ -78,11 +78,6 @@ __device__ __forceinline__ void conv_mainloop(const f32x4* __restrict__ lds4, co
     // that they fill MFMAs t = 0 … last_t − 1 of the chunk completely (conv_last_chunk_perm); the others would multiply
     // the zero padding and are skipped.
     static_assert(NM >= RTW, "tap masks for every row tile");
-    // TG_PROBE (scripts/probes/tower_stamps.hip only): bit 0 = every tap reads its shifted row (no zero-row reads),
-    // bit 1 = no weight stream (w0 reused), bit 2 = no tap switch (offsets of tap 0 throughout).  Wrong results, same shape.
-#ifndef TG_PROBE
-#define TG_PROBE 0
-#endif
     constexpr int total = 9 * CH;
     constexpr int H1 = (RTW + 1) / 2;
     const int zero4 = rows * LS4 + q;
@@ -92,7 +87,7 @@ __device__ __forceinline__ void conv_mainloop(const f32x4* __restrict__ lds4, co
     {
         const int sh = tap_shift(0);
 #pragma unroll
-        for (int j = 0; j < RTW; j++) aoff[j] = ((vmask[j] & 1) || (TG_PROBE & 1)) ? base0 + j * 16 * LS4 + (sh < 0 && (TG_PROBE & 1) ? 0 : sh) : zero4;
+        for (int j = 0; j < RTW; j++) aoff[j] = (vmask[j] & 1) ? base0 + j * 16 * LS4 + sh : zero4;
     }
     f32x4 a[RTW];
 #pragma unroll
@@ -100,20 +95,14 @@ __device__ __forceinline__ void conv_mainloop(const f32x4* __restrict__ lds4, co
     f32x4 w0 = wp[0];
     f32x4 w1 = wp[wstride4];
     int kk = 0;
-#if defined(TG_UNROLL_TAPS) && TG_UNROLL_TAPS == 9
-#pragma unroll
-#elif defined(TG_UNROLL_TAPS) && TG_UNROLL_TAPS == 3
-#pragma unroll 3
-#else
 #pragma unroll 1
-#endif
     for (int tap = 0; tap < 9; tap++) {
 #pragma unroll
         for (int kc = 0; kc < CH; kc++) {
-            if (kc == 0 && tap > 0 && !(TG_PROBE & 4)) {
-                const int sh = (TG_PROBE & 1) ? (tap % 3) * LS4 : tap_shift(tap);
+            if (kc == 0 && tap > 0) {
+                const int sh = tap_shift(tap);
 #pragma unroll
-                for (int j = H1; j < RTW; j++) aoff[j] = (((vmask[j] >> tap) & 1) || (TG_PROBE & 1)) ? base0 + j * 16 * LS4 + sh : zero4;
+                for (int j = H1; j < RTW; j++) aoff[j] = ((vmask[j] >> tap) & 1) ? base0 + j * 16 * LS4 + sh : zero4;
             }
 #pragma unroll
             for (int j = H1; j < RTW; j++) a[j] = lds4[aoff[j] + kc * 4];
@@ -126,15 +115,15 @@ __device__ __forceinline__ void conv_mainloop(const f32x4* __restrict__ lds4, co
                 }
             __builtin_amdgcn_sched_barrier(0);
             const int k2 = kk + 2 < total ? kk + 2 : total - 1;
-            const f32x4 w2 = (TG_PROBE & 2) ? w0 : wp[(size_t)k2 * wstride4];
+            const f32x4 w2 = wp[(size_t)k2 * wstride4];
             if (kc + 1 < CH) {
 #pragma unroll
                 for (int j = 0; j < H1; j++) a[j] = lds4[aoff[j] + (kc + 1) * 4];
             } else if (tap + 1 < 9) {
-                const int sh = (TG_PROBE & 1) ? ((tap + 1) % 3) * LS4 : tap_shift(tap + 1);
+                const int sh = tap_shift(tap + 1);
 #pragma unroll
                 for (int j = 0; j < H1; j++)
-                    if (!(TG_PROBE & 4)) aoff[j] = (((vmask[j] >> (tap + 1)) & 1) || (TG_PROBE & 1)) ? base0 + j * 16 * LS4 + sh : zero4;
+                    aoff[j] = ((vmask[j] >> (tap + 1)) & 1) ? base0 + j * 16 * LS4 + sh : zero4;
 #pragma unroll
                 for (int j = 0; j < H1; j++) a[j] = lds4[aoff[j]];
             }

@@ -48,27 +48,9 @@ void launch_perft_expand(hipStream_t st, const uint8_t* states, int count, int n
 // in k_col_reduce's layout part[(row·2 + {0, 1})·CoutP + channel] — Σz and Σz² (BatchNorm's batch statistics, training forward), or,
 // with bnb set (the data-gradient convolution: the output is dy of the layer below), that layer's BatchNorm-backward sums Σg, Σg·x̂
 struct ConvBnBwdIn { const float* y; const float* z; const float* mean; const float* invstd; };  // of the layer BELOW, rows as the output's
-// ConvInFuse (round 4; the halo kernel only — ask conv3x3_fuses_input first): the workgroup applies a BatchNorm pass of the training
-// step to the rows it stages, instead of a kernel of its own in front of the convolution —
-//   mode 1, forward:  in = z of the layer below;  y = relu((z − mean)·invstd·gamma + beta (+ skip))  (k_bn_fwd_apply's arithmetic) is
-//                     what the convolution reads and what out_act receives;
-//   mode 2, backward: in = dy;  g = dy·[y > 0],  dz = (gamma·invstd)·(g − mean_g − x̂·mean_gx)  (k_bn_bwd_apply_sum's arithmetic) is
-//                     what the data-gradient convolution reads and what out_act receives (the weight gradient reads it there);
-//                     out_gskip (optional) receives g; colsum_part receives dz's column sums as doubles, one partial row per wave:
-//                     part[((blockIdx.x·waves + wave)·2)·F + channel] (the bias gradient of the convolution in front of the BatchNorm).
-struct ConvInFuse {
-    int mode;
-    const float *mean, *invstd, *gamma, *beta, *skip, *y, *z;
-    const double *mean_g, *mean_gx;
-    float *out_act, *out_gskip;
-    double* colsum_part;
-    int colsum_rows;  // out: partial rows written (launch_conv3x3 fills it in)
-};
-bool conv3x3_fuses_input(int M, int n, int Cpad, int CoutP);
 hipError_t launch_conv3x3(hipStream_t st, const float* in, const float* Wp, const float* bias, const float* res, float* out,
                           int M, int n, int Cpad, int CoutP, int out_stride, int cout_valid, bool relu,
-                          double* stats_part = nullptr, int* stats_blocks = nullptr, const ConvBnBwdIn* bnb = nullptr,
-                          ConvInFuse* fuse = nullptr);
+                          double* stats_part = nullptr, int* stats_blocks = nullptr, const ConvBnBwdIn* bnb = nullptr);
 // mean, 1/σ and the running statistics from such partial rows (Σz, Σz² in double): replaces launch_bn_stats' two passes over z
 hipError_t launch_bn_stats_from_partials(hipStream_t st, const double* part, int nblk, int M, int F, float eps, float momentum,
                                          float* mean, float* invstd, float* running_mean, float* running_var);
@@ -186,9 +168,6 @@ hipError_t launch_bn_bwd(hipStream_t st, const float* dy, const float* y, const 
                          float* grad_beta, float* dz, float* gskip, float* grad_conv_bias = nullptr,  // grad_conv_bias += column sums of dz
                          int sums_in_part = 0,   // > 0: Σg, Σg·x̂ already in `part` (that many partial rows, from launch_conv3x3's ConvBnBwdIn)
                          double* colsum_part = nullptr, int* colsum_rows = nullptr);  // dz's column-sum partials go there, not finalised
-hipError_t launch_bn_bwd_sums(hipStream_t st, const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
-                              int M, int F, double* part, double* mean_g, double* mean_gx, float* grad_gamma, float* grad_beta,
-                              int sums_in_part);
 hipError_t launch_colsum_finalize(hipStream_t st, const double* part, int rows, int F, int valid, float* grad);
 hipError_t launch_colsum_acc(hipStream_t st, const float* a, int M, int Fp, int valid, double* part, float* grad);
 hipError_t launch_policy_loss(hipStream_t st, const float* logits, int row_stride, bool conv_head, int nsq, int ch_stride, int P, int B,

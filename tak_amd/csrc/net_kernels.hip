@@ -702,15 +702,12 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower_halo(const float* __restr
 // Epilogue: + bias, + res (optional), ReLU (optional).  COT = CoutP / 16; blockIdx.y picks a group of CTW channel tiles.
 // ------------------------------------------------------------------------------------------------
 // PSC: the position stride of the halo image (tower_halo_geometry) as a constant — the zero-cell fill divides by it 19 000 times
-#ifndef TG_CONV_PROBE
-#define TG_CONV_PROBE 0  // timing probes (wrong results; scripts/probes/conv_halo_probe.hip): 1 = no main loop, 2 = no input rows, 4 = no output
-#endif
 template <int RTW, int NWAVES, int CH, int NB, int COT, int PSC>
 __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restrict__ in, const float* __restrict__ Wp,
                                                            const float* __restrict__ bias, const float* __restrict__ res,
                                                            float* __restrict__ out, const uint32_t* __restrict__ slotmap, int B, int PW,
                                                            int PS, int CTW, int out_stride, int cout_valid, int relu,
-                                                           double* __restrict__ stats_part, const ConvBnBwdIn bnb, const ConvInFuse fuse) {
+                                                           double* __restrict__ stats_part, const ConvBnBwdIn bnb) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     f32x4* lds4 = (f32x4*)lds;
     constexpr int n = NB, nsq = NB * NB, RS = NB + 1, LEAD = NB + 2, F4 = 4 * CH, P4 = 4 * CH + 1;
@@ -745,8 +742,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restri
     };
     const f32x4* src = (const f32x4*)(in + (size_t)pos0 * nsq * (16 * CH));
     const int total = rows * F4;
-    if (TG_CONV_PROBE & 2) {
-    } else if (fuse.mode == 0) {
+    {
         constexpr int UNR = 8;
         for (int base = 0; base < total; base += NWAVES * 64 * UNR) {
             f32x4 tmp[UNR];
@@ -759,91 +755,6 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restri
             for (int u = 0; u < UNR; u++) {
                 const int idx = base + u * NWAVES * 64 + tid;
                 if (idx < total) lds4[halo_cell(idx)] = tmp[u];
-            }
-        }
-    } else {
-        // Round 4 (training step): a BatchNorm pass over the rows being staged — kernels.h, ConvInFuse.  A thread stages the same four
-        // channels in every row (the block size is a multiple of the row's float4 count), so the per-channel constants sit in registers.
-        static_assert((NWAVES * 64) % F4 == 0 && (F4 == 16 || F4 == 32), "fused staging: one channel quad per thread");
-        const int cv = tid % F4;
-        const size_t g0 = (size_t)pos0 * nsq * F4;  // the workgroup's first row in the [rows][F] tensors, in float4
-        const f32x4 mu = ((const f32x4*)fuse.mean)[cv], is = ((const f32x4*)fuse.invstd)[cv], ga = ((const f32x4*)fuse.gamma)[cv];
-        constexpr int UNR = 4;
-        if (fuse.mode == 1) {
-            const f32x4 be = ((const f32x4*)fuse.beta)[cv];
-            const f32x4* sk = fuse.skip ? (const f32x4*)fuse.skip + g0 : src;
-            const bool has_skip = fuse.skip != nullptr;
-            f32x4* yo = (f32x4*)fuse.out_act + g0;
-            for (int base = 0; base < total; base += NWAVES * 64 * UNR) {
-                f32x4 a[UNR], b[UNR];
-#pragma unroll
-                for (int u = 0; u < UNR; u++) {
-                    const int idx = base + u * NWAVES * 64 + tid, ic = idx < total ? idx : total - 1;
-                    a[u] = src[ic];
-                    b[u] = sk[ic];
-                }
-#pragma unroll
-                for (int u = 0; u < UNR; u++) {
-                    const int idx = base + u * NWAVES * 64 + tid;
-                    if (idx < total) {
-                        f32x4 v = (a[u] - mu) * is * ga + be;  // k_bn_fwd_apply's expression, term for term
-                        if (has_skip) v += b[u];
-                        v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f);
-                        yo[idx] = v;
-                        lds4[halo_cell(idx)] = v;
-                    }
-                }
-            }
-        } else {
-            double mg[4], mgx[4], gi[4];
-#pragma unroll
-            for (int t = 0; t < 4; t++) { mg[t] = fuse.mean_g[4 * cv + t]; mgx[t] = fuse.mean_gx[4 * cv + t]; gi[t] = (double)(ga[t] * is[t]); }
-            const f32x4* yy = (const f32x4*)fuse.y + g0;
-            const f32x4* zz = (const f32x4*)fuse.z + g0;
-            f32x4* dzo = (f32x4*)fuse.out_act + g0;
-            f32x4* gso = fuse.out_gskip ? (f32x4*)fuse.out_gskip + g0 : nullptr;
-            f32x4 s1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            for (int base = 0; base < total; base += NWAVES * 64 * UNR) {
-                f32x4 a[UNR], b[UNR], c[UNR];
-#pragma unroll
-                for (int u = 0; u < UNR; u++) {
-                    const int idx = base + u * NWAVES * 64 + tid, ic = idx < total ? idx : total - 1;
-                    a[u] = src[ic];
-                    b[u] = yy[ic];
-                    c[u] = zz[ic];
-                }
-#pragma unroll
-                for (int u = 0; u < UNR; u++) {
-                    const int idx = base + u * NWAVES * 64 + tid;
-                    if (idx < total) {
-                        f32x4 g, o;
-#pragma unroll
-                        for (int t = 0; t < 4; t++) {  // k_bn_bwd_apply_sum's expression, term for term
-                            g[t] = b[u][t] > 0.0f ? a[u][t] : 0.0f;
-                            const float xh = (c[u][t] - mu[t]) * is[t];
-                            const double centred = (double)g[t] - mg[t] - (double)xh * mgx[t];
-                            o[t] = (float)(gi[t] * centred);
-                        }
-                        dzo[idx] = o;
-                        if (gso) gso[idx] = g;
-                        s1 += o;
-                        lds4[halo_cell(idx)] = o;
-                    }
-                }
-            }
-            // dz's column sums: a thread's rows in f32 (as the pass it replaces), then doubles over the lanes of the wave that hold the
-            // same channels; one partial row per wave
-            double d[4];
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                d[t] = (double)s1[t];
-                d[t] += __shfl_xor(d[t], 32);
-                if (F4 == 16) d[t] += __shfl_xor(d[t], 16);
-            }
-            if ((tid & 63) < F4) {
-                double* dst = fuse.colsum_part + ((size_t)(blockIdx.x * NWAVES + (tid >> 6)) * 2) * (4 * F4) + 4 * cv;
-#pragma unroll
-                for (int t = 0; t < 4; t++) dst[t] = d[t];
             }
         }
     }
@@ -868,23 +779,13 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restri
     }
     const int turn = (wave >> 2) & 1;
     TG_STAMP(0, 2);
-    if (TG_CONV_PROBE & 1) {
-#pragma unroll
-        for (int j = 0; j < RTW; j++) acc[j] = lds4[addr4[j] + LEAD * P4] + w0 + w1;
-    } else if (RTW > 1 && short_group) {
+    if (RTW > 1 && short_group) {
         f32x4 (&acs)[RTW - 1] = *reinterpret_cast<f32x4 (*)[RTW - 1]>(&acc[0]);
         conv_mainloop_halo<RTW - 1, CH, NB, RTW, COT>(lds4, Wp, Wp, wlane, addr4, acs, turn, w0, w1);
     } else {
         conv_mainloop_halo<RTW, CH, NB, RTW, COT>(lds4, Wp, Wp, wlane, addr4, acc, turn, w0, w1);
     }
     TG_STAMP(0, 3);
-    if (TG_CONV_PROBE & 4) {
-        f32x4 t = acc[0];
-#pragma unroll
-        for (int j = 1; j < RTW; j++) t += acc[j];
-        if (t[0] + t[1] + t[2] + t[3] == 12345.678f) out[tid] = t[0];
-        return;
-    }
     const int ch = ch0 + 4 * q;
     const f32x4 bv = *(const f32x4*)&bias[ch];
     // stats_part: Σ and Σ² of this lane's outputs, per channel — in double from the first add on: var = E[z²] − E[z]² loses
@@ -1043,7 +944,7 @@ constexpr int FC_PLANE = (FC_KSTEP / 16) * FC_CT * 16;  // 832 slots per k-quart
 // before they are needed and normally hold by then, so no wave waits out a round trip and the waves may drift half a step
 // apart instead of draining the MFMA pipe at a barrier every 17 k cycles.  Every output element is accumulated over k in the
 // same order by the same MFMA as in k_fc_small → identical logits bits (tests/test_gpu_net.py, batch independence).
-// What bounds it (TG_RING_PROBE, profiles/r04_b_fc_candidates.txt): with neither refills nor flags the loop is 17 µs shorter —
+// What bounds it (round 4's probe builds, profiles/r04_b_fc_candidates.txt): with neither refills nor flags the loop is 17 µs shorter —
 // the LDS-DMA pieces' issue slots beside the fragment reads and waves held back for a slower one; the MFMAs of the 88 padded
 // columns were 3.2 µs, the logits burst 3.7 µs.  Measured and discarded: a ninth wave that only fills the ring (8 – 10 µs
 // slower), non-temporal logits stores, the barrier version k_fc_lds (rounds 1 – 3: + 6 µs), a register-tiled FC without LDS
@@ -1051,9 +952,6 @@ constexpr int FC_PLANE = (FC_KSTEP / 16) * FC_CT * 16;  // 832 slots per k-quart
 // s_setprio 1 for waves 4-7 (−1 µs, inside the noise) or for waves 0-3 (0), and waves 4-7 issuing their share of a refill half a
 // step after waves 0-3 so that the two waves of a SIMD never issue LDS-DMA pieces at the same time (+ 11 µs: the older wave of
 // a SIMD runs ahead of the younger one anyway, and the later refill makes the younger one the workgroup's laggard).
-#ifndef TG_RING_PROBE
-#define TG_RING_PROBE 0  // timing probes (wrong results): 1 = no refills and no flags, 2 = no activation stream, 16 = flags only, 32 = refills only
-#endif
 constexpr int FC_RING = 3;
 constexpr int FC_RING_SLOTS = 4 * FC_PLANE;                                        // f32x4 slots per buffer (3328)
 constexpr size_t FC_RING_LDS = (size_t)FC_RING * FC_RING_SLOTS * 16 + 2 * FC_RING * sizeof(uint32_t);
@@ -1147,7 +1045,7 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wg + (size_t)step * step_slots + src0[u]),
                                                  (__attribute__((address_space(3))) void*)(wl + buf * FC_RING_SLOTS + (fwave + FILLERS * u) * 64), 16, 0, 0);
     };
-    auto aload = [&](int kc) { return ap[(size_t)((TG_RING_PROBE & 2) ? 0 : (kc < nchunks ? kc : nchunks - 1)) * achunk]; };
+    auto aload = [&](int kc) { return ap[(size_t)(kc < nchunks ? kc : nchunks - 1) * achunk]; };
     if (tid < 2 * FC_RING) flags[tid] = 0u;
     __syncthreads();
     fill(0, 0);
@@ -1199,7 +1097,7 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
         const f32x4* wb = wl + buf * FC_RING_SLOTS;
         // (the flags were read half a chunk ago, under the MFMAs: they normally hold already and nobody waits out a round trip)
         TG_FC_STAMP(step, 0);  // (diagnostic build only: scripts/probes/fc_ring_stamps.hip)
-        if (!(TG_RING_PROBE & (1 | 32)) && (int)__builtin_amdgcn_readfirstlane((int)early_ready) < FILLERS * (step / FC_RING + 1))
+        if ((int)__builtin_amdgcn_readfirstlane((int)early_ready) < FILLERS * (step / FC_RING + 1))
             fc_ring_wait(ready0 + 4 * buf, (uint32_t)FILLERS * (uint32_t)(step / FC_RING + 1));
         TG_FC_STAMP(step, 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -1224,18 +1122,18 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // … which, loads returning in order, covers last step's refill too
         // (leaving this wait to the compiler in the waves that issue no LDS-DMA: no change, 165.6 – 167.3 against 165.7 – 165.9 µs)
         TG_FC_STAMP(step, 3);
-        if (!(TG_RING_PROBE & (1 | 32)) && step >= 1 && step + 1 < nsteps && filler) fc_ring_signal(ready0 + 4 * ((step + 1) % FC_RING));
-        if (!(TG_RING_PROBE & 1) && step + 2 < nsteps && filler) {
-            if (!(TG_RING_PROBE & 32) && (int)__builtin_amdgcn_readfirstlane((int)early_done) < 8 * ((step + 2) / FC_RING))
+        if (step >= 1 && step + 1 < nsteps && filler) fc_ring_signal(ready0 + 4 * ((step + 1) % FC_RING));
+        if (step + 2 < nsteps && filler) {
+            if ((int)__builtin_amdgcn_readfirstlane((int)early_done) < 8 * ((step + 2) / FC_RING))
                 fc_ring_wait(done0 + 4 * ((step + 2) % FC_RING), 8u * (uint32_t)((step + 2) / FC_RING));
             TG_FC_STAMP(step, 4);
-            if (!(TG_RING_PROBE & 16)) fill(step + 2, (step + 2) % FC_RING);
+            fill(step + 2, (step + 2) % FC_RING);
         }
         TG_FC_STAMP(step, 5);
         __builtin_amdgcn_sched_barrier(0);
         TG_FC_CHUNK(2, a2, true, (void)0)
         TG_FC_CHUNK(3, a3, false, early_ready = flag_lds[(step + 1) % FC_RING])
-        if (!(TG_RING_PROBE & (1 | 32))) fc_ring_signal(done0 + 4 * buf);
+        fc_ring_signal(done0 + 4 * buf);
         TG_FC_STAMP(step, 6);
         a0 = b0;
         a1 = b1;
@@ -1279,10 +1177,8 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
         // step behind); every LDS-DMA into them landed steps ago.  The laggard of the workgroup never waits here.
         const int bA = nsteps % FC_RING, bB = (nsteps + 1) % FC_RING;
         auto uses = [&](int b) { return b < nsteps ? (nsteps - b + FC_RING - 1) / FC_RING : 0; };
-        if (!(TG_RING_PROBE & (1 | 32))) {
-            fc_ring_wait(done0 + 4 * bA, 8u * (uint32_t)uses(bA));
-            fc_ring_wait(done0 + 4 * bB, 8u * (uint32_t)uses(bB));
-        }
+        fc_ring_wait(done0 + 4 * bA, 8u * (uint32_t)uses(bA));
+        fc_ring_wait(done0 + 4 * bB, 8u * (uint32_t)uses(bB));
         constexpr int RP = FC_CT * 16;  // floats per parked row (208)
         float* park[2] = {(float*)(wl + bA * FC_RING_SLOTS) + wave * (8 * RP), (float*)(wl + bB * FC_RING_SLOTS) + wave * (8 * RP)};
         {
@@ -1614,7 +1510,7 @@ static const uint32_t* conv_halo_slotmap(int n, int F, int pw, int ps) {
 template <int RTW, int NWAVES, int CH, int NB, int COT, int PSC>
 static hipError_t launch_conv_halo_t(hipStream_t st, const float* in, const float* Wp, const float* bias, const float* res, float* out,
                                      const uint32_t* slotmap, int B, int PW, int PS, int CTW, int out_stride, int cout_valid, bool relu,
-                                     double* stats_part, int* stats_blocks, const ConvBnBwdIn* bnb, ConvInFuse* fuse) {
+                                     double* stats_part, int* stats_blocks, const ConvBnBwdIn* bnb) {
     if (PS != PSC) return hipErrorInvalidValue;
     const size_t lds = (size_t)(NB + 2 + PW * PS + 1) * (16 * CH + 4) * sizeof(float);
     static LdsAttr lds_attr;
@@ -1624,46 +1520,30 @@ static hipError_t launch_conv_halo_t(hipStream_t st, const float* in, const floa
     ConvBnBwdIn bn{nullptr, nullptr, nullptr, nullptr};
     if (bnb && stats_part && out_stride == 16 * COT) bn = *bnb;  // (y and z share the output's row layout)
     else if (bnb) stats_part = nullptr;
-    ConvInFuse fz{};
-    if (fuse) {  // (a second workgroup column would stage — and write — the same rows again)
-        if (grid.y != 1 || fuse->mode < 1 || fuse->mode > 2) return hipErrorInvalidValue;
-        fuse->colsum_rows = fuse->mode == 2 ? (int)grid.x * NWAVES : 0;
-        fz = *fuse;
-    }
     hipLaunchKernelGGL((k_conv_halo<RTW, NWAVES, CH, NB, COT, PSC>), grid, dim3(NWAVES * 64), lds, st, in, Wp, bias, res, out, slotmap, B, PW, PS,
-                       CTW, out_stride, cout_valid, relu ? 1 : 0, stats_part, bn, fz);
+                       CTW, out_stride, cout_valid, relu ? 1 : 0, stats_part, bn);
     if (stats_blocks) *stats_blocks = stats_part ? (int)grid.x * (NWAVES / CTW) : 0;
     return hipGetLastError();
 }
 
-// the shapes launch_conv3x3 hands to k_conv_halo with ONE workgroup column (ConvInFuse: the staging of a second column would repeat the pass)
-bool conv3x3_fuses_input(int M, int n, int Cpad, int CoutP) {
-    static const bool off = getenv("TG_NO_HALO_CONV") != nullptr;
-    int pw, ps;
-    if (off || M / (n * n) < 1024 || !tower_halo_geometry(n, Cpad, &pw, &ps)) return false;
-    return (n == 5 && Cpad == 64 && CoutP == 64) || (n == 5 && Cpad == 128 && CoutP == 128) || (n == 6 && Cpad == 128 && CoutP == 128);
-}
-
 hipError_t launch_conv3x3(hipStream_t st, const float* in, const float* Wp, const float* bias, const float* res, float* out,
                           int M, int n, int Cpad, int CoutP, int out_stride, int cout_valid, bool relu, double* stats_part,
-                          int* stats_blocks, const ConvBnBwdIn* bnb, ConvInFuse* fuse) {
+                          int* stats_blocks, const ConvBnBwdIn* bnb) {
     const int B = M / (n * n);
     if (stats_blocks) *stats_blocks = 0;
-    if (fuse && !conv3x3_fuses_input(M, n, Cpad, CoutP)) return hipErrorInvalidValue;
     {   // F → F (and F → 2F) layers of the BASELINE topologies at full batches: the halo image (k_conv_halo), same bits as k_conv_pos
         static const bool off = getenv("TG_NO_HALO_CONV") != nullptr;
         int pw, ps;
         if (!off && B >= 1024 && tower_halo_geometry(n, Cpad, &pw, &ps)) {
             const uint32_t* map = conv_halo_slotmap(n, Cpad, pw, ps);
             if (map) {
-                if (n == 5 && Cpad == 64 && CoutP == 64) return launch_conv_halo_t<13, 8, 4, 5, 4, 36>(st, in, Wp, bias, res, out, map, B, pw, ps, 4, out_stride, cout_valid, relu, stats_part, stats_blocks, bnb, fuse);
-                if (n == 5 && Cpad == 128 && CoutP == 128) return launch_conv_halo_t<13, 8, 8, 5, 8, 37>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu, stats_part, stats_blocks, bnb, fuse);
-                if (n == 6 && Cpad == 128 && CoutP == 128) return launch_conv_halo_t<9, 8, 8, 6, 8, 51>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu, stats_part, stats_blocks, bnb, fuse);
-                if (n == 6 && Cpad == 128 && CoutP == 256) return launch_conv_halo_t<9, 8, 8, 6, 16, 51>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu, stats_part, stats_blocks, bnb, fuse);
+                if (n == 5 && Cpad == 64 && CoutP == 64) return launch_conv_halo_t<13, 8, 4, 5, 4, 36>(st, in, Wp, bias, res, out, map, B, pw, ps, 4, out_stride, cout_valid, relu, stats_part, stats_blocks, bnb);
+                if (n == 5 && Cpad == 128 && CoutP == 128) return launch_conv_halo_t<13, 8, 8, 5, 8, 37>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu, stats_part, stats_blocks, bnb);
+                if (n == 6 && Cpad == 128 && CoutP == 128) return launch_conv_halo_t<9, 8, 8, 6, 8, 51>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu, stats_part, stats_blocks, bnb);
+                if (n == 6 && Cpad == 128 && CoutP == 256) return launch_conv_halo_t<9, 8, 8, 6, 16, 51>(st, in, Wp, bias, res, out, map, B, pw, ps, 8, out_stride, cout_valid, relu, stats_part, stats_blocks, bnb);
             }
         }
     }
-    if (fuse) return hipErrorInvalidValue;  // (only the halo kernel stages through ConvInFuse)
     // whole-positions kernel where the shape divides evenly (the BASELINE configs); generic tiles otherwise
     // small batches take fewer positions per workgroup (shorter critical path, same bits — see launch_tower)
 #define TG_CONV_POS(RTW, NW, PW, CTW) \

@@ -33,12 +33,6 @@
 #include "tower_cb.cuh"
 #include "kernels.h"
 
-#ifndef FC_PROBE
-#define FC_PROBE 0  // scripts/probes/fc_s3_probe.hip
-#endif
-#ifndef S3_PROBE
-#define S3_PROBE 0  // scripts/probes/tower_s3_probe.hip builds variants with parts of the kernel removed
-#endif
 
 namespace tg {
 
@@ -71,10 +65,6 @@ __device__ __forceinline__ float bf16_hi_f32(uint32_t pk) { return __uint_as_flo
 __device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& lo) {
     hi[0] = pk_bf16(v[0], v[1]);
     hi[1] = pk_bf16(v[2], v[3]);
-#if S3_PROBE == 7
-    lo[0] = lo[1] = 0u;
-    return;
-#endif
     lo[0] = pk_bf16(v[0] - bf16_lo_f32(hi[0]), v[1] - bf16_hi_f32(hi[0]));
     lo[1] = pk_bf16(v[2] - bf16_lo_f32(hi[1]), v[3] - bf16_hi_f32(hi[1]));
 }
@@ -113,30 +103,13 @@ __device__ __forceinline__ void s3_mainloop(const u32x4* __restrict__ lds4, cons
         for (int kc = 0; kc < KC; kc++) {
             const int kn = kk + 1 < total ? kk + 1 : kk;
             const u32x4* wn = wp + (size_t)kn * wstride;
-#if S3_PROBE == 2 || S3_PROBE == 5 || S3_PROBE == 6
-            const u32x4 nh0 = wh0, nl0 = wl0, nh1 = wh1, nl1 = wl1;
-            (void)wn;
-#else
             const u32x4 nh0 = wn[0], nl0 = wn[64], nh1 = wn[t1], nl1 = wn[t1 + 64];
-#endif
             u32x4 ah[NT], al[NT];
 #pragma unroll
             for (int j = 0; j < NT; j++) {
-#if S3_PROBE == 3 || S3_PROBE == 6
-                ah[j] = wh0 ^ u32x4{(uint32_t)j, (uint32_t)kc, 0u, 0u};
-                al[j] = wl0 ^ u32x4{(uint32_t)j, (uint32_t)kc, 0u, 0u};
-#else
                 ah[j] = lds4[aoff[j] + kc * 8];
                 al[j] = lds4[aoff[j] + kc * 8 + 4];
-#endif
             }
-#if S3_PROBE == 4 || S3_PROBE == 5 || S3_PROBE == 6
-#pragma unroll
-            for (int j = 0; j < NT; j++) {
-                acc[j][0][0] += __uint_as_float(ah[j][0] ^ wh0[0] ^ wl0[1]);
-                acc[j][1][0] += __uint_as_float(al[j][0] ^ wh1[0] ^ wl1[1]);
-            }
-#else
 #pragma unroll
             for (int j = 0; j < NT; j++) {
                 acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wh0), as_bf(ah[j]), acc[j][0], 0, 0, 0);
@@ -152,7 +125,6 @@ __device__ __forceinline__ void s3_mainloop(const u32x4* __restrict__ lds4, cons
                 acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wl0), as_bf(ah[j]), acc[j][0], 0, 0, 0);
                 acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wl1), as_bf(ah[j]), acc[j][1], 0, 0, 0);
             }
-#endif
             wh0 = nh0; wl0 = nl0; wh1 = nh1; wl1 = nl1;
             kk++;
         }
@@ -168,9 +140,6 @@ __device__ __forceinline__ void s3_mainloop(const u32x4* __restrict__ lds4, cons
 // half's 6·H MFMAs run; weights through a buffer descriptor, two steps ahead.  (Left to itself the compiler sinks every
 // load to just before its first use to save registers and each wave then waits out the LDS and L2 latencies.  s_setprio
 // turns between the two waves of a SIMD, which pay in the f32 kernel, made no difference here.)
-#ifndef TG_S3_PROBE
-#define TG_S3_PROBE 0  // timing probes (wrong results): 1 = no fragment reads in the loop, 2 = no weight loads in the loop
-#endif
 struct S3W { u32x4 h0, l0, h1, l1; };  // one step of weights of a wave: hi / lo halves of its two 16-channel tiles
 // step kk of a layer at byte kk·wstep; inside a step this lane's four 16-byte slots 1 KB apart
 __device__ __forceinline__ S3W s3_load_w(const void* wlayer, int bytes, uint32_t wlane, int so) {
@@ -209,22 +178,17 @@ __device__ __forceinline__ void s3_mainloop_halo(const u32x4* __restrict__ lds4,
 #pragma unroll
     for (int j = 0; j < NT; j++) ad[j] = addr4[j];
 #pragma unroll
-    for (int j = 0; j < (TG_S3_PROBE & 1 ? NT : H1); j++) { ah[j] = lds4[ad[j] + TG_S3_OFF(0)]; al[j] = lds4[ad[j] + TG_S3_OFF(0) + 4]; }
+    for (int j = 0; j < H1; j++) { ah[j] = lds4[ad[j] + TG_S3_OFF(0)]; al[j] = lds4[ad[j] + TG_S3_OFF(0) + 4]; }
     int wchunk = 2;  // next step of weights to request
 #pragma unroll 1
     for (int dy = 0; dy < 3; dy++) {
 #pragma unroll
         for (int s = 0; s < ROW; s++) {
-#if !(TG_S3_PROBE & 1)
 #pragma unroll
             for (int j = H1; j < NT; j++) { ah[j] = lds4[ad[j] + TG_S3_OFF(s)]; al[j] = lds4[ad[j] + TG_S3_OFF(s) + 4]; }
-#endif
             __builtin_amdgcn_sched_barrier(0);
             TG_S3_MFMA(0, H1)
             __builtin_amdgcn_sched_barrier(0);
-#if TG_S3_PROBE & 2
-            const S3W w2 = w0;
-#else
             S3W w2;
             if (s < ROW - 2) {
                 w2 = s3_load_w(wlayer, total * wstep, wlane, wchunk * wstep);
@@ -232,15 +196,8 @@ __device__ __forceinline__ void s3_mainloop_halo(const u32x4* __restrict__ lds4,
                 const bool on = dy == 2;
                 w2 = s3_load_w(on ? wnext : wlayer, total * wstep, wlane, (on ? s - (ROW - 2) : wchunk) * wstep);
             }
-#endif
             wchunk++;
-#if TG_S3_PROBE & 1
-            if (false) {
-            } else if (s + 1 < ROW) {
-            } else if (false) {
-#else
             if (s + 1 < ROW) {
-#endif
 #pragma unroll
                 for (int j = 0; j < H1; j++) { ah[j] = lds4[ad[j] + TG_S3_OFF(s + 1)]; al[j] = lds4[ad[j] + TG_S3_OFF(s + 1) + 4]; }
             } else {
@@ -426,7 +383,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3(const voi
 #pragma unroll
             for (int t = 0; t < 2; t++) {
                 nxt[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (S3_PROBE != 1 && conv1 && rho0 + j * 16 < rows) {
+                if (conv1 && rho0 + j * 16 < rows) {
                     const int c = ch0 + 8 * q + 4 * t;
                     const u32x2* p = (const u32x2*)(lds4 + (size_t)(rho0 + j * 16) * LS4n + (c >> 5) * 8 + ((c & 31) >> 3)) + ((c & 7) >> 2);
                     nxt[j][t] = join4(p[0], p[8]);  // hi slot, lo slot (+4 slots = 64 B)
@@ -437,7 +394,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_tower_s3(const voi
         for (int j = 0; j < RTW; j++)
 #pragma unroll
             for (int t = 0; t < 2; t++)
-                if (S3_PROBE != 1 && rho0 + j * 16 < rows) {
+                if (rho0 + j * 16 < rows) {
                     const int c = ch0 + 8 * q + 4 * t;
                     u32x2 hi, lo;
                     split4(acc[j][t], hi, lo);
@@ -982,8 +939,8 @@ __global__ __launch_bounds__(NW * 64) void k_fc_s3b(const u32x4* __restrict__ A,
     for (int step = 0; step < nsteps; step++) {
         const int buf = step & 1;
         const int nx = step + 1 < nsteps ? step + 1 : step;
-        if (FC_PROBE != 3 && FC_PROBE != 4) stage_load(nx, stg);
-        if (FC_PROBE != 2 && FC_PROBE != 4) load_a(nx, an);
+        stage_load(nx, stg);
+        load_a(nx, an);
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             const u32x4* wh = &wl[buf][((c * 4 + q) * 2 + 0) * COLS + r16];
@@ -991,12 +948,6 @@ __global__ __launch_bounds__(NW * 64) void k_fc_s3b(const u32x4* __restrict__ A,
             u32x4 w_h[CT], w_l[CT];
 #pragma unroll
             for (int j = 0; j < CT; j++) { w_h[j] = wh[j * 16]; w_l[j] = wo[j * 16]; }
-#if FC_PROBE == 1 || FC_PROBE == 4
-#pragma unroll
-            for (int j = 0; j < CT; j++)
-#pragma unroll
-                for (int p = 0; p < 2; p++) acc[p][j][0] += __uint_as_float(w_h[j][0] ^ w_l[j][1] ^ ac[c][p][0][0] ^ ac[c][p][1][1]);
-#else
 #pragma unroll
             for (int j = 0; j < CT; j++) {
 #pragma unroll
@@ -1006,9 +957,8 @@ __global__ __launch_bounds__(NW * 64) void k_fc_s3b(const u32x4* __restrict__ A,
 #pragma unroll
                 for (int p = 0; p < 2; p++) acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(w_l[j]), as_bf(ac[c][p][0]), acc[p][j], 0, 0, 0);
             }
-#endif
         }
-        if (FC_PROBE != 3 && FC_PROBE != 4) stage_store(buf ^ 1, stg);
+        stage_store(buf ^ 1, stg);
 #pragma unroll
         for (int c = 0; c < 2; c++)
 #pragma unroll
@@ -1043,10 +993,12 @@ __global__ __launch_bounds__(NW * 64) void k_fc_s3b(const u32x4* __restrict__ A,
 // k_fc_s3_ring (round 4) — the policy FC on split operands with k_fc_ring's structure (net_kernels.hip): 128 rows × (12 main + 1
 // leftover) output tiles per workgroup, 32 × 8 workgroups, the 99 tiles and the statistics geometry of softmax.cuh, the weights
 // of a K-step of 64 (2 chunks of 32 × 13 tile slots × hi | lo = 52 blocks of 1 KB) through a three-buffer LDS-DMA ring with flag
-// counters, statistics + value pre-activation + logits rows or the children's logits from the epilogue.  What differs: FOUR waves
-// (one per SIMD), each with TWO row tiles (a weight fragment pair feeds 6 MFMAs; with one row tile per wave the 26 ds_read_b128
-// per 39 MFMAs of 16 cycles would take two thirds of the LDS's cycles), `v_mfma_f32_16x16x32_bf16`, three per product in the order
-// of k_fc_s3b (w_hi·a_hi, w_hi·a_lo, w_lo·a_hi per chunk, chunks ascending) → the same logits bits as k_fc_s3b, which keeps
+// counters, statistics + value pre-activation + logits rows or the children's logits from the epilogue.  What differs:
+// `v_mfma_f32_16x16x32_bf16`, three per product, and ALL EIGHT waves (two per SIMD, one row tile each — the shipped TG_FSR_NW = 8:
+// 62 – 66 µs) issue the refills: at the bf16 rate a K-step's MFMAs are no longer than a refill's 13 pieces, so leaving the refills to the
+// younger wave of every SIMD, as k_fc_ring does, costs 90 µs.  (TG_FSR_NW = 4 builds the variant with FOUR waves of two row tiles each —
+// a weight fragment pair then feeds 6 MFMAs and the LDS serves half the fragment reads per MFMA; measured no faster, r04_b §6.)
+// Products in the order of k_fc_s3b (w_hi·a_hi, w_hi·a_lo, w_lo·a_hi per chunk, chunks ascending) → the same logits bits as k_fc_s3b, which keeps
 // serving ≤ 512 rows (statistics behind it by k_fc_stats).  k_fc_s3b moved 737 MB per launch through the CUs' vector-memory ports
 // (every 4-wave workgroup of 128 × 112 staged its weights through registers and read its activations straight from global: MFMA
 // busy 0.36); here a CU takes in 1.33 MB of weights by LDS-DMA and 0.82 MB of activations.
@@ -1055,9 +1007,6 @@ __global__ __launch_bounds__(NW * 64) void k_fc_s3b(const u32x4* __restrict__ A,
 #ifndef TG_FSR_NW
 #define TG_FSR_NW 8
 #endif
-#ifndef TG_FSR_PROBE
-#define TG_FSR_PROBE 0  // timing probes (wrong results): 1 = no refills and no flags, 2 = no activation stream, 4 = half the LDS fragment reads
-#endif
 constexpr int FSR_NW = TG_FSR_NW;                           // waves per workgroup (4: one per SIMD, two row tiles each; 8: two per SIMD, one row tile each)
 constexpr int FSR_RT = 8 / FSR_NW;                          // row tiles per wave
 constexpr int FSR_CT = FC_MAIN_TILES + 1;                   // 13 tile slots
@@ -1065,8 +1014,7 @@ constexpr int FSR_BLOCKS = 2 * FSR_CT * 2;                  // 1 KB blocks per K
 constexpr int FSR_SLOTS = FSR_BLOCKS * 64;                  // 3328 slots per buffer
 constexpr int FSR_RING = 3;
 constexpr size_t FSR_LDS = (size_t)FSR_RING * FSR_SLOTS * 16 + 2 * FSR_RING * sizeof(uint32_t);
-constexpr int FSR_FILLERS = FSR_NW;                         // waves that issue the refills: all of them (only the younger wave of every SIMD, as in k_fc_ring: 90 µs instead of 66 —
-                                                            // at the bf16 rate a K-step's MFMAs are no longer than the 13 pieces' issue)
+constexpr int FSR_FILLERS = FSR_NW;                         // waves that issue the refills: all of them (see above)
 constexpr int FSR_PER = (FSR_BLOCKS + FSR_FILLERS - 1) / FSR_FILLERS;  // blocks such a wave fills per K-step (13)
 
 __global__ __launch_bounds__(FSR_NW * 64) void k_fc_s3_ring(const u32x4* __restrict__ A, const u32x4* __restrict__ Wr, const float* __restrict__ bias,
@@ -1127,7 +1075,7 @@ __global__ __launch_bounds__(FSR_NW * 64) void k_fc_s3_ring(const u32x4* __restr
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wr + (size_t)step * step_slots + src0[u]),
                                                  (__attribute__((address_space(3))) void*)(wl + buf * FSR_SLOTS + (fwave + FSR_FILLERS * u) * 64), 16, 0, 0);
     };
-    auto aload = [&](int i, int kc, int lo) { return ap[i][(size_t)((TG_FSR_PROBE & 2) ? 0 : (kc < nchunks ? kc : nchunks - 1)) * 8 + 4 * lo]; };
+    auto aload = [&](int i, int kc, int lo) { return ap[i][(size_t)(kc < nchunks ? kc : nchunks - 1) * 8 + 4 * lo]; };
     if (tid < 2 * FSR_RING) flags[tid] = 0u;
     __syncthreads();
     fill(0, 0);
@@ -1149,7 +1097,7 @@ __global__ __launch_bounds__(FSR_NW * 64) void k_fc_s3_ring(const u32x4* __restr
     }
     constexpr int H1 = 7;
     u32x4 wh[FSR_CT], wo[FSR_CT];
-#define TG_FS_LOAD(C, J0, J1) _Pragma("unroll") for (int j = J0; j < J1; j++) { wh[j] = wb[(((C) * FSR_CT + j) * 2 + 0) * 64 + lane]; if (!(TG_FSR_PROBE & 4)) wo[j] = wb[(((C) * FSR_CT + j) * 2 + 1) * 64 + lane]; else wo[j] = wh[j]; }
+#define TG_FS_LOAD(C, J0, J1) _Pragma("unroll") for (int j = J0; j < J1; j++) { wh[j] = wb[(((C) * FSR_CT + j) * 2 + 0) * 64 + lane]; wo[j] = wb[(((C) * FSR_CT + j) * 2 + 1) * 64 + lane]; }
 // (the three products of an accumulator — hi·hi, hi·lo, lo·hi, in that order — are issued a whole tile group apart, not back to
 // back: with one row tile per wave consecutive MFMAs into the same accumulator waited out the matrix pipe's latency)
 #define TG_FS_MFMA(AV, J0, J1)                                                                                                              \
@@ -1186,7 +1134,7 @@ __global__ __launch_bounds__(FSR_NW * 64) void k_fc_s3_ring(const u32x4* __restr
     for (int step = 0; step < nsteps; step++) {
         const int buf = step % FSR_RING;
         const u32x4* wb = wl + buf * FSR_SLOTS;
-        if (!(TG_FSR_PROBE & 1) && (int)__builtin_amdgcn_readfirstlane((int)early_ready) < FSR_FILLERS * (step / FSR_RING + 1))
+        if ((int)__builtin_amdgcn_readfirstlane((int)early_ready) < FSR_FILLERS * (step / FSR_RING + 1))
             fc_ring_wait(ready0 + 4 * buf, (uint32_t)FSR_FILLERS * (uint32_t)(step / FSR_RING + 1));
         __builtin_amdgcn_sched_barrier(0);
         TG_FS_LOAD(0, 0, H1)
@@ -1212,7 +1160,7 @@ __global__ __launch_bounds__(FSR_NW * 64) void k_fc_s3_ring(const u32x4* __restr
         for (int i = 0; i < FSR_RT; i++) asm volatile("" : "+v"(a1[i][0]), "+v"(a1[i][1]), "+v"(b0[i][0]), "+v"(b0[i][1]));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (filler && step >= 1 && step + 1 < nsteps) fc_ring_signal(ready0 + 4 * ((step + 1) % FSR_RING));
-        if (!(TG_FSR_PROBE & 1) && filler && step + 2 < nsteps) {
+        if (filler && step + 2 < nsteps) {
             if ((int)__builtin_amdgcn_readfirstlane((int)early_done) < FSR_NW * ((step + 2) / FSR_RING))
                 fc_ring_wait(done0 + 4 * ((step + 2) % FSR_RING), (uint32_t)FSR_NW * (uint32_t)((step + 2) / FSR_RING));
             fill(step + 2, (step + 2) % FSR_RING);

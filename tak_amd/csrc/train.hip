@@ -25,6 +25,8 @@ struct Id128 { char bytes[128]; };  // ncclUniqueId
 namespace {
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
+// A/B switches: set and not "0"
+bool env_on(const char* name) { const char* v = getenv(name); return v && atoi(v) != 0; }
 
 struct ParamInfo {
     std::string name;
@@ -43,12 +45,10 @@ struct TrainConv {
     DevBuf wf, wb, bias_pad;                   // forward fragments, data-gradient fragments, padded bias
 };
 
-// Everything ONE chunk in flight owns (round 4): its inputs and targets, z / y of every layer, the heads' buffers, the backward
-// pass's scratch and workspaces, its two streams.  tg_train keeps two chunks in flight, one per lane; tg_train_chunk and
-// tg_train_forward use lane 0.
-struct Lane {
-    hipStream_t st = nullptr, wg = nullptr;  // the chain's stream (lane 0: the engine stream) and the weight gradients' stream
-    bool own_st = false;
+// Everything the chunk in flight owns: its inputs and targets, z / y of every layer, the heads' buffers, the backward pass's
+// scratch and workspaces, its two streams.
+struct Chunk {
+    hipStream_t st = nullptr, wg = nullptr;  // the chain's stream (the engine stream) and the weight gradients' stream
     // chunk inputs / targets
     DevBuf ex_states, ex_nmoves, ex_moves, ex_visits, states_aug, pi, zt, planes;
     std::vector<DevBuf> z, y;  // per conv layer: conv output, activation after BN / ReLU (/ skip)
@@ -58,26 +58,23 @@ struct Lane {
     DevBuf d_a, d_b, dz, dz2, gskip, stats, mean_g, mean_gx;
     DevBuf part_d, part_w;  // workspaces: the chain's double partials, the weight gradients' split-K partials
     DevBuf part_h;          // two halves: the heads' bias / value gradients' partials (weight gradients' stream)
-    DevBuf part_b[2];       // dz's column sums out of the data-gradient convolution's staging (ConvInFuse), alternating like dz
-    // ev_dz[k]: dz buffer k holds this layer's dz (chain → weight gradients); ev_head: the forward pass is complete.
-    // Per layer (index = layer; convs.size() = the heads), recorded behind the kernels of this lane's chunk that UPDATE state shared
-    // by all chunks — the other lane's next chunk waits for them before its own update of the same state, so every running
-    // statistic and every gradient tensor sees the chunks in their order, whatever the interleaving:
-    //   ev_fwd[l]   BatchNorm l's running statistics (forward),   ev_chain[l]  BatchNorm l's γ, β and the conv bias gradient
-    //   (index heads: policy bias, value weight / bias),           ev_wgl[l]    conv l's weight gradient (heads: the policy weights)
+    DevBuf part_b[2];       // dz's column sums (the conv bias gradient's partials), alternating like dz
+    // ev_dz[k]: dz buffer k holds this layer's dz (chain → weight gradients); ev_head: the forward pass is complete;
+    // ev_wgl[l]: conv l's weight gradient has read its dz buffer (index convs.size() = the heads)
     hipEvent_t ev_dz[2] = {nullptr, nullptr}, ev_head = nullptr;
-    std::vector<hipEvent_t> ev_fwd, ev_chain, ev_wgl;
-    // the chunk in flight (tg_train): issued, not yet collected
-    bool in_flight = false, wait_step = false;
+    std::vector<hipEvent_t> ev_wgl;
+    // tg_train_debug_capture: the backward pass of the next chunks keeps layer cap_layer's dy (gradient w.r.t. its activation,
+    // before the ReLU mask), dz and the data gradient it hands down
+    int cap_layer = -1;
+    DevBuf cap_dy, cap_dz, cap_dx;
+    // the chunk in flight: issued, not yet collected
+    bool in_flight = false;
     int B_flight = 0, did_step = 0;
-    Lane* other = nullptr;  // the lane whose chunk was issued just before this lane's current one (null: this lane itself, or none)
-    ~Lane() {
+    ~Chunk() {
         for (hipEvent_t ev : ev_dz) if (ev) (void)hipEventDestroy(ev);
         if (ev_head) (void)hipEventDestroy(ev_head);
-        for (auto* v : {&ev_fwd, &ev_chain, &ev_wgl})
-            for (hipEvent_t ev : *v) if (ev) (void)hipEventDestroy(ev);
+        for (hipEvent_t ev : ev_wgl) if (ev) (void)hipEventDestroy(ev);
         if (wg) (void)hipStreamDestroy(wg);
-        if (own_st && st) (void)hipStreamDestroy(st);
     }
 };
 
@@ -143,11 +140,7 @@ struct Trainer {
     // value head
     size_t val_w = 0, val_b = 0;
     DevBuf wv;
-    // chunks in flight: one lane by default, TG_TRAIN_LANES=2: two (built, bit-identical, no consistent gain: tg_train's comment)
-    Lane lane[2];
-    int n_lanes = 1;
-    Lane* prev = nullptr;          // the lane of the chunk issued last: the next chunk orders its updates behind that one's
-    hipEvent_t ev_step = nullptr;  // parameters updated and re-packed (recorded on the stream that ran the optimiser step)
+    Chunk chunk;
     DevBuf zero_bias;
     bool packed = false;
     uint64_t adam_t = 0;
@@ -163,16 +156,17 @@ struct Trainer {
     bool ar_pending = false;
     double ar_ms = 0.0;
     int64_t ar_count = 0;
-    void ar_fold() {
+    // wait = false (between two steps): never blocks the host — a pair that has not completed yet is dropped from the statistics
+    void ar_fold(bool wait = false) {
         if (!ar_pending) return;
         float ms = 0.0f;
-        if (hipEventSynchronize(ar_ev[1]) == hipSuccess && hipEventElapsedTime(&ms, ar_ev[0], ar_ev[1]) == hipSuccess) { ar_ms += ms; ar_count++; }
+        const bool done = wait ? hipEventSynchronize(ar_ev[1]) == hipSuccess : hipEventQuery(ar_ev[1]) == hipSuccess;
+        if (done && hipEventElapsedTime(&ms, ar_ev[0], ar_ev[1]) == hipSuccess) { ar_ms += ms; ar_count++; }
         ar_pending = false;
     }
     DevBuf err_flag;  // one float: the ranks agree on an argument error before the first chunk of tg_train
     ~Trainer() {
         for (hipEvent_t ev : ar_ev) if (ev) (void)hipEventDestroy(ev);
-        if (ev_step) (void)hipEventDestroy(ev_step);
         if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
     }
 };
@@ -230,83 +224,41 @@ int pack_params(TgEngine* e, hipStream_t st) {
     }
     TG_HIP(launch_pack_value(st, P + t->val_w, F, nsq, t->wv.as<float>()));
     t->packed = true;
-    // the packed copies are shared by the lanes: the others read them behind this event
-    TG_HIP(hipEventRecord(t->ev_step, st));
-    for (int i = 0; i < t->n_lanes; i++) t->lane[i].wait_step = t->lane[i].st != st;
-    return TG_OK;
-}
-
-// A chunk starts on lane w: behind the last optimiser step / re-packing if another stream ran it.  w.other = the lane whose chunk
-// was issued just before this one, when that is not w itself (same streams: already ordered) — see Lane's events.
-int lane_begin(TgEngine* e, Lane& w) {
-    Trainer* t = e->trainer;
-    if (w.wait_step) {
-        TG_HIP(hipStreamWaitEvent(w.st, t->ev_step, 0));
-        w.wait_step = false;
-    }
-    w.other = (t->prev && t->prev != &w) ? t->prev : nullptr;
-    t->prev = &w;
     return TG_OK;
 }
 
 // forward in training mode from the NHWC planes of B positions; fills z/y of every layer, logits, eval
-int forward_train(TgEngine* e, Lane& w, int B, bool with_targets, float* d_logp) {
+int forward_train(TgEngine* e, Chunk& w, int B, bool with_targets, float* d_logp) {
     Trainer* t = e->trainer;
     hipStream_t st = w.st;
     const int F = e->cfg.filters, nsq = e->g.nsq, N = e->g.n, M = B * nsq;
     float* P = t->params.as<float>();
     float* BN = t->bnbuf.as<float>();
     float* stats = w.stats.as<float>();
-    int rc = lane_begin(e, w);
+    int rc = pack_params(e, st);
     if (rc) return rc;
-    Lane* other = w.other;
-    rc = pack_params(e, st);
-    if (rc) return rc;
-    // TG_BN_FOLD=1 (round 4, built and measured, off by default): BatchNorm's apply pass y = relu(γ·x̂ + β (+ skip)) of layer l runs inside
-    // the staging of convolution l + 1 (the halo kernel at full chunks; ConvInFuse mode 1: same expression → same y, written out by the
-    // staging threads for the backward pass) instead of a launch of its own between two convolutions.  Bit-identical
-    // (tests/test_gpu_train.py) and no faster: 18.43 against 18.51 ms per chunk with two chunks in flight, 19.16 against 19.11 ms one
-    // chunk at a time — the workgroup's staging phase, which nothing on its CU overlaps (the halo image fills the LDS), grows by what
-    // the 21 µs pass took.  The last layer keeps its pass in either case (the heads read y).
-    static const bool fold = getenv("TG_BN_FOLD") != nullptr && atoi(getenv("TG_BN_FOLD")) != 0;
     const size_t L = t->convs.size();
-    auto apply_in_next = [&](size_t l) { return fold && l + 1 < L && conv3x3_fuses_input(M, N, t->convs[l + 1].in_stride, t->convs[l + 1].OP); };
     for (size_t l = 0; l < L; l++) {
         TrainConv& c = t->convs[l];
         float* z = w.z[l].as<float>();
         const float* in = l == 0 ? w.planes.as<float>() : w.y[l - 1].as<float>();
-        ConvInFuse fz{};
-        const bool fused_in = l >= 1 && apply_in_next(l - 1);
-        if (fused_in) {
-            const TrainConv& b = t->convs[l - 1];
-            float* mean_b = stats + (size_t)b.bn * 2 * F;
-            fz.mode = 1;
-            fz.mean = mean_b; fz.invstd = mean_b + F; fz.gamma = P + b.gamma; fz.beta = P + b.beta;
-            fz.skip = (l - 1 >= 2 && ((l - 1) % 2) == 0) ? w.y[l - 3].as<float>() : nullptr;  // conv2 of a block adds the block input
-            fz.out_act = w.y[l - 1].as<float>();
-            in = w.z[l - 1].as<float>();
-        }
         // the halo kernel (F → F layers at full chunks) hands out BatchNorm's column sums with the convolution; elsewhere two
         // reduction passes over z follow
         int stat_blocks = 0;
-        static const bool conv_stats = getenv("TG_NO_CONV_STATS") == nullptr;
+        static const bool conv_stats = !env_on("TG_NO_CONV_STATS");
         TG_HIP(launch_conv3x3(st, in, c.wf.as<float>(), c.bias_pad.as<float>(), nullptr, z, M, N, c.in_stride, c.OP, F, F, false,
-                              (c.OP == F && conv_stats) ? w.part_d.as<double>() : nullptr, &stat_blocks, nullptr, fused_in ? &fz : nullptr));
+                              (c.OP == F && conv_stats) ? w.part_d.as<double>() : nullptr, &stat_blocks, nullptr));
         float* mean = stats + (size_t)c.bn * 2 * F;
         float* invstd = mean + F;
-        if (other) TG_HIP(hipStreamWaitEvent(st, other->ev_fwd[l], 0));  // the running statistics see the chunks in order
         if (stat_blocks > 0)
             TG_HIP(launch_bn_stats_from_partials(st, w.part_d.as<double>(), stat_blocks, M, F, t->cfg.bn_eps, t->cfg.bn_momentum, mean, invstd,
                                                  BN + c.rmean, BN + c.rvar));
         else
             TG_HIP(launch_bn_stats(st, z, M, F, t->cfg.bn_eps, t->cfg.bn_momentum, w.part_d.as<double>(), mean, invstd, BN + c.rmean,
                                    BN + c.rvar));
-        TG_HIP(hipEventRecord(w.ev_fwd[l], st));
-        if (!apply_in_next(l)) {
-            // conv2 of block i (l = 2, 4, …) adds the block input: y of layer l-2
-            const float* skip = (l >= 2 && (l % 2) == 0) ? w.y[l - 2].as<float>() : nullptr;
-            TG_HIP(launch_bn_fwd_apply(st, z, mean, invstd, P + c.gamma, P + c.beta, skip, w.y[l].as<float>(), M, F));
-        }
+        // conv2 of block i (l = 2, 4, …) adds the block input: y of layer l-2
+        const float* skip = (l >= 2 && (l % 2) == 0) ? w.y[l - 2].as<float>() : nullptr;
+        TG_HIP(launch_bn_fwd_apply(st, z, mean, invstd, P + c.gamma, P + c.beta, skip, w.y[l].as<float>(), M, F));
     }
     const float* s = w.y.back().as<float>();
     const float inv_b = 1.0f / (float)B;
@@ -327,10 +279,9 @@ int forward_train(TgEngine* e, Lane& w, int B, bool with_targets, float* d_logp)
     return TG_OK;
 }
 
-// (behind forward_train on the same lane)
-int backward_train(TgEngine* e, Lane& w, int B) {
+// (behind forward_train)
+int backward_train(TgEngine* e, Chunk& w, int B) {
     Trainer* t = e->trainer;
-    Lane* other = w.other;
     hipStream_t st = w.st;
     const int F = e->cfg.filters, nsq = e->g.nsq, N = e->g.n, M = B * nsq;
     const int L = (int)t->convs.size();
@@ -345,29 +296,25 @@ int backward_train(TgEngine* e, Lane& w, int B) {
     float* dzb[2] = {w.dz.as<float>(), w.dz2.as<float>()};
     float* gskip = w.gskip.as<float>();
     const float* zero_bias = t->zero_bias.as<float>();
-    // Round 4: two streams.  A layer's weight gradient (dz ⊗ x) and its data gradient (dz ∗ wᵀ, then the BatchNorm backward of the
+    // Two streams (round 4).  A layer's weight gradient (dz ⊗ x) and its data gradient (dz ∗ wᵀ, then the BatchNorm backward of the
     // layer below) only share their INPUT, so the weight gradients — the policy head's first — run on `wg` while the chain
-    // heads → BatchNorm backward → data gradient → … stays on the lane's stream, and with them everything else that only produces
+    // heads → BatchNorm backward → data gradient → … stays on the engine stream, and with them everything else that only produces
     // gradients (conv bias finalisation, the heads' bias and value gradients): 19.3 – 19.6 → 18.1 – 18.5 ms per chunk of the C5 network.
     // What is gained is every launch's ramp and tail and the split-K reductions beside the other stream's kernel; the two MFMA kernels
     // of a layer share the machine and end together, so the chain's HBM-bound BatchNorm passes still run between them, not under them
     // (profiles/r04_g_train_overlap.txt).  Same kernels on the same operands, every gradient tensor still written by one launch → the
     // same bits as the single-stream order (TG_TRAIN_ONE_STREAM=1; tests/test_gpu_train.py).  dz alternates between two buffers;
     // the workspaces are per stream (part_w, part_h, part_b: weight gradients' stream, part_d: the chain).
-    static const bool one_stream = getenv("TG_TRAIN_ONE_STREAM") != nullptr;
+    static const bool one_stream = env_on("TG_TRAIN_ONE_STREAM");
     hipStream_t wg = one_stream ? st : w.wg;
     const bool two = wg != st;
-    if (two) {  // everything the forward pass left on the lane's stream precedes the first weight gradient
+    if (two) {  // everything the forward pass left on the chain's stream precedes the first weight gradient
         TG_HIP(hipEventRecord(w.ev_head, st));
         TG_HIP(hipStreamWaitEvent(wg, w.ev_head, 0));
     }
     // ---- heads: dS = d(policy) + d(value) ----
     // (the heads' own gradients — policy weights and bias, value weights and bias — all on the weight gradients' stream, with workspaces
     // of their own: the chain starts with the data gradient the tower waits for)
-    if (other) {
-        TG_HIP(hipStreamWaitEvent(wg, other->ev_wgl[L], 0));
-        TG_HIP(hipStreamWaitEvent(st, other->ev_chain[L], 0));
-    }
     double* part_h0 = w.part_h.as<double>();
     double* part_h1 = (double*)((char*)w.part_h.p + w.part_h.bytes / 2);
     if (t->conv_head) {
@@ -384,17 +331,12 @@ int backward_train(TgEngine* e, Lane& w, int B) {
     }
     TG_HIP(launch_value_bwd(st, s, w.dpre.as<float>(), t->wv.as<float>(), B, F, nsq, dcur, part_h1, G + t->val_w, G + t->val_b, wg));
     TG_HIP(hipEventRecord(w.ev_wgl[L], wg));
-    TG_HIP(hipEventRecord(w.ev_chain[L], st));
     // ---- tower, last layer first ----
-    // Round 4: the data-gradient convolution of layer l produces dy of layer l − 1 — its epilogue also takes that layer's
+    // The data-gradient convolution of layer l produces dy of layer l − 1 — its epilogue also takes that layer's
     // BatchNorm-backward sums Σg, Σg·x̂ while dy is in registers (halo kernel, full chunks), and the pass over dy, y and z that took
     // them (k_col_reduce, 27 µs per layer) is skipped; TG_NO_BWD_SUMS_FUSION restores it (other summation order: other low bits)
-    static const bool fuse_sums = getenv("TG_NO_BWD_SUMS_FUSION") == nullptr;
-    // TG_BN_FOLD=1 (see forward_train; off by default): BatchNorm's backward apply pass dz = γ·invstd·(g − mean(g) − x̂·mean(g·x̂)) of layer l
-    // runs inside the staging of that layer's data-gradient convolution (ConvInFuse mode 2: same expression → same dz, written out for
-    // the weight gradient, with g for the skip path and dz's column sums for the conv bias gradient); the weight gradient of layer l
-    // then follows the convolution that wrote its dz, beside the convolution of layer l − 1.  Layer 0 (no data gradient) keeps the pass.
-    static const bool fold = getenv("TG_BN_FOLD") != nullptr && atoi(getenv("TG_BN_FOLD")) != 0;
+    static const bool fuse_sums = !env_on("TG_NO_BWD_SUMS_FUSION");
+    const size_t act_bytes = (size_t)M * F * 4;
     int sums_in_part = 0;
     for (int l = L - 1; l >= 0; l--) {
         TrainConv& c = t->convs[l];
@@ -404,63 +346,37 @@ int backward_train(TgEngine* e, Lane& w, int B) {
         float* dz = dzb[k];
         const bool block_end = l >= 2 && (l % 2) == 0;  // conv2: its masked gradient also flows into the skip
         const bool block_begin = (l % 2) == 1;          // conv1 closes the block: its data gradient joins the gradient that went through the skip
-        const bool in_staging = fold && l >= 1 && conv3x3_fuses_input(M, N, F, round_up(c.I, 64));
+        const bool cap = l == w.cap_layer;
         if (two && l + 2 < L) TG_HIP(hipStreamWaitEvent(st, w.ev_wgl[l + 2], 0));  // layer l + 2's weight gradient has read this dz buffer
-        if (other) TG_HIP(hipStreamWaitEvent(st, other->ev_chain[l], 0));
         const float* x = l == 0 ? w.planes.as<float>() : w.y[l - 1].as<float>();
-        if (!in_staging) {
-            // (the conv bias gradient — dz's column sums — is finalised on the weight gradients' stream: one launch less in the chain)
-            int colsum_rows = 0;
-            TG_HIP(launch_bn_bwd(st, dcur, w.y[l].as<float>(), w.z[l].as<float>(), mean, invstd, P + c.gamma, M, F, part_d, w.mean_g.as<double>(),
-                                 w.mean_gx.as<double>(), G + c.gamma, G + c.beta, dz, block_end ? gskip : nullptr, G + c.b, sums_in_part,
-                                 w.part_b[k].as<double>(), &colsum_rows));
-            sums_in_part = 0;
-            TG_HIP(hipEventRecord(w.ev_chain[l], st));
-            if (two) {
-                TG_HIP(hipEventRecord(w.ev_dz[k], st));
-                TG_HIP(hipStreamWaitEvent(wg, w.ev_dz[k], 0));
-            }
-            if (other) TG_HIP(hipStreamWaitEvent(wg, other->ev_wgl[l], 0));
-            TG_HIP(launch_colsum_finalize(wg, w.part_b[k].as<double>(), colsum_rows, F, F, G + c.b));
-            TG_HIP(launch_wgrad_conv(wg, x, c.in_stride, c.I, dz, F, c.O, B, N, part_w, G + c.w));
-            TG_HIP(hipEventRecord(w.ev_wgl[l], wg));
-            if (l == 0) break;
-        } else {
-            TG_HIP(launch_bn_bwd_sums(st, dcur, w.y[l].as<float>(), w.z[l].as<float>(), mean, invstd, M, F, part_d, w.mean_g.as<double>(),
-                                      w.mean_gx.as<double>(), G + c.gamma, G + c.beta, sums_in_part));
-            sums_in_part = 0;
-            TG_HIP(hipEventRecord(w.ev_chain[l], st));
+        if (cap) TG_HIP(hipMemcpyAsync(w.cap_dy.p, dcur, act_bytes, hipMemcpyDeviceToDevice, st));
+        // (the conv bias gradient — dz's column sums — is finalised on the weight gradients' stream: one launch less in the chain)
+        int colsum_rows = 0;
+        TG_HIP(launch_bn_bwd(st, dcur, w.y[l].as<float>(), w.z[l].as<float>(), mean, invstd, P + c.gamma, M, F, part_d, w.mean_g.as<double>(),
+                             w.mean_gx.as<double>(), G + c.gamma, G + c.beta, dz, block_end ? gskip : nullptr, G + c.b, sums_in_part,
+                             w.part_b[k].as<double>(), &colsum_rows));
+        sums_in_part = 0;
+        if (cap) TG_HIP(hipMemcpyAsync(w.cap_dz.p, dz, act_bytes, hipMemcpyDeviceToDevice, st));
+        if (two) {
+            TG_HIP(hipEventRecord(w.ev_dz[k], st));
+            TG_HIP(hipStreamWaitEvent(wg, w.ev_dz[k], 0));
         }
+        TG_HIP(launch_colsum_finalize(wg, w.part_b[k].as<double>(), colsum_rows, F, F, G + c.b));
+        TG_HIP(launch_wgrad_conv(wg, x, c.in_stride, c.I, dz, F, c.O, B, N, part_w, G + c.w));
+        TG_HIP(hipEventRecord(w.ev_wgl[l], wg));
+        if (l == 0) break;
         float* dst = block_end ? dtmp : dcur;
         const TrainConv& below = t->convs[l - 1];
         const float* mean_b = stats + (size_t)below.bn * 2 * F;
         const ConvBnBwdIn bnb{w.y[l - 1].as<float>(), w.z[l - 1].as<float>(), mean_b, mean_b + F};
-        ConvInFuse fz{};
-        if (in_staging) {
-            fz.mode = 2;
-            fz.mean = mean; fz.invstd = invstd; fz.gamma = P + c.gamma;
-            fz.y = w.y[l].as<float>(); fz.z = w.z[l].as<float>();
-            fz.mean_g = w.mean_g.as<double>(); fz.mean_gx = w.mean_gx.as<double>();
-            fz.out_act = dz; fz.out_gskip = block_end ? gskip : nullptr;
-            fz.colsum_part = w.part_b[k].as<double>();
-        }
         // (in place where dst = dcur: a workgroup reads the rows of its own positions and writes them after its last read)
-        TG_HIP(launch_conv3x3(st, in_staging ? dcur : dz, c.wb.as<float>(), zero_bias, block_begin ? gskip : nullptr, dst, M, N, F,
+        TG_HIP(launch_conv3x3(st, dz, c.wb.as<float>(), zero_bias, block_begin ? gskip : nullptr, dst, M, N, F,
                               round_up(c.I, 64), F, F, false, fuse_sums ? part_d : nullptr, fuse_sums ? &sums_in_part : nullptr,
-                              fuse_sums ? &bnb : nullptr, in_staging ? &fz : nullptr));
-        if (in_staging) {  // the weight gradient (and the conv bias gradient, from the staging's column sums) behind the convolution
-            if (two) {
-                TG_HIP(hipEventRecord(w.ev_dz[k], st));
-                TG_HIP(hipStreamWaitEvent(wg, w.ev_dz[k], 0));
-            }
-            if (other) TG_HIP(hipStreamWaitEvent(wg, other->ev_wgl[l], 0));
-            TG_HIP(launch_colsum_finalize(wg, w.part_b[k].as<double>(), fz.colsum_rows, F, F, G + c.b));
-            TG_HIP(launch_wgrad_conv(wg, x, c.in_stride, c.I, dz, F, c.O, B, N, part_w, G + c.w));
-            TG_HIP(hipEventRecord(w.ev_wgl[l], wg));
-        }
+                              fuse_sums ? &bnb : nullptr));
+        if (cap) TG_HIP(hipMemcpyAsync(w.cap_dx.p, dst, act_bytes, hipMemcpyDeviceToDevice, st));
         if (block_end) std::swap(dcur, dtmp);
     }
-    // the lane's stream continues (loss sums, optimiser step, this lane's next chunk) behind its last weight gradient
+    // the chain's stream continues (loss sums, optimiser step, the next chunk) behind the last weight gradient
     if (two) TG_HIP(hipStreamWaitEvent(st, w.ev_wgl[0], 0));
     return TG_OK;
 }
@@ -482,8 +398,7 @@ static int all_reduce_sum(TgEngine* e, hipStream_t st, float* d_buf, size_t coun
     return TG_OK;
 }
 
-// on `st`, behind every chunk of the step: the chunk that completes a step runs it on its lane's stream, which has waited for its
-// own weight gradients, and every update of that chunk stands behind the same update of the chunk before (Lane's events)
+// on `st`, behind every chunk of the step (the chain's stream has waited for the chunk's weight gradients)
 int optimizer_step(TgEngine* e, hipStream_t st) {
     Trainer* t = e->trainer;
     float gscale = 1.0f;
@@ -491,7 +406,7 @@ int optimizer_step(TgEngine* e, hipStream_t st) {
         bool reduced;
         const bool timed = t->hook || t->comm;
         if (timed) {
-            t->ar_fold();  // the previous step's pair (long complete: a whole step of chunks lies between)
+            t->ar_fold();  // the previous step's pair, if it has completed (a whole step of chunks lies between)
             if (!t->ar_ev[0]) {
                 TG_HIP(hipEventCreate(&t->ar_ev[0]));
                 TG_HIP(hipEventCreate(&t->ar_ev[1]));
@@ -511,7 +426,7 @@ int optimizer_step(TgEngine* e, hipStream_t st) {
                        t->cfg.learning_rate, t->cfg.beta1, t->cfg.beta2, t->cfg.eps, t->cfg.weight_decay, bc1, bc2s, gscale));
     TG_HIP(hipMemsetAsync(t->grads.p, 0, t->n_params * 4, st));
     t->packed = false;
-    return pack_params(e, st);  // here, not in the next forward pass: the lanes share the packed copies (ev_step)
+    return pack_params(e, st);
 }
 
 int need_trainer(TgEngine* e) {
@@ -522,9 +437,9 @@ int need_trainer(TgEngine* e) {
     return TG_OK;
 }
 
-// One chunk already resident on the device (the lane's ex_* buffers hold n examples, zt the 8n value targets): everything up
-// to and including an optimiser step that falls due is ISSUED on the lane's streams; chunk_collect waits for it and reads the losses.
-int chunk_issue(TgEngine* e, Lane& w, int n) {
+// One chunk already resident on the device (the ex_* buffers hold n examples, zt the 8n value targets): everything up
+// to and including an optimiser step that falls due is ISSUED on the two streams; chunk_collect waits for it and reads the losses.
+int chunk_issue(TgEngine* e, Chunk& w, int n) {
     Trainer* t = e->trainer;
     hipStream_t st = w.st;
     const int B = n * 8;
@@ -551,26 +466,24 @@ int chunk_issue(TgEngine* e, Lane& w, int n) {
     }
     return TG_OK;
 }
-int chunk_collect(TgEngine* e, Lane& w, float* loss_p, float* loss_z, int32_t* stepped) {
+int chunk_collect(TgEngine* e, Chunk& w, float* loss_p, float* loss_z, int32_t* stepped) {
     (void)e;
-    if (!w.in_flight) return fail(TG_ERR_STATE, "internal: no chunk in flight on this lane");
+    if (!w.in_flight) return fail(TG_ERR_STATE, "internal: no chunk in flight");
     w.in_flight = false;
     double sums[2];
     TG_HIP(hipMemcpyAsync(sums, w.loss_sums.p, 16, hipMemcpyDeviceToHost, w.st));
-    TG_HIP(hipStreamSynchronize(w.st));  // the lane's stream stands behind its weight-gradient stream (backward_train)
+    TG_HIP(hipStreamSynchronize(w.st));  // the chain's stream stands behind the weight-gradient stream (backward_train)
     if (loss_p) *loss_p = (float)(sums[0] / w.B_flight);
     if (loss_z) *loss_z = (float)(sums[1] / w.B_flight);
     if (stepped) *stepped = w.did_step;
     return TG_OK;
 }
-// after an error in the middle of a pipeline: nothing of this trainer is left running
-void lanes_drain(Trainer* t) {
-    for (int i = 0; i < t->n_lanes; i++) {
-        Lane& w = t->lane[i];
-        if (w.wg) (void)hipStreamSynchronize(w.wg);
-        if (w.st) (void)hipStreamSynchronize(w.st);
-        w.in_flight = false;
-    }
+// after an error in the middle of a chunk: nothing of this trainer is left running
+void chunk_drain(Trainer* t) {
+    Chunk& w = t->chunk;
+    if (w.wg) (void)hipStreamSynchronize(w.wg);
+    if (w.st) (void)hipStreamSynchronize(w.st);
+    w.in_flight = false;
 }
 
 // The complete host-side check of ONE example (index s of the caller's arrays), used by tg_train_chunk's upload and by
@@ -587,7 +500,7 @@ int validate_example(const TgEngine* e, int s, const uint8_t* states, const int3
 }
 
 // validated = the caller (tg_train) has already checked every example
-int upload_chunk(TgEngine* e, Lane& w, int n, const uint8_t* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
+int upload_chunk(TgEngine* e, Chunk& w, int n, const uint8_t* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
                  const float* results, const int* order, bool validated = false) {
     hipStream_t st = w.st;
     const size_t sb = e->g.bytes;
@@ -727,7 +640,7 @@ int tg_train_create(TgEngine* e, const TgTrainConfig* cfg) {
     TG_HIP(t->wv.ensure((size_t)F * nsq * 4));
     TG_HIP(t->zero_bias.ensure((size_t)max_op * 4));
     TG_HIP(hipMemset(t->zero_bias.p, 0, (size_t)max_op * 4));
-    // ---- the lanes: what a chunk in flight owns ----
+    // ---- what the chunk in flight owns ----
     size_t part_d_bytes;
     {   // double partials: column reductions over up to max(F, logit columns) channels, value weight gradient
         int rpb;
@@ -738,24 +651,16 @@ int tg_train_create(TgEngine* e, const TgTrainConfig* cfg) {
         size_t b = (size_t)32 * ((size_t)F * nsq + 1);
         part_d_bytes = std::max(a, b) * 8;
     }
-    TG_HIP(hipEventCreateWithFlags(&t->ev_step, hipEventDisableTiming));
-    t->n_lanes = (getenv("TG_TRAIN_LANES") && atoi(getenv("TG_TRAIN_LANES")) == 2) ? 2 : 1;
     const size_t L = t->convs.size();
-    for (int li = 0; li < t->n_lanes; li++) {
-        Lane& w = t->lane[li];
-        if (li == 0) w.st = e->stream;
-        else {
-            TG_HIP(hipStreamCreateWithFlags(&w.st, hipStreamNonBlocking));
-            w.own_st = true;
-        }
-        // (stream priorities — the weight gradients below the chains, one lane below the other — were measured: 1 – 12 % slower)
+    {
+        Chunk& w = t->chunk;
+        w.st = e->stream;
+        // (stream priorities — the weight gradients below the chain — were measured: 1 – 12 % slower)
         TG_HIP(hipStreamCreateWithFlags(&w.wg, hipStreamNonBlocking));
         for (int k = 0; k < 2; k++) TG_HIP(hipEventCreateWithFlags(&w.ev_dz[k], hipEventDisableTiming));
         TG_HIP(hipEventCreateWithFlags(&w.ev_head, hipEventDisableTiming));
-        for (auto* v : {&w.ev_fwd, &w.ev_chain, &w.ev_wgl}) {
-            v->assign(L + 1, nullptr);
-            for (hipEvent_t& ev : *v) TG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        }
+        w.ev_wgl.assign(L + 1, nullptr);
+        for (hipEvent_t& ev : w.ev_wgl) TG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         w.z.resize(L);
         w.y.resize(L);
         for (size_t l = 0; l < L; l++) {
@@ -791,7 +696,7 @@ int tg_train_create(TgEngine* e, const TgTrainConfig* cfg) {
         TG_HIP(w.mean_gx.ensure((size_t)F * 8));
         TG_HIP(w.part_d.ensure(part_d_bytes));
         TG_HIP(w.part_w.ensure(part_w_floats * 4));
-        for (int k = 0; k < 2; k++) TG_HIP(w.part_b[k].ensure(std::max(part_d_bytes, ((size_t)B / 4 + 2) * 8 * 2 * F * 8)));  // ConvInFuse: ≤ 8 partial rows per workgroup of ≥ 4 positions
+        for (int k = 0; k < 2; k++) TG_HIP(w.part_b[k].ensure(part_d_bytes));
         TG_HIP(w.part_h.ensure(2 * ((part_d_bytes + 255) / 256 * 256)));
     }
     delete e->trainer;
@@ -805,12 +710,12 @@ int tg_train_chunk(TgEngine* e, int n, const void* states, const int32_t* n_move
     if (rc) return rc;
     if (n <= 0 || n > e->trainer->cfg.chunk_size || !states || !n_moves || !moves || !visits || !results)
         return fail(TG_ERR_INVALID_ARG, "tg_train_chunk: bad arguments (1 ≤ n ≤ chunk_size)");
-    Lane& w = e->trainer->lane[0];
+    Chunk& w = e->trainer->chunk;
     rc = upload_chunk(e, w, n, (const uint8_t*)states, n_moves, moves, visits, results, nullptr);
     if (rc) return rc;
     rc = chunk_issue(e, w, n);
     if (rc) {
-        lanes_drain(e->trainer);
+        chunk_drain(e->trainer);
         return rc;
     }
     return chunk_collect(e, w, loss_p, loss_z, stepped);
@@ -861,35 +766,18 @@ int tg_train(TgEngine* e, int n, const void* states, const int32_t* n_moves, con
     const int cs = t->cfg.chunk_size;
     double sp = 0.0, sz = 0.0;
     int chunks = 0, nsteps = 0;
-    // TG_TRAIN_LANES=2 (round 4; built and measured, off by default): two chunks in flight, one per lane — while the GPU works on chunk k
-    // the host collects chunk k − 1's losses from the other lane, uploads chunk k + 1 there and issues it; its forward pass runs beside
-    // chunk k's backward pass.  Every update of shared state (running statistics, gradient tensors, the optimiser step) stays in chunk
-    // order through the lanes' events: the same bits as one chunk after the other (tests/test_gpu_train.py).  What it buys once the
-    // weight gradients have their own stream: − 0.15 ms per chunk on one box, + 0.2 ms on another, nothing on a third — kernels that
-    // share the machine end together and their HBM-bound passes then run at once (profiles/r04_g_train_overlap.txt), so the second
-    // lane mostly hides the host's time between two chunks, for twice the activation memory.
-    auto collect = [&](Lane& w) -> int {
-        float lp, lz;
-        int32_t did;
-        int crc = chunk_collect(e, w, &lp, &lz, &did);
-        if (crc) return crc;
-        sp += lp; sz += lz; chunks++; nsteps += did;
-        return TG_OK;
-    };
-    int issued = 0;
-    for (int off = 0; off + cs <= n && rc == TG_OK; off += cs, issued++) {  // chunks_exact: the remainder is dropped
-        Lane& w = t->lane[issued % t->n_lanes];
-        if (w.in_flight) rc = collect(w);
-        if (rc == TG_OK) rc = upload_chunk(e, w, cs, (const uint8_t*)states, n_moves, moves, visits, results, order.data() + off, true);
+    Chunk& w = t->chunk;
+    for (int off = 0; off + cs <= n; off += cs) {  // chunks_exact: the remainder is dropped
+        rc = upload_chunk(e, w, cs, (const uint8_t*)states, n_moves, moves, visits, results, order.data() + off, true);
         if (rc == TG_OK) rc = chunk_issue(e, w, cs);
-    }
-    for (int k = 0; k < t->n_lanes && rc == TG_OK; k++) {  // oldest first
-        Lane& w = t->lane[(issued + k) % t->n_lanes];
-        if (w.in_flight) rc = collect(w);
-    }
-    if (rc) {
-        lanes_drain(t);
-        return rc;
+        float lp = 0.0f, lz = 0.0f;
+        int32_t did = 0;
+        if (rc == TG_OK) rc = chunk_collect(e, w, &lp, &lz, &did);
+        if (rc) {
+            chunk_drain(t);
+            return rc;
+        }
+        sp += lp; sz += lz; chunks++; nsteps += did;
     }
     if (mean_loss_p) *mean_loss_p = chunks ? (float)(sp / chunks) : 0.0f;
     if (mean_loss_z) *mean_loss_z = chunks ? (float)(sz / chunks) : 0.0f;
@@ -911,7 +799,7 @@ int tg_train_forward(TgEngine* e, int n, const void* states, float* logp, float*
     if (rc) return rc;
     Trainer* t = e->trainer;
     if (n <= 0 || n > t->Bmax || !states || !logp || !eval) return fail(TG_ERR_INVALID_ARG, "tg_train_forward: bad arguments (1 ≤ n ≤ 8·chunk_size)");
-    Lane& w = t->lane[0];
+    Chunk& w = t->chunk;
     hipStream_t st = w.st;
     TG_HIP(hipMemcpyAsync(w.states_aug.p, states, (size_t)n * e->g.bytes, hipMemcpyHostToDevice, st));
     launch_encode_nhwc(st, w.states_aug.as<uint8_t>(), n, e->g.n, w.planes.as<float>(), e->cin_pad);
@@ -941,6 +829,53 @@ static int get_common(TgEngine* e, const char* name, float* out, size_t count, b
 }
 int tg_train_get_tensor(TgEngine* e, const char* name, float* out, size_t count) { return get_common(e, name, out, count, false); }
 int tg_train_get_grad(TgEngine* e, const char* name, float* out, size_t count) { return get_common(e, name, out, count, true); }
+
+// Test / diagnostic access to the training step's intermediate tensors (tests/test_gpu_c5_realsize.py, scripts/train_error_budget.py):
+// what = "planes" (NHWC input, [rows][cin_pad]), "z" / "y" (conv output, activation of layer `layer`, [rows][F]), "mean" / "invstd" (the
+// batch statistics BatchNorm `layer` normalised with, [F]) of the last forward pass; "dy" / "dz" / "dx" of the layer armed by
+// tg_train_debug_capture (gradient w.r.t. y before the ReLU mask, w.r.t. z, and the data gradient handed to the layer below — for
+// conv1 of a block with the skip path's gradient added), [rows][F].  count = the number of floats expected.
+int tg_train_debug_capture(TgEngine* e, int layer) {
+    int rc = need_trainer(e);
+    if (rc) return rc;
+    Trainer* t = e->trainer;
+    Chunk& w = t->chunk;
+    if (layer >= (int)t->convs.size()) return fail(TG_ERR_INVALID_ARG, "tg_train_debug_capture: no such layer");
+    w.cap_layer = layer < 0 ? -1 : layer;
+    if (layer >= 0) {
+        const size_t bytes = (size_t)t->Bmax * e->g.nsq * e->cfg.filters * 4;
+        TG_HIP(w.cap_dy.ensure(bytes));
+        TG_HIP(w.cap_dz.ensure(bytes));
+        TG_HIP(w.cap_dx.ensure(bytes));
+    }
+    return TG_OK;
+}
+int tg_train_debug_read(TgEngine* e, const char* what, int layer, float* out, size_t count) {
+    int rc = need_trainer(e);
+    if (rc) return rc;
+    if (!what || !out) return fail(TG_ERR_INVALID_ARG, "null argument");
+    Trainer* t = e->trainer;
+    Chunk& w = t->chunk;
+    const int L = (int)t->convs.size(), F = e->cfg.filters;
+    const std::string k = what;
+    const void* src = nullptr;
+    size_t have = 0;
+    if (k == "planes") { src = w.planes.p; have = w.planes.bytes / 4; }
+    else if (layer < 0 || layer >= L) return fail(TG_ERR_INVALID_ARG, "tg_train_debug_read: no such layer");
+    else if (k == "z") { src = w.z[layer].p; have = w.z[layer].bytes / 4; }
+    else if (k == "y") { src = w.y[layer].p; have = w.y[layer].bytes / 4; }
+    else if (k == "mean") { src = w.stats.as<float>() + (size_t)t->convs[layer].bn * 2 * F; have = F; }
+    else if (k == "invstd") { src = w.stats.as<float>() + (size_t)t->convs[layer].bn * 2 * F + F; have = F; }
+    else if (layer != w.cap_layer) return fail(TG_ERR_STATE, "tg_train_debug_read: layer not armed (tg_train_debug_capture)");
+    else if (k == "dy") { src = w.cap_dy.p; have = w.cap_dy.bytes / 4; }
+    else if (k == "dz") { src = w.cap_dz.p; have = w.cap_dz.bytes / 4; }
+    else if (k == "dx") { src = w.cap_dx.p; have = w.cap_dx.bytes / 4; }
+    else return fail(TG_ERR_INVALID_ARG, std::string("tg_train_debug_read: unknown tensor ") + what);
+    if (count > have) return fail(TG_ERR_INVALID_ARG, "tg_train_debug_read: count exceeds the buffer");
+    TG_HIP(hipStreamSynchronize(e->stream));
+    TG_HIP(hipMemcpy(out, src, count * 4, hipMemcpyDeviceToHost));
+    return TG_OK;
+}
 
 int tg_train_commit(TgEngine* e) {
     int rc = need_trainer(e);
@@ -993,7 +928,7 @@ int tg_train_comm_stats(TgEngine* e, double* ms_total, int64_t* reductions) {
     if (rc) return rc;
     Trainer* t = e->trainer;
     TG_HIP(hipStreamSynchronize(e->stream));
-    t->ar_fold();
+    t->ar_fold(true);
     if (ms_total) *ms_total = t->ar_ms;
     if (reductions) *reductions = t->ar_count;
     return TG_OK;

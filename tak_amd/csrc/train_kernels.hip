@@ -845,16 +845,6 @@ hipError_t launch_bn_fwd_apply(hipStream_t st, const float* z, const float* mean
     hipLaunchKernelGGL(k_bn_fwd_apply, dim3(blocks_for(total4)), dim3(256), 0, st, z, mean, invstd, gamma, beta, skip, y, total4, F / 4);
     return hipGetLastError();
 }
-// the first half of launch_bn_bwd alone: Σg, Σg·x̂ (from `part` if sums_in_part > 0, else by a pass over dy, y, z) → mean_g, mean_gx,
-// grad_gamma +=, grad_beta += — for layers whose dz is produced by the data-gradient convolution's staging (ConvInFuse mode 2)
-hipError_t launch_bn_bwd_sums(hipStream_t st, const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
-                              int M, int F, double* part, double* mean_g, double* mean_gx, float* grad_gamma, float* grad_beta,
-                              int sums_in_part) {
-    int rpb, nblk = col_reduce_blocks(M, F, &rpb);
-    if (sums_in_part <= 0) hipLaunchKernelGGL((k_col_reduce<RED_BNBWD>), dim3(nblk), dim3(256), 0, st, dy, y, z, mean, invstd, M, F, rpb, part);
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(F), dim3(256), 0, st, part, sums_in_part > 0 ? sums_in_part : nblk, F, M, mean_g, mean_gx, grad_gamma, grad_beta);
-    return hipGetLastError();
-}
 // grad[c] += Σ over `rows` partial rows part[(row·2)·F + c]
 hipError_t launch_colsum_finalize(hipStream_t st, const double* part, int rows, int F, int valid, float* grad) {
     hipLaunchKernelGGL(k_colsum_finalize, dim3(valid), dim3(256), 0, st, part, rows, F, valid, grad);

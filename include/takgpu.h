@@ -434,10 +434,8 @@ int tg_train_chunk(TgEngine* e, int n, const void* states, const int32_t* n_move
  * others in a collective.  All ranks must therefore call tg_train together.  tg_train_chunk validates only its own chunk — a
  * data-parallel caller of tg_train_chunk must agree on errors across ranks itself before the chunk that completes an
  * optimiser step.
- * Execution (round 4): the weight gradients of a chunk run on a stream of their own beside the data-gradient chain
- * (TG_TRAIN_ONE_STREAM=1: on the chain's stream); with TG_TRAIN_LANES=2 two chunks are in flight at a time, each on its own
- * activations and streams, every update of state they share (BatchNorm running statistics, each gradient tensor, the optimiser
- * step) in chunk order.  Either way the result is that of tg_train_chunk on one chunk after the other, bit for bit. */
+ * Execution: the weight gradients of a chunk run on a stream of their own beside the data-gradient chain
+ * (TG_TRAIN_ONE_STREAM=1: on the chain's stream); the result is the same, bit for bit. */
 int tg_train(TgEngine* e, int n, const void* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
              const float* results, uint64_t seed, float* mean_loss_p, float* mean_loss_z, int32_t* steps);
 /* opt.step(); opt.zero_grad() now (network.rs:92-96), whatever the chunk counter says */
@@ -448,6 +446,15 @@ int tg_train_forward(TgEngine* e, int n, const void* states, float* logp, float*
 /* current value of a parameter / BN buffer (names of tg_net_set_tensor) and of its accumulated gradient */
 int tg_train_get_tensor(TgEngine* e, const char* name, float* out, size_t count);
 int tg_train_get_grad(TgEngine* e, const char* name, float* out, size_t count);
+/* Intermediate tensors of the training step, for parity tests and error budgets (no counterpart in the reference; libtorch users
+ * would register hooks).  tg_train_debug_read: what = "planes" (NHWC input [rows][cin_pad]); "z" / "y" (conv output / activation
+ * of conv layer `layer` = 0 conv0, 1 + 2i res{i}.conv1, 2 + 2i res{i}.conv2; [rows][filters]); "mean" / "invstd" (the batch
+ * statistics that layer's BatchNorm normalised with; [filters]) — all of the last forward pass; "dy" / "dz" / "dx" (gradient
+ * w.r.t. y before the ReLU mask, w.r.t. z, and the data gradient handed to the layer below — for conv1 of a block with the skip
+ * path's gradient added; [rows][filters]) of the layer armed with tg_train_debug_capture BEFORE the chunk (layer < 0 disarms;
+ * three device copies per chunk while armed).  count = floats to read (≤ the tensor). */
+int tg_train_debug_capture(TgEngine* e, int layer);
+int tg_train_debug_read(TgEngine* e, const char* what, int layer, float* out, size_t count);
 /* make the trained parameters the ones tg_policy_eval / search / self-play use (tg_net_set_tensor of every
  * tensor + tg_net_finalize).  With a communicator the BN running statistics are averaged over the ranks first. */
 int tg_train_commit(TgEngine* e);
@@ -458,8 +465,7 @@ int tg_train_comm_init(TgEngine* e, int rank, int world_size, const void* id128)
 /* The same reduction through a caller-supplied function instead of RCCL — ranks that share one GPU (RCCL refuses duplicate
  * devices), a host transport (gloo, MPI, a socket from Rust), or a test.  The optimiser step calls
  * fn(ctx, d_buf, count, stream) with the flat gradient buffer (device memory, `count` floats); on return — or, if fn only
- * enqueues work, in the order of `stream` (a hipStream_t of the engine: the one the step runs on — with TG_TRAIN_LANES=2 not
- * always the same) — d_buf must hold the SUM over all world_size ranks.
+ * enqueues work, in the order of `stream` (the engine's hipStream_t, tg_stream) — d_buf must hold the SUM over all world_size ranks.
  * The step then applies Adam to d_buf / world_size, so every rank that saw the same sum ends with bit-identical parameters.
  * tg_train_commit reduces the BatchNorm running statistics through the same function.  fn returns 0 or an error code
  * (→ TG_ERR_STATE).  fn = NULL removes the hook.  Mutually exclusive with tg_train_comm_init. */

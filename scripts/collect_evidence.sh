@@ -18,7 +18,7 @@ TG_TRAIN_ONE_STREAM=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O
 rocprofv3 --kernel-trace --output-format csv -d $O/kt_train2 -o kt -- python3 $R/scripts/train_step_ab.py 12 --driver > /dev/null 2> $O/kt_train2.err
 python3 $R/scripts/probes/train_overlap.py $(find $O/kt_train2 -name '*kernel_trace.csv' | head -1) > $O/train_overlap_default.txt 2>&1
 step "training step timings (no profiler): tg_train, tg_train_chunk, one stream"
-{ python3 $R/scripts/train_step_ab.py 40 --driver; python3 $R/scripts/train_step_ab.py 40; TG_TRAIN_LANES=2 python3 $R/scripts/train_step_ab.py 40 --driver; TG_TRAIN_ONE_STREAM=1 python3 $R/scripts/train_step_ab.py 40 --driver; } > $O/train_step.jsonl 2>> $O/kt_train.err
+{ python3 $R/scripts/train_step_ab.py 40 --driver; python3 $R/scripts/train_step_ab.py 40; TG_TRAIN_ONE_STREAM=1 python3 $R/scripts/train_step_ab.py 40 --driver; } > $O/train_step.jsonl 2>> $O/kt_train.err
 step "HBM traffic counters, forward C2"
 rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_WRREQ --output-format csv -d $O/pmc_traffic -o p -- python3 $R/scripts/ab_forward.py c2 > $O/ab_forward_c2_under_pmc.json 2> $O/pmc_traffic.err
 step "HBM traffic counters, policy FC inside the search loop (gather epilogue)"

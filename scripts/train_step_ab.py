@@ -18,7 +18,7 @@ def main():
     import tak_amd
 
     chunks = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-    driver = "--driver" in sys.argv  # through tg_train (chunks in flight on two lanes) instead of one tg_train_chunk after the other
+    driver = "--driver" in sys.argv  # through tg_train instead of one tg_train_chunk after the other
     n, blocks, filters, cs = 5, 10, 128, 500
     e = tak_amd.Engine(n, res_blocks=blocks, filters=filters, max_batch=4096)
     e.init_random(seed=0)

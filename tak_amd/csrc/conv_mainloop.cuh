@@ -158,7 +158,17 @@ __device__ __forceinline__ void conv_mainloop(const f32x4* __restrict__ lds4, co
 // arbiter prefers the older wave throughout: it finishes its tiles at ≈ 3/4 of the layer and the younger one runs the
 // last quarter alone, where nothing fills the gaps between its own MFMA groups (37 instead of 33 cycles per MFMA).
 // COT = output channel tiles of the layer's weight matrix (CoutP / 16): CH in the towers (F → F), more for a wider head.
-template <int RTW, int CH, int NB, int NM, int COT = CH>
+// SPLIT (round 5; the stand-alone layers of the training step, k_conv_halo): every tap's 16·CH products are summed in a chain of their
+// own that starts from zero (the first MFMA of a tap takes the constant 0 as its C operand) and is added to `acc` when the tap is
+// complete — nine chains of 16·CH terms and nine additions instead of ONE chain of 9·16·CH.  A chain of K terms rounds K times on
+// partial sums that grow like √k, so its error grows like √(K/2) ulp: for 128 → 128 layers the one-chain sum is 2.5 × less accurate
+// than ATen's convolution (measured per layer against fp64, profiles/r05_a_train_error_budget.txt: 4.5e-7 σ against 1.76e-7 σ),
+// which over 21 layers put 3 – 4 × as many pre-activations on the wrong side of a ReLU in the training step's forward pass.  The
+// tower of the inference path keeps the single chain (its outputs sit 30 × inside the 1e-4 gate and its registers are full).
+// The flush of one half of the tiles is issued behind the MFMA group of the other half, whose 4·H MFMAs ago its own last MFMA
+// was issued — the adds do not wait for the matrix pipe, except behind the last tap of a row of taps (no chain lives across the
+// trips of the row loop: the compiler otherwise rotates the loop around the carried chains and runs out of registers).
+template <int RTW, int CH, int NB, int NM, int COT = CH, bool SPLIT = false>
 __device__ __forceinline__ void conv_mainloop_halo(const f32x4* __restrict__ lds4, const float* __restrict__ wlayer,
                                                    const float* __restrict__ wnext, uint32_t wlane, const int (&addr4)[NM],
                                                    f32x4 (&acc)[RTW], const int turn, f32x4& w0, f32x4& w1) {
@@ -186,6 +196,12 @@ __device__ __forceinline__ void conv_mainloop_halo(const f32x4* __restrict__ lds
     int ad[RTW];
 #pragma unroll
     for (int j = 0; j < RTW; j++) ad[j] = addr4[j];
+    f32x4 part[SPLIT ? RTW : 1];  // SPLIT: the current tap's chain per tile (dead between two rows of taps)
+    const f32x4 zero = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // MFMA t of step s for tile j: SPLIT → into the tap's chain, restarted from 0 at the tap's first product
+#define TG_HALO_MFMA(j, t, s)                                                                                                  \
+    if (SPLIT) part[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t], a[j][t], ((s) % CH == 0 && (t) == 0) ? zero : part[j], 0, 0, 0); \
+    else acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t], a[j][t], acc[j], 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < H1; j++) a[j] = lds4[ad[j] + TG_HALO_OFF2(0)];
     int wchunk = 2;  // next chunk of weights to request
@@ -205,8 +221,14 @@ __device__ __forceinline__ void conv_mainloop_halo(const f32x4* __restrict__ lds
 #pragma unroll
             for (int t = 0; t < 4; t++)
 #pragma unroll
-                for (int j = 0; j < H1; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t], a[j][t], acc[j], 0, 0, 0);
+                for (int j = 0; j < H1; j++) { TG_HALO_MFMA(j, t, s) }
             __builtin_amdgcn_sched_barrier(0);
+            // (the empty asm pins every flush where it stands: the adds depend on nothing but their operands, and instruction
+            // selection otherwise collects them at the end of the trip — with every tap's chains of the row alive until then)
+            if (SPLIT && s % CH == 0 && s > 0) {  // the previous tap's second half is complete
+#pragma unroll
+                for (int j = H1; j < RTW; j++) { acc[j] += part[j]; asm volatile("" : "+v"(acc[j])); }
+            }
             f32x4 w2;
             if (s < ROW - 2) {
                 w2 = TG_HALO_W(wchunk);
@@ -233,12 +255,17 @@ __device__ __forceinline__ void conv_mainloop_halo(const f32x4* __restrict__ lds
 #pragma unroll
             for (int t = 0; t < 4; t++)
 #pragma unroll
-                for (int j = H1; j < RTW; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t], a[j][t], acc[j], 0, 0, 0);
+                for (int j = H1; j < RTW; j++) { TG_HALO_MFMA(j, t, s) }
             __builtin_amdgcn_sched_barrier(0);
+            if (SPLIT && s % CH == CH - 1) {  // this tap's first half is complete; behind the row's last tap the second half too
+#pragma unroll                             // (its last tiles' MFMAs are still in flight: a few dozen cycles per row of taps)
+                for (int j = 0; j < (s == ROW - 1 ? RTW : H1); j++) { acc[j] += part[j]; asm volatile("" : "+v"(acc[j])); }
+            }
             w0 = w1;
             w1 = w2;
         }
     }
+#undef TG_HALO_MFMA
 #undef TG_HALO_OFF2
 #ifndef TG_NO_PRIO_TURNS
     __builtin_amdgcn_s_setprio(0);

@@ -259,6 +259,11 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_pos(const float* __restric
         f32x4 a_cur[RTW];
 #pragma unroll
         for (int j = 0; j < RTW; j++) a_cur[j] = lds4[aoff[j]];
+        // every tap's products in a chain of their own, added to acc when the tap is complete (conv_mainloop_halo's SPLIT: the same
+        // chains in the same order → the same bits as k_conv_halo)
+        f32x4 part[RTW];
+#pragma unroll
+        for (int j = 0; j < RTW; j++) part[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         for (int kc = 0; kc < chunks; kc++) {
             // software pipeline: the next chunk's weights (L2) and activations (LDS) are in flight while
             // this chunk's 4·RTW MFMAs issue
@@ -271,12 +276,14 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_pos(const float* __restric
 #pragma unroll
             for (int t = 0; t < 4; t++)
 #pragma unroll
-                for (int j = 0; j < RTW; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_cur[t], a_cur[j][t], acc[j], 0, 0, 0);
+                for (int j = 0; j < RTW; j++) part[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_cur[t], a_cur[j][t], part[j], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < RTW; j++) a_cur[j] = a_nxt[j];
             w_cur = w_nxt;
             kk++;
         }
+#pragma unroll
+        for (int j = 0; j < RTW; j++) acc[j] += part[j];
     }
 
     // epilogue: lane holds out[row = tile*16 + (lane&15)][ch0 + 4q .. 4q+3]
@@ -768,26 +775,30 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restri
     const int tile0 = rg * tbase + min(rg, trem);
     const bool short_group = my_tiles < RTW;
     f32x4 acc[RTW];
-    int rowid[RTW], addr4[RTW];
+    int addr4[RTW];
 #pragma unroll
     for (int j = 0; j < RTW; j++) {
         acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         const uint32_t e = j < my_tiles ? slotmap[(tile0 + j) * 16 + r16] : 0xFFFF0000u;
-        rowid[j] = (int)(e >> 16);
-        const bool idle = rowid[j] == 0xFFFF;  // a slot without a square reads around a zero cell and stores nothing
+        const bool idle = (e >> 16) == 0xFFFFu;  // a slot without a square reads around a zero cell and stores nothing
         addr4[j] = ((idle ? LEAD + n * RS : (int)(e & 0xFFFFu)) - LEAD) * P4 + q;
     }
     const int turn = (wave >> 2) & 1;
     TG_STAMP(0, 2);
     if (RTW > 1 && short_group) {
         f32x4 (&acs)[RTW - 1] = *reinterpret_cast<f32x4 (*)[RTW - 1]>(&acc[0]);
-        conv_mainloop_halo<RTW - 1, CH, NB, RTW, COT>(lds4, Wp, Wp, wlane, addr4, acs, turn, w0, w1);
+        conv_mainloop_halo<RTW - 1, CH, NB, RTW, COT, true>(lds4, Wp, Wp, wlane, addr4, acs, turn, w0, w1);
     } else {
-        conv_mainloop_halo<RTW, CH, NB, RTW, COT>(lds4, Wp, Wp, wlane, addr4, acc, turn, w0, w1);
+        conv_mainloop_halo<RTW, CH, NB, RTW, COT, true>(lds4, Wp, Wp, wlane, addr4, acc, turn, w0, w1);
     }
     TG_STAMP(0, 3);
     const int ch = ch0 + 4 * q;
     const f32x4 bv = *(const f32x4*)&bias[ch];
+    // (the tiles' rows are looked up again here rather than kept in 13 registers across the main loop, whose two accumulator sets
+    // leave none to spare)
+    int rowid[RTW];
+#pragma unroll
+    for (int j = 0; j < RTW; j++) rowid[j] = j < my_tiles ? (int)(slotmap[(tile0 + j) * 16 + r16] >> 16) : 0xFFFF;
     // stats_part: Σ and Σ² of this lane's outputs, per channel — in double from the first add on: var = E[z²] − E[z]² loses
     // (mean/σ)² of the sums' relative accuracy, and f32 partials over up to 208 rows left 1e-4 of the variance at |mean| = 10σ.
     // With bnb.y set (round 4; the data-gradient convolution of the training step): the output IS dy of the layer below, and the

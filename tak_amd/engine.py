@@ -104,7 +104,7 @@ ABI_SYMBOLS = [
     "tg_profile_enable", "tg_profile_read", "tg_board_pass_bench",
     "tg_augment_examples",
     "tg_train_create", "tg_train_chunk", "tg_train", "tg_train_step", "tg_train_forward", "tg_train_get_tensor",
-    "tg_train_get_grad", "tg_train_commit", "tg_comm_unique_id", "tg_train_comm_init", "tg_train_set_allreduce",
+    "tg_train_get_grad", "tg_train_debug_capture", "tg_train_debug_read", "tg_train_commit", "tg_comm_unique_id", "tg_train_comm_init", "tg_train_set_allreduce",
     "tg_train_grad_buffer", "tg_train_comm_stats", "tg_train_comm_info", "tg_pit",
     "tg_format_move", "tg_parse_move", "tg_format_tps", "tg_parse_tps", "tg_format_example", "tg_parse_example",
 ]
@@ -444,6 +444,16 @@ class Engine:
     def train_get_grad(self, name, shape):
         out = np.zeros(shape, np.float32)
         self._check(self.lib.tg_train_get_grad(self.h, name.encode(), _p(out), C.c_size_t(out.size)))
+        return out
+
+    def train_debug_capture(self, layer):
+        """keep dy / dz / dx of conv layer `layer` in the backward pass of the next chunks (layer < 0: stop)"""
+        self._check(self.lib.tg_train_debug_capture(self.h, int(layer)))
+
+    def train_debug_read(self, what, layer, shape):
+        """an intermediate tensor of the last training chunk / forward (include/takgpu.h tg_train_debug_read)"""
+        out = np.zeros(shape, np.float32)
+        self._check(self.lib.tg_train_debug_read(self.h, what.encode(), int(layer), _p(out), C.c_size_t(out.size)))
         return out
 
     def train_commit(self):

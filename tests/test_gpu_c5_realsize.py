@@ -3,23 +3,25 @@
 Example::to_tensors' 8-fold augmentation) — against PyTorch-CPU autograd of the same network: the kernels `bench.py`'s
 `extra.train_c5` times (k_conv_halo<…,37>, k_wgrad_halo<5,2>, BatchNorm's sums from the conv accumulators, the ring FC).
 
-Tolerances:
+What is compared, and how tightly (round 5):
   losses           relative 1e-5 against PyTorch f32
-  gradients        per tensor ‖g − g64‖₂ ≤ 2e-4·‖g64‖₂ + 2·A, where g64 is an fp64 run of the same network and A is what the
-                   ReLU decisions that f32 rounding cannot make leave open (below); the tensors no ReLU mask reaches (policy /
-                   value heads) have A = 0 and meet the plain 2e-4.  PyTorch's own f32 gradients are held to the same bound and
-                   both are written to gpurun_out/ next to each other.
-  Adam             given identical gradients, parameters within 2e-7 after a step
-
-Why A.  The forward is continuous in every pre-activation, the backward is not: relu'(y) jumps at y = 0.  Among the 2.7·10⁸
-pre-activations of this chunk a few dozen lie within f32 rounding (≈ 10⁻⁶ of their scale) of zero, and ANY f32 implementation —
-ATen's included — puts some of them on the other side than exact arithmetic does.  One such decision changes the weight gradient
-of its layer by ≈ ‖g‖/√(M·F) ≈ 3·10⁻⁴ (and every earlier layer's by a similar amount), i.e. by more than the 2e-4 gate, whoever
-computes it.  A is measured, not assumed: the fp64 network is differentiated twice more with the ReLU mask taken at y > +τ and at
-y > −τ (τ = 3·10⁻⁶; BatchNorm keeps y at unit scale), and A = ‖g64(+τ) − g64(−τ)‖₂ is the norm of everything those undecidable
-elements can move.  A wrong product, a wrong BatchNorm moment or a wrong reduction moves a tensor by orders of magnitude more than
-A (A/‖g‖ is of the order of 1e-3) only if it is itself small — so the test also demands that the MEDIAN per-tensor error over the
-network stays under 2e-4 + A, and that the head tensors meet 2e-4 outright."""
+  gradients        the backward pass is the exact derivative of a piecewise-linear function ONCE the ReLU decisions are fixed, and
+                   every decision is taken by the forward pass.  So the fp64 reference is differentiated with the ENGINE's decisions
+                   (the masks y > 0 of all 21 layers, read back through tg_train_debug_read): every gradient tensor then has to agree
+                   with no allowance at all — ‖g − g64‖₂ ≤ 2e-5·‖g64‖₂ (measured: ≤ 1e-6).  A wrong product, a wrong BatchNorm
+                   moment, a dropped partial row or a wrong reduction anywhere in the backward pass fails this by orders of
+                   magnitude; nothing is hidden behind a tolerance the builder chose.
+  decisions        the engine's masks differ from the fp64 network's own at a few dozen of 2.7·10⁸ elements; each of those has a
+                   pre-activation within the forward pass's rounding error of zero (|y64| ≤ 5e-5 at unit scale is asserted; measured
+                   ≤ 2e-5), and their number is held against PyTorch-f32's own count on the same chunk (≤ 2 × + 10).  Since round 5
+                   the training convolutions sum every tap in a chain of its own (conv_mainloop.cuh, SPLIT), the engine's forward
+                   error per layer equals ATen's (1.8e-7 σ; one chain over all 1152 products: 4.5e-7 σ and 3 – 4 × the flips).
+  plain distance   per tensor ‖g − g64(own decisions)‖₂ for the engine and for PyTorch f32 is still written to gpurun_out/ — a record
+                   of what the differing decisions move (one flip moves a tensor near the loss by 2e-5 … 4e-4 of its norm, whoever
+                   computes it: ATen's own f32 gradients miss a plain 2e-4 on 38 of 62 tensors; round 4 measured the ambiguity A of
+                   the elements within ±3e-6 of zero, profiles/r04_a_c5_realsize_gradient_parity.json) — and held loosely against
+                   PyTorch's on the same chunk (≤ 3 × + 2e-4); it is not the gate.
+  Adam             given identical gradients, parameters within 2e-7 after a step"""
 import json
 import os
 
@@ -30,7 +32,7 @@ import torch_ref
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAU = 3e-6
+TAU = 3e-6  # |pre-activation| below which a ReLU decision is counted as near zero (report only)
 
 
 def _examples(orc, n, count, seed):
@@ -47,54 +49,91 @@ def _examples(orc, n, count, seed):
     return sts, cnt.astype(np.int32), mv, visits, results
 
 
-def _fp64_gradients(net, planes, pi, z):
-    """fp64 gradients of train_inner's loss with the ReLU mask taken at y > t for t = 0, +TAU, −TAU (one forward, three
-    backward passes) → ({name: g64}, {name: ‖g64(+τ) − g64(−τ)‖₂})"""
+def _fp64_gradients(net, planes, pi, z, mask_sets):
+    """fp64 forward of train_inner's loss, then one backward pass per entry of mask_sets: None = the fp64 network's own ReLU
+    decisions, a float t = the decisions taken at y > t, a list of 21 bool arrays [B, F, n, n] = those decisions (layer order
+    conv0, res0.conv1, res0.conv2, …).  → ([{name: gradient}], [pre-activation of every ReLU as float64 numpy arrays])"""
     import copy
 
     import torch
-    import torch.nn.functional as F
 
     class Relu(torch.autograd.Function):
-        t = 0.0
+        mode = None
+        layer = 0
 
         @staticmethod
-        def forward(ctx, x):
+        def forward(ctx, x, layer):
             ctx.save_for_backward(x)
+            ctx.layer = layer
             return x.clamp_min(0.0)
 
         @staticmethod
         def backward(ctx, g):
             (x,) = ctx.saved_tensors
-            return g * (x > Relu.t)
+            m = Relu.mode
+            if m is None:
+                return g * (x > 0.0), None
+            if isinstance(m, float):
+                return g * (x > m), None
+            return g * m[ctx.layer], None
 
     n64 = copy.deepcopy(net).double().train()
     x = torch.from_numpy(planes.astype(np.float64))
-    s = Relu.apply(n64.bn0(n64.conv0(x)))
+    pres = []
+
+    def relu(t):
+        pres.append(t.detach())
+        return Relu.apply(t, len(pres) - 1)
+
+    s = relu(n64.bn0(n64.conv0(x)))
     for blk in n64.res:  # res_block.rs:13-24
-        y = Relu.apply(blk.bn1(blk.conv1(s)))
-        s = Relu.apply(blk.bn2(blk.conv2(y)) + s)
+        y = relu(blk.bn1(blk.conv1(s)))
+        s = relu(blk.bn2(blk.conv2(y)) + s)
     flat = s.reshape(s.shape[0], -1)
     logp = torch.log_softmax(n64.policy(flat), dim=1)
     v = torch.tanh(n64.value(flat))
     b = x.shape[0]
     loss = -(torch.from_numpy(pi.astype(np.float64)) * logp).sum() / b + (torch.from_numpy(np.asarray(z, np.float64))[:, None] - v).square().sum() / b
     params = list(n64.named_parameters())
-    grads = {}
-    for t in (0.0, TAU, -TAU):
-        Relu.t = t
-        gs = torch.autograd.grad(loss, [p for _, p in params], retain_graph=True)
-        grads[t] = {torch_ref.abi_name(k): g.numpy().copy() for (k, _), g in zip(params, gs)}
-    amb = {k: float(np.linalg.norm(grads[TAU][k] - grads[-TAU][k])) for k in grads[0.0]}
-    return grads[0.0], amb
+    out = []
+    for i, m in enumerate(mask_sets):
+        Relu.mode = m
+        gs = torch.autograd.grad(loss, [p for _, p in params], retain_graph=i + 1 < len(mask_sets))
+        print(f"  fp64 backward pass {i + 1} of {len(mask_sets)} done", flush=True)
+        out.append({torch_ref.abi_name(k): g.numpy().copy() for (k, _), g in zip(params, gs)})
+    return out, pres
 
 
-def test_c5_chunk_gradients_and_adam_at_the_reference_chunk_size(orc):
+def _f32_masks(net, planes):
+    """the ReLU decisions PyTorch f32 takes on this chunk (a no-grad forward in training mode: the arithmetic of its autograd run)"""
+    import copy
+
     import torch
 
+    n32 = copy.deepcopy(net).train()
+    masks = []
+    with torch.no_grad():
+        x = torch.from_numpy(planes.astype(np.float32))
+        s = torch.relu(n32.bn0(n32.conv0(x)))
+        masks.append(s > 0)
+        for blk in n32.res:
+            y = torch.relu(blk.bn1(blk.conv1(s)))
+            masks.append(y > 0)
+            s = torch.relu(blk.bn2(blk.conv2(y)) + s)
+            masks.append(s > 0)
+    return masks
+
+
+CFG = (5, 10, 128, "fc5", 500)
+CAP = 20  # res9.conv2: conv2 of a block — its data gradient is handed down without the skip path's gradient added
+
+
+@pytest.fixture(scope="module")
+def c5(orc):
+    """ONE chunk of the C5 step on the engine, with the backward pass's tensors of layer CAP kept (tg_train_debug_capture)"""
     import tak_amd
 
-    n, blocks, filters, head, count = 5, 10, 128, "fc5", 500
+    n, blocks, filters, head, count = CFG
     net = torch_ref.make_net(n, blocks, filters, head, seed=17)
     shapes = {torch_ref.abi_name(k): tuple(v.shape) for k, v in net.named_parameters()}
     e = tak_amd.Engine(n, res_blocks=blocks, filters=filters, evaluator=tak_amd.EVAL_RESNET, max_batch=64)
@@ -102,30 +141,139 @@ def test_c5_chunk_gradients_and_adam_at_the_reference_chunk_size(orc):
     lr, wd = 1e-3, 1e-2
     e.train_create(learning_rate=lr, weight_decay=wd, chunk_size=count, chunks_in_step=1000)
     ex = _examples(orc, n, count, seed=41)
+    e.train_debug_capture(CAP)
+    lp, lz, stepped = e.train_chunk(*ex)
+    assert not stepped
+    rows = count * 8 * n * n
+    run = dict(e=e, net=net, shapes=shapes, ex=ex, lp=lp, lz=lz, lr=lr, wd=wd, rows=rows,
+               g_eng={k: e.train_get_grad(k, shapes[k]) for k in shapes})
+    for what in ("dy", "dz", "dx", "z", "y", "mean", "invstd"):
+        run[what] = e.train_debug_read(what, CAP, (filters,) if what in ("mean", "invstd") else (rows, filters))
+    run["x"] = e.train_debug_read("y", CAP - 1, (rows, filters))
+    e.train_debug_capture(-1)
+    yield run
+    e.close()
+
+
+def test_one_layer_of_the_backward_pass_without_a_relu_decision(c5):
+    """Mask-free layerwise check at the real size (round 5): ONE 128 → 128 layer of the backward pass — BatchNorm backward, weight
+    gradient (k_wgrad_halo + split-K reduction), data gradient (k_conv_halo with the flipped taps) — fed the engine's own saved
+    input activation x, its ReLU mask and its upstream gradient dy, against fp64 autograd of conv → batch_norm(training) on the
+    same operands.  No ReLU decision is taken on the reference side, so the plain bound applies: ≤ 2e-5 relative per tensor.
+    The forward convolution of the same layer is held to 2.5e-7 σ rms against the fp64 convolution of the same input — what
+    ATen's f32 convolution achieves (1.8e-7 σ) and a single accumulation chain over all 1152 products does not (4.5e-7 σ).
+    Reference: alpha-tak/src/model/res_block.rs:13-24 (conv2 → bn2), network.rs:58-97 (backward through it)."""
+    import torch
+    import torch.nn.functional as F
+
+    n, blocks, filters, head, count = CFG
+    net, rows = c5["net"], c5["rows"]
+    blk = net.res[(CAP - 2) // 2]
+    conv, bn = blk.conv2, blk.bn2
+    B = rows // (n * n)
+
+    def nchw(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).double().reshape(B, n, n, filters).permute(0, 3, 1, 2).contiguous()
+
+    def nhwc(t):
+        return t.permute(0, 2, 3, 1).reshape(-1, filters).numpy()
+
+    x = nchw(c5["x"]).requires_grad_(True)
+    w = conv.weight.detach().double().requires_grad_(True)
+    b = conv.bias.detach().double().requires_grad_(True)
+    gamma = bn.weight.detach().double().requires_grad_(True)
+    beta = bn.bias.detach().double().requires_grad_(True)
+    z = F.conv2d(x, w, b, padding=1)
+    z.retain_grad()
+    out = F.batch_norm(z, None, None, gamma, beta, True, 0.0, 1e-5)
+    g = nchw(c5["dy"] * (c5["y"] > 0))  # the engine's mask on the engine's upstream gradient
+    out.backward(g)
+
+    rep = {}
+
+    def rel(name, ours, ref):
+        ref = np.asarray(ref, np.float64)
+        rep[name] = float(np.linalg.norm(np.asarray(ours, np.float64) - ref) / np.linalg.norm(ref))
+
+    z64 = nhwc(z.detach())
+    sigma = z64.std(0)
+    rep["forward z: rms error / sigma"] = float(np.sqrt((((c5["z"] - z64) / sigma) ** 2).mean()))
+    rel("BatchNorm mean (of sigma)", c5["mean"] / sigma, z64.mean(0) / sigma)
+    rel("BatchNorm invstd", c5["invstd"], 1.0 / np.sqrt(z64.var(0) + 1e-5))
+    rel("dz (BatchNorm backward)", c5["dz"], nhwc(z.grad))
+    rel("dx (data gradient)", c5["dx"], nhwc(x.grad))
+    name = f"res{(CAP - 2) // 2}"
+    rel("dW (weight gradient)", c5["g_eng"][f"{name}.conv2.weight"], w.grad.numpy())
+    rel("dgamma", c5["g_eng"][f"{name}.bn2.weight"], gamma.grad.numpy())
+    rel("dbeta", c5["g_eng"][f"{name}.bn2.bias"], beta.grad.numpy())
+    print("layerwise check, layer", CAP, json.dumps(rep, indent=1))
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "c5_realsize_layerwise_backward.json"), "w") as f:
+            json.dump(dict(layer=CAP, tensors=rep), f, indent=1)
+    except OSError:
+        pass
+    assert rep["forward z: rms error / sigma"] <= 2.5e-7, rep
+    assert rep["BatchNorm invstd"] <= 2e-7 and rep["BatchNorm mean (of sigma)"] <= 2e-6, rep
+    for k in ("dz (BatchNorm backward)", "dx (data gradient)", "dW (weight gradient)", "dgamma", "dbeta"):
+        assert rep[k] <= 2e-5, (k, rep)
+    # the conv bias gradient (true value: zero, BatchNorm removes the mean) against the scale of dz's column sums' terms
+    gb = c5["g_eng"][f"{name}.conv2.bias"]
+    assert np.abs(gb).max() <= 1e-6 * np.abs(c5["dz"]).sum(0).max(), float(np.abs(gb).max())
+
+
+def test_c5_chunk_gradients_and_adam_at_the_reference_chunk_size(orc, c5):
+    import torch
+
+    n, blocks, filters, head, count = CFG
+    e, net, shapes, ex, lp, lz, lr, wd = (c5[k] for k in ("e", "net", "shapes", "ex", "lp", "lz", "lr", "wd"))
     sts, cnt, mv, visits, results = ex
     a_states, pi = orc.augment(n, orc.HEAD_FC5, sts, cnt, mv, visits)
     planes, z = orc.encode(n, a_states), np.repeat(results, 8)
-    assert planes.shape[0] == 4000
-
-    lp, lz, stepped = e.train_chunk(*ex)
-    assert not stepped
-    g_eng = {k: e.train_get_grad(k, shapes[k]) for k in shapes}
+    B = planes.shape[0]
+    assert B == 4000
+    g_eng = c5["g_eng"]
+    L = 1 + 2 * blocks
+    # the engine's ReLU decisions, layer by layer ([rows][F] NHWC → [B, F, n, n])
+    m_eng = [torch.from_numpy(e.train_debug_read("y", l, (c5["rows"], filters)) > 0).reshape(B, n, n, filters).permute(0, 3, 1, 2) for l in range(L)]
 
     lp_ref, lz_ref = torch_ref.train_chunk(net, planes, pi, z)  # PyTorch f32 autograd
     g32 = torch_ref.named_grads(net)
     assert abs(lp - lp_ref) <= 1e-5 * abs(lp_ref) and abs(lz - lz_ref) <= 1e-5 * max(abs(lz_ref), 1e-3), (lp, lp_ref, lz, lz_ref)
-    g64, amb = _fp64_gradients(net, planes, pi, z)
+    m_t32 = _f32_masks(net, planes)
+    # The gate needs ONE fp64 backward pass (the engine's decisions).  TG_C5_FULL_AUDIT=1 (scripts/collect_evidence.sh; the record in
+    # profiles/) adds two more — the fp64 network's own decisions and PyTorch f32's — for the plain distances and ATen's own error
+    # under fixed decisions; each pass costs a minute of CPU time.
+    full = os.environ.get("TG_C5_FULL_AUDIT", "0") != "0"
+    print(f"PyTorch f32 done; fp64 forward and {3 if full else 1} backward pass(es) …", flush=True)
+    gs, pres = _fp64_gradients(net, planes, pi, z, [m_eng, None, m_t32] if full else [m_eng])
+    g64e = gs[0]
+    g64, g64t = (gs[1], gs[2]) if full else (None, None)
 
-    scale = np.sqrt(sum(float((g ** 2).sum()) for g in g64.values()) / sum(g.size for g in g64.values()))
+    # ---- the decisions themselves ----
+    flips = []
+    for l in range(L):
+        own = pres[l] > 0
+        de, dt = m_eng[l] != own, m_t32[l] != own
+        flips.append(dict(layer=l, engine=int(de.sum()), torch_f32=int(dt.sum()), near_zero=int((pres[l].abs() < TAU).sum()),
+                          engine_max_abs_pre=float(pres[l][de].abs().max()) if de.any() else 0.0,
+                          torch_f32_max_abs_pre=float(pres[l][dt].abs().max()) if dt.any() else 0.0))
+    n_eng, n_t32 = sum(f["engine"] for f in flips), sum(f["torch_f32"] for f in flips)
+    print(f"ReLU decisions that differ from the fp64 network's, of {L * B * filters * n * n}: engine {n_eng}, PyTorch f32 {n_t32};"
+          f" largest |pre-activation| among them: engine {max(f['engine_max_abs_pre'] for f in flips):.2e}, PyTorch f32 {max(f['torch_f32_max_abs_pre'] for f in flips):.2e}")
+
+    scale = np.sqrt(sum(float((g ** 2).sum()) for g in g64e.values()) / sum(g.size for g in g64e.values()))
     rows = []
     for name in shapes:
-        nrm = float(np.linalg.norm(g64[name]))
-        ours = float(np.linalg.norm(g_eng[name].astype(np.float64) - g64[name]))
-        theirs = float(np.linalg.norm(g32[name].astype(np.float64) - g64[name]))
-        both = float(np.linalg.norm(g_eng[name].astype(np.float64) - g32[name].astype(np.float64)))
-        rows.append(dict(tensor=name, norm=nrm, engine_vs_fp64=ours, torch_f32_vs_fp64=theirs, engine_vs_torch_f32=both, ambiguity=amb[name]))
+        d = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b))  # noqa: E731
+        r = dict(tensor=name, norm=float(np.linalg.norm(g64e[name])), engine_vs_fp64_same_decisions=d(g_eng[name], g64e[name]),
+                 engine_vs_torch_f32=d(g_eng[name], g32[name].astype(np.float64)))
+        if full:
+            r.update(torch_f32_vs_fp64_same_decisions=d(g32[name], g64t[name]), engine_vs_fp64=d(g_eng[name], g64[name]),
+                     torch_f32_vs_fp64=d(g32[name], g64[name]))
+        rows.append(r)
     report = dict(config="C5 network 5x5 10x128, one chunk of 500 examples x 8 symmetries (100000 rows)", tau=TAU,
-                  loss_p=[lp, lp_ref], loss_z=[lz, lz_ref], tensors=rows)
+                  loss_p=[lp, lp_ref], loss_z=[lz, lz_ref], relu_decisions=flips, tensors=rows)
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "c5_realsize_gradient_parity.json"), "w") as f:
@@ -133,23 +281,27 @@ def test_c5_chunk_gradients_and_adam_at_the_reference_chunk_size(orc):
     except OSError:
         pass
 
-    rel = []
-    worst = None
+    # every decision the engine takes differently lies within the forward pass's rounding error of zero, and there are not many
+    assert max(f["engine_max_abs_pre"] for f in flips) <= 5e-5, flips
+    assert n_eng <= 2 * n_t32 + 10, (n_eng, n_t32)
+    worst_same = worst_plain = ("", 0.0)
     for r in rows:
         name = r["tensor"]
-        bias_before_bn = name.endswith(".bias") and "conv" in name and not name.startswith("policy")
-        if bias_before_bn:  # true gradient is exactly zero; both sides hold rounding noise
+        if name.endswith(".bias") and "conv" in name and not name.startswith("policy"):  # true gradient exactly zero: rounding noise
             assert np.abs(g_eng[name]).max() <= 1e-3 * scale * np.sqrt(4000 * n * n), name
             continue
-        bound = 2e-4 * r["norm"] + 2.0 * r["ambiguity"] + 1e-12
-        assert r["engine_vs_fp64"] <= bound, ("engine", r)
-        rel.append(r["engine_vs_fp64"] / r["norm"])
-        if worst is None or rel[-1] > worst[1]:
-            worst = (name, rel[-1], r["torch_f32_vs_fp64"] / r["norm"], r["ambiguity"] / r["norm"])
-        if name.startswith("policy.") or name.startswith("value."):  # no ReLU mask between these and the loss
-            assert r["ambiguity"] == 0.0 and r["engine_vs_fp64"] <= 2e-4 * r["norm"] + 1e-12, r
-    print("worst tensor (name, engine vs fp64, PyTorch f32 vs fp64, ambiguity; all relative):", worst)
-    assert np.median(rel) <= 2e-4 + float(np.median([r["ambiguity"] / r["norm"] for r in rows if r["norm"] > 0])), np.median(rel)
+        # THE gate: with the same ReLU decisions, no allowance
+        same = r["engine_vs_fp64_same_decisions"] / r["norm"]
+        assert same <= 2e-5, ("engine, same decisions", r)
+        worst_same = max(worst_same, (name, same), key=lambda t: t[1])
+        if full:
+            # the plain distance (own decisions on the reference side) is what the differing decisions move — on both sides: the
+            # engine's against PyTorch f32's on the same chunk (each a handful of random single elements: a loose factor)
+            assert r["engine_vs_fp64"] <= 3.0 * r["torch_f32_vs_fp64"] + 2e-4 * r["norm"], ("engine, own decisions", r)
+            worst_plain = max(worst_plain, (name, r["engine_vs_fp64"] / r["norm"]), key=lambda t: t[1])
+    print("worst tensor with the engine's ReLU decisions on the fp64 side (relative):", worst_same)
+    if full:
+        print("worst tensor against the fp64 network's own decisions (relative):", worst_plain)
     gb = g_eng["policy.bias"]  # every row of dLogits sums to zero → so does the policy bias gradient
     assert abs(float(gb.astype(np.float64).sum())) <= 1e-5
 
@@ -165,4 +317,51 @@ def test_c5_chunk_gradients_and_adam_at_the_reference_chunk_size(orc):
         # lr·m̂/(√v̂ + eps): float rounding only, except where g + wd·p cancels down to the order of eps = 1e-8
         assert np.quantile(d, 0.999) <= 2e-7 and d.max() <= 1.001 * lr, (name, float(d.max()))
         assert np.abs(e.train_get_grad(name, shapes[name])).max() == 0.0  # zero_grad
-    e.close()
+
+
+GRAD_DUMP = r"""
+import sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+import numpy as np
+import tak_amd, torch_ref
+from oracle import oracle as orc
+import test_gpu_c5_realsize as T
+n, blocks, filters, head, count = T.CFG
+net = torch_ref.make_net(n, blocks, filters, head, seed=17)
+e = tak_amd.Engine(n, res_blocks=blocks, filters=filters, evaluator=tak_amd.EVAL_RESNET, max_batch=64)
+e.load_state_dict(torch_ref.abi_tensors(net))
+e.train_create(chunk_size=count, chunks_in_step=1000)
+lp, lz, _ = e.train_chunk(*T._examples(orc, n, count, seed=41))
+out = dict(loss=np.float32([lp, lz]))
+for k, v in net.named_parameters():
+    out[torch_ref.abi_name(k)] = e.train_get_grad(torch_ref.abi_name(k), tuple(v.shape))
+np.savez({out!r}, **out)
+"""
+
+
+def test_fused_backward_sums_and_two_streams_by_value_at_the_real_size(tmp_path):
+    """The default path (BatchNorm-backward sums from the data-gradient convolution's epilogue, weight gradients on their own stream)
+    against the plain path (TG_NO_BWD_SUMS_FUSION=1: a pass over dy, y, z; TG_TRAIN_ONE_STREAM=1) at B = 4000, where the partial-row
+    counts differ from the small configurations the bit-exact A/B digests run at.  The forward pass — and with it every ReLU mask —
+    is the same in both, so apart from the order of two double-precision sums per channel the gradients must agree: ≤ 1e-5
+    relative per tensor, no allowance.  A dropped or mis-indexed partial row would cost O(1e-3)."""
+    import subprocess
+    import sys
+
+    def run(tag, **env):
+        e = {k: v for k, v in os.environ.items() if not k.startswith("TG_")}
+        e.update(env)
+        path = str(tmp_path / f"{tag}.npz")
+        subprocess.run([sys.executable, "-c", GRAD_DUMP.format(root=ROOT, out=path)], env=e, check=True, timeout=600)
+        return dict(np.load(path))
+
+    a, b = run("default"), run("plain", TG_NO_BWD_SUMS_FUSION="1", TG_TRAIN_ONE_STREAM="1")
+    assert np.array_equal(a["loss"], b["loss"])
+    worst = ("", 0.0)
+    for k in a:
+        if k == "loss" or (k.endswith(".bias") and "conv" in k and not k.startswith("policy")):
+            continue  # (conv biases in front of a BatchNorm: zero true gradient, rounding noise on both sides)
+        r = float(np.linalg.norm(a[k].astype(np.float64) - b[k].astype(np.float64)) / np.linalg.norm(b[k].astype(np.float64)))
+        worst = max(worst, (k, r), key=lambda t: t[1])
+        assert r <= 1e-5, (k, r)
+    print("default vs plain backward at B = 4000: worst tensor", worst)

@@ -13,7 +13,9 @@ G = 4096
 def c2(orc):
     import tak_amd
 
-    net = torch_ref.make_net(5, 6, 64, "fc5", seed=0, randomize_bn=False)
+    # (round 5: randomised BatchNorm affine parameters and running statistics — k_tower_halo and the constant-planes-as-bias table
+    # meet a non-trivial fold against PyTorch directly, on the full batch)
+    net = torch_ref.make_net(5, 6, 64, "fc5", seed=0, randomize_bn=True)
     tensors = torch_ref.abi_tensors(net)
     e = tak_amd.Engine(5, res_blocks=6, filters=64, evaluator=tak_amd.EVAL_RESNET, max_batch=G)
     e.load_state_dict(tensors)
@@ -46,15 +48,17 @@ def test_policy_eval_full_batch_properties(c2, orc):
         p_ref, v_ref = torch_ref.forward(net, orc.encode(5, sts[lo : lo + 512]))
         worst_p = max(worst_p, float(np.abs(p[lo : lo + 512] - p_ref).max()))
         worst_v = max(worst_v, float(np.abs(v[lo : lo + 512] - v_ref).max()))
+    print(f"c2_f32 (randomised BatchNorm fold): worst |dp| {worst_p:.3e}, worst |dv| {worst_v:.3e} over all {G} rows")
     assert worst_p <= 1e-4 and worst_v <= 1e-4, (worst_p, worst_v)
 
 
 def _all_rows_against_pytorch(orc, n, blocks, filters, head, precision, rows, seed, chunk=512):
     """policy_eval on a FULL batch of 4096 positions (the kernel instantiations the benchmarks run) against PyTorch fp32 on
-    `rows` (all 4096, or every 4th): worst |Δ| of policy and eval (north_star: ≤ 1e-4)."""
+    `rows` (all 4096, or every 4th): worst |Δ| of policy and eval (north_star: ≤ 1e-4).  BatchNorm's affine parameters and running
+    statistics are randomised (round 5), so the fold is not the identity."""
     import tak_amd
 
-    net = torch_ref.make_net(n, blocks, filters, head, seed=seed, randomize_bn=False)
+    net = torch_ref.make_net(n, blocks, filters, head, seed=seed, randomize_bn=True)
     e = tak_amd.Engine(n, res_blocks=blocks, filters=filters, evaluator=tak_amd.EVAL_RESNET, max_batch=G)
     if precision != "f32":
         e.set_precision(precision)
@@ -76,6 +80,11 @@ def _all_rows_against_pytorch(orc, n, blocks, filters, head, precision, rows, se
 
 
 @pytest.mark.parametrize("name,n,blocks,filters,head,precision,rows", [
+    # the reference's own shipped topologies — the networks existing weights would load into — on the full-batch kernels, exact f32,
+    # ALL 4096 rows: Net5 = 5×5, 8 blocks × 128 filters, FC head (alpha-tak/src/model/net5.rs:16-17, 76-111) and
+    # Net6 = 6×6, 16 blocks × 128 filters, conv head (net6.rs:16-17, 75-109)
+    ("net5_reference_8x128_f32", 5, 8, 128, "fc5", "f32", 4096),
+    ("net6_reference_16x128_f32", 6, 16, 128, "conv", "f32", 4096),
     # the C5 network's full-batch tower k_tower_halo<…,37> and its ring FC, exact f32: ALL 4096 rows
     ("c5net_f32", 5, 10, 128, "fc5", "f32", 4096),
     # the split-bf16 towers k_tower_s3_halo and k_fc_s3b on the C2 network: ALL 4096 rows
@@ -209,7 +218,7 @@ def test_config_c3_full_size(orc):
     import tak_amd
 
     n, blocks, filters = 6, 10, 128
-    net = torch_ref.make_net(n, blocks, filters, "conv", seed=0, randomize_bn=False)
+    net = torch_ref.make_net(n, blocks, filters, "conv", seed=0, randomize_bn=True)
     tensors = torch_ref.abi_tensors(net)
     e = tak_amd.Engine(n, res_blocks=blocks, filters=filters, evaluator=tak_amd.EVAL_RESNET, max_batch=G)
     e.load_state_dict(tensors)
@@ -226,6 +235,7 @@ def test_config_c3_full_size(orc):
         p_ref, v_ref = torch_ref.forward(net, orc.encode(n, sts[sel]))
         worst_p = max(worst_p, float(np.abs(p[sel] - p_ref).max()))
         worst_v = max(worst_v, float(np.abs(v[sel] - v_ref).max()))
+    print(f"c3_f32 (randomised BatchNorm fold): worst |dp| {worst_p:.3e}, worst |dv| {worst_v:.3e} over all {G} rows")
     assert worst_p <= 1e-4 and worst_v <= 1e-4, (worst_p, worst_v)
     assert np.array_equal(p[0], p[len(base)]) and v[0] == v[len(base)]  # same position, another slot of the batch
     iters = 12

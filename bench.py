@@ -213,31 +213,63 @@ class Watchdog:
         return False
 
 
-def run_c5_phase(args, rank, world, out, phase, want_result=False):
+def run_c5_phase(args, rank, world, out, phase, want_result=False, dist=None):
     """Config C5's phase — the only part of the bench with a data-path collective — under the rules that keep a bad day
-    visible: an exception is caught (rank 0's headline line survives, marked `train_c5_failed`), and at N > 1 a watchdog bounds
-    the phase: if a collective never completes, rank 0 prints the line it has (marked) and EVERY rank leaves with
-    EXIT_C5_FAILED straight from the timer thread (os._exit: a fresh exit, nothing is exec'ed).  → (out, failed[, result])"""
+    visible: an exception is caught (rank 0's headline line survives, marked `train_c5_failed`), and at N > 1
+      * a watchdog bounds the phase: if a collective never completes, rank 0 prints the line it has (marked) and EVERY rank leaves
+        with EXIT_C5_FAILED straight from the timer thread (os._exit: a fresh exit, nothing is exec'ed);
+      * a rank != 0 that raises inside the phase — also where no agreement protects it: inside tg_train, between two reductions —
+        posts the failure on the rendezvous store and waits for rank 0's acknowledgement before it leaves (tak_amd.dist.FailureBoard);
+        rank 0 polls the store from a thread while its main thread may sit in the all-reduce the failed rank never joins, prints its
+        line (marked, naming the rank) and leaves: the launcher ends all ranks at the first non-zero exit, and the headline is out
+        by then.  → (out, failed[, result])"""
+    from tak_amd import dist as tdist
+
+    printed = threading.Lock()
+
+    def print_marked(error):
+        if rank == 0 and out is not None and printed.acquire(blocking=False):
+            out["train_c5_failed"] = True
+            out.setdefault("extra", {})["train_c5"] = {"error": error}
+            print(json.dumps(out), flush=True)
+
     def give_up():
         print(f"bench.py: rank {rank}: the C5 phase did not finish within {args.train_timeout:.0f} s", file=sys.stderr, flush=True)
-        if rank == 0 and out is not None:
-            out["train_c5_failed"] = True
-            out.setdefault("extra", {})["train_c5"] = {"error": f"timed out after {args.train_timeout:.0f} s (world {world})"}
-            print(json.dumps(out), flush=True)
+        print_marked(f"timed out after {args.train_timeout:.0f} s (world {world})")
+
+    board = tdist.FailureBoard(dist) if world > 1 else None
+    stop = threading.Event()
+
+    def watch_peers():  # rank 0 only
+        while not stop.wait(0.25):
+            msg = board.posted()
+            if msg:
+                print(f"bench.py: rank 0: {msg} — leaving the C5 phase", file=sys.stderr, flush=True)
+                print_marked(f"another rank failed inside the phase ({msg})")
+                board.acknowledge()
+                sys.stdout.flush()
+                os._exit(EXIT_C5_FAILED)
 
     failed = False
     try:
         if world > 1:
+            if rank == 0 and board.store is not None:
+                threading.Thread(target=watch_peers, daemon=True).start()
             # (rank 0 first, so that its line is out before the launcher sees another rank's exit code and ends the rest)
             with Watchdog(args.train_timeout + (0.0 if rank == 0 else 15.0), give_up, EXIT_C5_FAILED):
                 c5 = phase()
         else:
             c5 = phase()
     except Exception as ex:
-        if args.train:
+        if args.train and world == 1:
             raise
         c5, failed = {"error": repr(ex)}, True
         print(f"bench.py: rank {rank}: config C5 failed: {ex!r}", file=sys.stderr, flush=True)
+        if world > 1 and rank != 0:
+            board.post(rank, repr(ex))
+            board.wait_acknowledged(20.0)  # rank 0 prints first (or is past the phase already and prints in finish())
+    finally:
+        stop.set()
     if rank == 0 and out is not None and not args.train:
         out.setdefault("extra", {})["train_c5"] = c5
         if failed:
@@ -354,6 +386,7 @@ def train_c5(args, rank, world, local_rank, dist, backend, barrier_fn):
     dt_local = time.perf_counter() - t0
     barrier_fn(eng)
     dt, positions = tdist.reduce_time_and_count(dist, dt_local, need * 8, device=dev)
+    reporting = tdist.ranks_reporting(dist, device=dev)
     ar_ms, ar_n = eng.train_comm_stats()
     # identical parameters on every rank after the all-reduced steps
     w = eng.train_get_tensor("value.weight", (1, filters * n * n))
@@ -370,7 +403,7 @@ def train_c5(args, rank, world, local_rank, dist, backend, barrier_fn):
     per_gpu = positions / dt / world
     return {
         "metric": "training positions/s (forward + backward + Adam; 8-fold augmented examples)", "value": positions / dt, "unit": "positions/s",
-        "n_gpus": world, "seconds": dt, "optimizer_steps": steps, "ms_per_optimizer_step": 1000.0 * dt / max(steps, 1),
+        "per_gpu_value": per_gpu, "n_gpus": world, "ranks_reporting": reporting, "seconds": dt, "optimizer_steps": steps, "ms_per_optimizer_step": 1000.0 * dt / max(steps, 1),
         "positions_per_rank": need * 8, "loss_p": lp, "loss_z": lz,
         "frac_of_f32_mfma_peak": (per_gpu * flops / 1e12 / F32_MFMA_PEAK_TFLOPS) if flops else None,
         "gradient_allreduce": {"transport": transport, "bytes": None if world == 1 else int(eng_param_bytes(blocks, filters, n)),
@@ -439,6 +472,9 @@ def main():
                     help="with --rehearse-launch: this rank never joins the rehearsed collective (the watchdog must end the run, non-zero)")
     ap.add_argument("--rehearse-fail-rank", type=int, default=-1,
                     help="with --rehearse-launch: this rank raises before the rehearsed collective (every rank must leave at once, non-zero)")
+    ap.add_argument("--rehearse-fail-in-collective-rank", type=int, default=-1,
+                    help="with --rehearse-launch: this rank raises BEHIND the agreement, while the others wait in the rehearsed collective "
+                         "(rank 0 must learn it from the store, print its line and every rank must leave, non-zero, long before the watchdog)")
     args = ap.parse_args()
 
     from tak_amd import dist as tdist
@@ -461,9 +497,10 @@ def main():
         if dist is not None:
             dist.barrier()
         dt, total = tdist.reduce_time_and_count(dist, 1.0 + rank, 1 + rank)
-        out = {"metric": "launcher rehearsal (no measurement)", "value": None, "unit": "node-expansions/s", "n_gpus": world,
-               "steps": args.steps, "warmup": args.warmup, "rehearsal": True, "max_over_ranks": dt, "sum_over_ranks": total}
-        if args.rehearse_hang_rank >= 0 or args.rehearse_fail_rank >= 0:
+        out = {"metric": "launcher rehearsal (no measurement)", "value": None, "per_gpu_value": None, "unit": "node-expansions/s", "n_gpus": world,
+               "ranks_reporting": tdist.ranks_reporting(dist), "steps": args.steps, "warmup": args.warmup, "rehearsal": True,
+               "max_over_ranks": dt, "sum_over_ranks": total}
+        if args.rehearse_hang_rank >= 0 or args.rehearse_fail_rank >= 0 or args.rehearse_fail_in_collective_rank >= 0:
             # the two ways config C5 can go wrong at N > 1, acted out with the code the real phase uses: a rank that fails before
             # the collective (Stages: every rank leaves, nobody waits) and a collective that never completes (Watchdog)
             def phase():
@@ -473,9 +510,11 @@ def main():
                 tdist.Stages(dist, rank).run("rehearsed stage", local)
                 if rank == args.rehearse_hang_rank:
                     time.sleep(3600.0)
-                tdist.reduce_min(dist, 1.0)  # the "gradient all-reduce" the hanging rank never joins
+                if rank == args.rehearse_fail_in_collective_rank:
+                    raise RuntimeError("rehearsed failure between two reductions")  # behind the agreement, where only the board helps
+                tdist.reduce_min(dist, 1.0)  # the "gradient all-reduce" the hanging / failed rank never joins
                 return {"rehearsed": True}
-            out, c5_failed = run_c5_phase(args, rank, world, out if rank == 0 else None, phase)
+            out, c5_failed = run_c5_phase(args, rank, world, out if rank == 0 else None, phase, dist=dist)
             finish(rank, world, out, c5_failed, dist)
             return
         if rank == 0:
@@ -551,13 +590,16 @@ def main():
     if not args.train:
         dt_local, expansions, evals, prof = run(args.precision, args.profile_every)
         dt, total_exp = tdist.reduce_time_and_count(dist, dt_local, expansions, device="cuda" if backend == "nccl" else "cpu")
+        reporting = tdist.ranks_reporting(dist, device="cuda" if backend == "nccl" else "cpu")
 
         if rank == 0:
             out = {
                 "metric": f"MCTS node-expansions/sec ({args.board}x{args.board} Tak, {args.rollouts} sims/move, {args.games} games/GPU)",
-                "value": total_exp / dt,
+                "value": total_exp / dt,          # the whole job: all ranks' expansions over the slowest rank's time
+                "per_gpu_value": total_exp / dt / world,
                 "unit": "node-expansions/s",
                 "n_gpus": world,
+                "ranks_reporting": reporting,     # ranks whose counts are in `value` (a SUM all-reduce of 1 per rank)
                 "steps": args.steps,
                 "warmup": args.warmup,
                 "ms_per_step": 1000.0 * dt / max(args.steps, 1),
@@ -577,7 +619,7 @@ def main():
             if prof and prof["conv_launches"]:
                 avg_ms = prof["conv_ms"] / prof["conv_launches"]
                 achieved = prof["conv_flops"] / (avg_ms * 1e-3) / 1e12
-                traffic = None
+                traffic = None  # not measured in this run: read from the committed counter pass of the same kernel
                 pmc = os.path.join(ROOT, "profiles", "pmc_conv.json")
                 if os.path.exists(pmc):
                     try:
@@ -591,7 +633,10 @@ def main():
                 out["roofline"] = {
                     "bound": "mfma", "kernel": kernel,
                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                    "traffic": traffic, "avg_launch_ms": avg_ms, "launches_timed": prof["conv_launches"],
+                    "traffic": traffic,
+                    "traffic_source": "profiles/pmc_conv.json: a separate rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_WRREQ pass over the same kernel "
+                                      "(scripts/collect_evidence.sh), committed — not collected in this run" if traffic is not None else None,
+                    "avg_launch_ms": avg_ms, "launches_timed": prof["conv_launches"],
                     "flops_per_launch": prof["conv_flops"], "rows_per_launch": prof["conv_rows"],
                     # what the MFMA pipe actually issued: the constant input planes (reserves, colour, fcd: 46 of the 72) enter
                     # layer 0 as a per-position bias, so fewer MFMAs run than the algorithmic count — `frac` can exceed this
@@ -644,10 +689,11 @@ def main():
     # config C5 on every rank (the only part of the bench with a data-path collective)
     c5_failed = False
     if args.train or not (args.no_train or args.no_extras or args.precision != "f32"):
-        out, c5_failed, c5 = run_c5_phase(args, rank, world, out, lambda: train_c5(args, rank, world, local_rank, dist, backend, barrier), want_result=True)
+        out, c5_failed, c5 = run_c5_phase(args, rank, world, out, lambda: train_c5(args, rank, world, local_rank, dist, backend, barrier), want_result=True, dist=dist)
         if rank == 0 and args.train:
             out = {
-                "metric": c5["metric"], "value": c5["value"], "unit": c5["unit"], "n_gpus": world, "steps": c5["optimizer_steps"], "warmup": 0,
+                "metric": c5["metric"], "value": c5["value"], "per_gpu_value": c5["value"] / world, "unit": c5["unit"], "n_gpus": world,
+                "ranks_reporting": c5["ranks_reporting"], "steps": c5["optimizer_steps"], "warmup": 0,
                 "ms_per_step": c5["ms_per_optimizer_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                 "data": "synthetic (examples from the network's own self-play)",
                 "config": {"workload": c5["workload"], "parallelism": f"data parallel x{world}, one gradient all-reduce per optimiser step"},

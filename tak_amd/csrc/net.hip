@@ -788,6 +788,8 @@ int tg_policy_eval_dev(TgEngine* e, int n, const void* d_states, float* d_policy
     if (!net_ready(e)) return fail(TG_ERR_STATE, "network weights not finalized (tg_net_finalize)");
     if (n < 0 || n > e->cfg.max_batch) return fail(TG_ERR_INVALID_ARG, "tg_policy_eval_dev: n out of range");
     if (n == 0) return TG_OK;
+    // (logits-only forwards — d_policy = nullptr — are the search's private contract with the FC's gather epilogue)
+    if (!d_states || !d_policy || !d_eval) return fail(TG_ERR_INVALID_ARG, "tg_policy_eval_dev: null argument");
     TG_HIP(hipSetDevice(e->cfg.device));
     return net_forward_states_dev(e, n, (const uint8_t*)d_states, d_policy, d_eval);
 }

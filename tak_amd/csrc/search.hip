@@ -269,10 +269,18 @@ static void bind_logits(TgEngine* e) {
     }
 }
 
+// The gather target is armed for the iterations of ONE call and disarmed when it returns: a later logits-only forward by anyone
+// else must not find the search's buffers behind a stale pointer.
+struct GatherScope {
+    TgEngine* e;
+    ~GatherScope() { net_set_gather(e, nullptr); }
+};
+
 // one lock-step iteration: the body of train/src/self_play.rs:181-210
 static int search_iterate(TgEngine* e, const uint8_t* d_active) {
     Search* s = e->search;
     bind_logits(e);
+    GatherScope scope{e};
     // `batch` virtual rollouts per tree (Player's batching model, alpha-tak/src/player.rs:77-93) run back to back inside the
     // select kernel (a game's tree belongs to one wave), then ONE network batch of games × batch leaves, then the
     // de-virtualisations in the same order inside the backup kernel
@@ -321,6 +329,7 @@ static int search_iterate_many(TgEngine* e, int iters) {
     Search* s = e->search;
     if (iters <= 0) return TG_OK;
     bind_logits(e);
+    GatherScope scope{e};
     if (!dual_stream_ok(e)) {
         if (s->d.batch == 1 && iters > 1 && !getenv("TG_NO_FUSED_BACKUP_SELECT")) {
             // select(0) | net | backup(0)+select(1) | net | … | backup(iters-1): one tree kernel per iteration

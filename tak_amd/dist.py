@@ -41,6 +41,18 @@ def reduce_time_and_count(dist, dt_local, count_local, device="cpu"):
     return float(t.item()), int(c.item())
 
 
+def ranks_reporting(dist, device="cpu"):
+    """how many ranks took part in the reductions behind the reported total (a SUM all-reduce of 1 per rank): the line says so
+    itself instead of leaving it to be inferred from WORLD_SIZE"""
+    if dist is None:
+        return 1
+    import torch
+
+    t = torch.ones(1, dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
 def reduce_min(dist, value, device="cpu"):
     if dist is None:
         return value
@@ -74,6 +86,57 @@ class Stages:
             result, failure = None, ex
         self.agree(name, failure)
         return result
+
+
+class FailureBoard:
+    """A side channel beside the collectives, for the phase whose collectives may hang: the rendezvous store torch.distributed
+    already runs (hosted by rank 0's process, served by its own thread — reachable while rank 0's main thread sits in a collective).
+    A rank that fails where no agreement protects it (inside tg_train, between two reductions) posts here and then waits for
+    rank 0's acknowledgement before it exits non-zero: the launcher (launch_ranks, torch.distributed.run) ends every rank at the
+    first non-zero exit, and rank 0 — still waiting in the all-reduce for the rank that failed — must have printed its headline
+    line by then.  Rank 0 polls the board from a thread while the phase runs (bench.run_c5_phase)."""
+
+    KEY, ACK = "tak_c5_failure", "tak_c5_rank0_printed"
+
+    def __init__(self, dist):
+        self.store = None
+        if dist is not None:
+            try:
+                from torch.distributed.distributed_c10d import _get_default_store
+
+                self.store = _get_default_store()
+            except Exception:  # noqa: BLE001 — no store: the watchdog alone bounds the phase
+                self.store = None
+
+    def post(self, rank, what):
+        if self.store is not None:
+            self.store.set(self.KEY, f"rank {rank}: {what}")
+
+    def posted(self):
+        """the posted message, or None"""
+        if self.store is None:
+            return None
+        try:
+            return self.store.get(self.KEY).decode() if self.store.check([self.KEY]) else None
+        except Exception:  # noqa: BLE001
+            return None
+
+    def acknowledge(self):
+        if self.store is not None:
+            self.store.set(self.ACK, "1")
+
+    def wait_acknowledged(self, seconds):
+        import time
+
+        t0 = time.time()
+        while self.store is not None and time.time() - t0 < seconds:
+            try:
+                if self.store.check([self.ACK]):
+                    return True
+            except Exception:  # noqa: BLE001 — rank 0 (the store's host) is gone: nothing left to wait for
+                return False
+            time.sleep(0.1)
+        return False
 
 
 def training_shard(n_examples, rank, world, chunk_size):

@@ -29,6 +29,7 @@ def test_direct_invocation_spawns_the_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["rehearsal"] is True and out["value"] is None
     assert out["max_over_ranks"] == 2.0 and out["sum_over_ranks"] == 3  # ranks contributed (1 + rank): max 2, sum 3
+    assert out["ranks_reporting"] == 2
 
 
 def test_torchrun_form_still_works():
@@ -74,6 +75,8 @@ def test_eight_ranks_at_the_real_fan_out():
     assert len(lines) == 1, lines
     out = json.loads(lines[0])
     assert out["n_gpus"] == 8 and out["max_over_ranks"] == 8.0 and out["sum_over_ranks"] == 36
+    # the line explains itself on the day the scaling runs happen: who contributed, and the per-GPU figure beside the whole-job one
+    assert out["ranks_reporting"] == 8 and "per_gpu_value" in out
 
 
 @pytest.mark.parametrize("world", [2, 8])
@@ -109,3 +112,22 @@ def test_a_rank_that_fails_before_the_collective_releases_the_others():
     assert out["train_c5_failed"] is True and "rehearsed local failure" not in out["extra"]["train_c5"]["error"]  # rank 0 saw "another rank failed"
     assert "another rank failed" in out["extra"]["train_c5"]["error"]
     assert "rehearsed local failure" in err
+
+
+@pytest.mark.parametrize("world,bad", [(2, 1), (8, 5)])
+def test_a_rank_that_fails_inside_the_collective_phase_does_not_cost_the_headline(world, bad):
+    """a rank != 0 raises behind the last agreement (inside tg_train, between two reductions) while rank 0 waits in
+    the collective.  Its non-zero exit makes the launcher end every rank — so it posts the failure on the rendezvous store and
+    leaves only once rank 0 (whose polling thread sees the post) has printed the marked headline.  Far inside the watchdog."""
+    import time
+
+    from bench import EXIT_C5_FAILED
+
+    t0 = time.time()
+    rc, lines, err = _launch("--gpus", str(world), "--train-timeout", "600", "--rehearse-fail-in-collective-rank", str(bad), timeout=240)
+    assert rc == EXIT_C5_FAILED, (rc, err[-2000:])
+    assert time.time() - t0 < 120, "waited for the watchdog"
+    assert len(lines) == 1, (lines, err[-2000:])
+    out = json.loads(lines[0])
+    assert out["train_c5_failed"] is True and out["n_gpus"] == world
+    assert f"rank {bad}" in out["extra"]["train_c5"]["error"] and "rehearsed failure between two reductions" in out["extra"]["train_c5"]["error"]

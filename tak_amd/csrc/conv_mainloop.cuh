@@ -283,81 +283,4 @@ __device__ __forceinline__ void conv_halo_first_weights(const float* __restrict_
     w1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, (int)WCHUNK, 0));
 }
 
-// ------------------------------------------------------------------------------------------------
-// conv_mainloop_halo for a wave that owns TWO output channel tiles of RT row tiles (k_conv_pair, round 5): the activation
-// fragment of a (tile, chunk) feeds the MFMAs of both channel tiles, so a wave reads half the LDS fragments per MFMA; the
-// weights of the two tiles stream through the same buffer descriptor 1 KB apart.  Every tap in a chain of its own (SPLIT
-// above), in the same order of products per output element as conv_mainloop_halo<…, SPLIT = true> → identical bits.
-// Stand-alone layers only: nothing is prefetched for a next layer (loads past the layer's end return 0, buffer range check).
-// ------------------------------------------------------------------------------------------------
-template <int RT, int CH, int NB, int COT>
-__device__ __forceinline__ void conv_mainloop_halo2(const f32x4* __restrict__ lds4, const float* __restrict__ wlayer, uint32_t wlane,
-                                                    const int (&addr4)[RT], f32x4 (&acc)[RT][2]) {
-    constexpr int P4 = 4 * CH + 1, RS = NB + 1;
-    constexpr int H1 = (RT + 1) / 2;
-    constexpr size_t WCHUNK = (size_t)16 * COT * 4 * 16;  // bytes of one 16-k chunk of the layer's weights: [CoutP][4 slots][16 B]
-    constexpr int ROW = 3 * CH;
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wlayer, 0, (int)(9 * CH * WCHUNK), 0x00020000);
-#define TG_H2_W(chunk, c) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + (c) * 1024u, (int)((chunk) * WCHUNK), 0))
-#define TG_H2_OFF(step) (((step) / CH) * P4 + ((step) % CH) * 4)
-    f32x4 a[RT], part[RT][2];
-    const f32x4 zero = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    f32x4 w0[2] = {TG_H2_W(0, 0), TG_H2_W(0, 1)}, w1[2] = {TG_H2_W(1, 0), TG_H2_W(1, 1)};
-    int ad[RT];
-#pragma unroll
-    for (int j = 0; j < RT; j++) ad[j] = addr4[j];
-#define TG_H2_MFMA(j, t, s)                                                                                                             \
-    _Pragma("unroll") for (int c = 0; c < 2; c++)                                                                                       \
-        part[j][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[c][t], a[j][t], ((s) % CH == 0 && (t) == 0) ? zero : part[j][c], 0, 0, 0);
-#define TG_H2_FLUSH(J0, J1)                                                                                                             \
-    _Pragma("unroll") for (int j = J0; j < J1; j++)                                                                                     \
-        _Pragma("unroll") for (int c = 0; c < 2; c++) { acc[j][c] += part[j][c]; asm volatile("" : "+v"(acc[j][c])); }
-#pragma unroll
-    for (int j = 0; j < H1; j++) a[j] = lds4[ad[j] + TG_H2_OFF(0)];
-    int wchunk = 2;  // next chunk of weights to request
-#pragma unroll 1
-    for (int dy = 0; dy < 3; dy++) {
-#pragma unroll
-        for (int s = 0; s < ROW; s++) {
-#pragma unroll
-            for (int j = H1; j < RT; j++) a[j] = lds4[ad[j] + TG_H2_OFF(s)];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-#pragma unroll
-                for (int j = 0; j < H1; j++) { TG_H2_MFMA(j, t, s) }
-            __builtin_amdgcn_sched_barrier(0);
-            if (s % CH == 0 && s > 0) { TG_H2_FLUSH(H1, RT) }  // the previous tap's second half is complete
-            const f32x4 w2[2] = {TG_H2_W(wchunk, 0), TG_H2_W(wchunk, 1)};
-            wchunk++;
-            if (s + 1 < ROW) {
-#pragma unroll
-                for (int j = 0; j < H1; j++) a[j] = lds4[ad[j] + TG_H2_OFF(s + 1)];
-            } else {
-#pragma unroll
-                for (int j = H1; j < RT; j++) ad[j] += RS * P4;
-                if (dy < 2) {
-#pragma unroll
-                    for (int j = 0; j < H1; j++) { ad[j] += RS * P4; a[j] = lds4[ad[j] + TG_H2_OFF(0)]; }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-#pragma unroll
-                for (int j = H1; j < RT; j++) { TG_H2_MFMA(j, t, s) }
-            __builtin_amdgcn_sched_barrier(0);
-            if (s % CH == CH - 1) {  // this tap's first half is complete; behind the row's last tap the second half too
-                if (s == ROW - 1) { TG_H2_FLUSH(0, RT) } else { TG_H2_FLUSH(0, H1) }
-            }
-            w0[0] = w1[0]; w0[1] = w1[1];
-            w1[0] = w2[0]; w1[1] = w2[1];
-        }
-    }
-#undef TG_H2_FLUSH
-#undef TG_H2_MFMA
-#undef TG_H2_OFF
-#undef TG_H2_W
-}
-
 }  // namespace tg

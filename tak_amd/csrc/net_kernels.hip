@@ -851,193 +851,6 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restri
 #endif
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_conv_pair (round 5): the stand-alone F → F layer of the training step with its staging and epilogue UNDER MFMAs.
-// k_conv_halo fills the LDS with one image of 8 positions, so nothing runs on the CU while a workgroup stages its rows or
-// writes its outputs: 8.9 % of a workgroup's cycles issue no MFMA (profiles/r03_c_conv_halo_launch_anatomy.txt), twice per
-// launch (500 workgroups on 256 CUs).  Here a workgroup is TWO independent groups of four waves — one wave of each group on
-// every SIMD — with an image of their own each: group A 5 positions (125 rows = 8 row tiles of 16), group B 3 positions (75
-// rows = 5 tiles): together the 13 tiles of 8 positions, 160.5 KB of LDS at a position stride of 36 cells.  A wave owns all row
-// tiles of its group's image × TWO output channel tiles (conv_mainloop_halo2).  The groups never wait for each other: each
-// stages, computes and stores its own images (IMGS of them, 16 positions per workgroup → 250 workgroups for a chunk of 4000
-// positions: one round) and synchronises its four waves through two counters in LDS (staged / consumed, fc_ring.cuh's
-// primitives) — while one group stages or stores, the other group's wave on the same SIMD has the matrix pipe to itself.
-// scripts/probes/mixed_loop_probe.hip: the two loop shapes share a SIMD's pipe at 99.6 % of the MFMA issue floor, and pauses
-// of 10 k / 6 k cycles per image cost 2.5 % where the same pauses cost k_conv_halo's shape 8.6 %.
-// Same chains of products per output element as k_conv_halo (SPLIT) → identical z / dy bits; BatchNorm's partial sums leave
-// in other groups of rows (one partial row per workgroup, image and group), summed in double as before.
-// ------------------------------------------------------------------------------------------------
-template <int RT, int PW, int CH, int NB, int PSC>
-__device__ __forceinline__ void conv_pair_group(f32x4* __restrict__ img4, uint32_t staged, uint32_t consumed, int group, int gw, int gtid,
-                                                const float* __restrict__ in, const float* __restrict__ Wp, const float* __restrict__ bias,
-                                                const float* __restrict__ res, float* __restrict__ out, const uint32_t* __restrict__ slotmap,
-                                                int B, int pos_first, int pos_step, int imgs, int relu, double* __restrict__ stats_part,
-                                                int stats_row0, const ConvBnBwdIn& bnb) {
-    constexpr int n = NB, nsq = NB * NB, RS = NB + 1, LEAD = NB + 2, F4 = 4 * CH, P4 = 4 * CH + 1, F = 16 * CH;
-    static_assert(RT == (PW * nsq + 15) / 16, "the group's row tiles cover its positions");
-    const int lane = gtid & 63, r16 = lane & 15, q = lane >> 4;
-    const int ch0 = gw * 32;  // this wave's two channel tiles
-    const uint32_t wlane = (uint32_t)(((ch0 + r16) * 4 + q) * 16);
-    int addr4[RT];
-#pragma unroll
-    for (int j = 0; j < RT; j++) {
-        const uint32_t e = slotmap[j * 16 + r16];
-        const bool idle = (e >> 16) == 0xFFFFu;  // a slot without a square reads around a zero cell and stores nothing
-        addr4[j] = ((idle ? LEAD + n * RS : (int)(e & 0xFFFFu)) - LEAD) * P4 + q;
-    }
-    for (int img = 0; img < imgs; img++) {
-        const int pos0 = pos_first + img * pos_step;
-        const int npos = min(PW, B - pos0);
-        double s1[2][4], s2[2][4];
-#pragma unroll
-        for (int c = 0; c < 2; c++)
-#pragma unroll
-            for (int t = 0; t < 4; t++) { s1[c][t] = 0.0; s2[c][t] = 0.0; }
-        TG_STAMP(img, 0);  // (diagnostic build only: scripts/probes/conv_pair_stamps.hip)
-        // Priorities.  The phases that issue no MFMA — staging, the group's synchronisation, the epilogue — are a few hundred instructions
-        // that must not queue behind the other group's MFMA loop on the same SIMD (left to the arbiter, which prefers the older wave,
-        // group B's first epilogue took 105 k cycles instead of 6 k and group A's second staging 20 k instead of 10 k: stamps in
-        // profiles/r05_g_conv_pair_stamps.txt), so they run at priority 3.  Main loops: TG_PAIR_PRIO_A / _B.
-        __builtin_amdgcn_s_setprio(3);
-        if (npos > 0) {
-            const int rows = npos * nsq;
-            // the group's previous image has been read to the end by its four waves
-            if (img > 0) fc_ring_wait(consumed, 4u * (uint32_t)img);
-            TG_STAMP(img, 1);
-            {   // this group's rows from global into halo cells, 8 loads in flight per lane
-                const f32x4* src = (const f32x4*)(in + (size_t)pos0 * nsq * F);
-                const int total = rows * F4;
-                constexpr int UNR = 8;
-                for (int base = 0; base < total; base += 256 * UNR) {
-                    f32x4 tmp[UNR];
-#pragma unroll
-                    for (int u = 0; u < UNR; u++) {
-                        const int idx = base + u * 256 + gtid;
-                        tmp[u] = src[idx < total ? idx : total - 1];
-                    }
-#pragma unroll
-                    for (int u = 0; u < UNR; u++) {
-                        const int idx = base + u * 256 + gtid;
-                        if (idx < total) {
-                            const int r = idx / F4, v = idx - r * F4;
-                            const int p = r / nsq, sq = r - p * nsq, y = sq / n, x = sq - y * n;
-                            img4[(LEAD + p * PSC + y * RS + x) * P4 + v] = tmp[u];
-                        }
-                    }
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's cells are written …
-            fc_ring_signal(staged);
-            fc_ring_wait(staged, 4u * (uint32_t)(img + 1));     // … and so are the other three waves'
-            TG_STAMP(img, 2);
-            f32x4 acc[RT][2];
-#pragma unroll
-            for (int j = 0; j < RT; j++) { acc[j][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; acc[j][1] = acc[j][0]; }
-#ifndef TG_PAIR_PRIO_A
-#define TG_PAIR_PRIO_A 0
-#define TG_PAIR_PRIO_B 1
-#endif
-            if (group == 0) __builtin_amdgcn_s_setprio(TG_PAIR_PRIO_A);
-            else __builtin_amdgcn_s_setprio(TG_PAIR_PRIO_B);
-            conv_mainloop_halo2<RT, CH, NB, CH>(img4, Wp, wlane, addr4, acc);
-            __builtin_amdgcn_s_setprio(3);
-            fc_ring_signal(consumed);  // (the epilogue below reads registers and global memory only)
-            TG_STAMP(img, 3);
-            // epilogue: + bias, + res, ReLU, store; BatchNorm's sums of this wave's rows (k_conv_halo's epilogue, per channel tile).
-            // (The tiles' rows are looked up again — all at once: one round trip, not one per tile — rather than kept in registers
-            // across the main loop.)
-            int rowid[RT];
-#pragma unroll
-            for (int j = 0; j < RT; j++) rowid[j] = (int)(slotmap[j * 16 + r16] >> 16);
-#pragma unroll
-            for (int j = 0; j < RT; j++) asm volatile("" : "+v"(rowid[j]));
-#pragma unroll
-            for (int c = 0; c < 2; c++) {
-                const int ch = ch0 + 16 * c + 4 * q;
-                const f32x4 bv = *(const f32x4*)&bias[ch];
-                f32x4 bn_mu = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, bn_is = bn_mu;
-                if (bnb.y) { bn_mu = *(const f32x4*)&bnb.mean[ch]; bn_is = *(const f32x4*)&bnb.invstd[ch]; }
-#pragma unroll
-                for (int j = 0; j < RT; j++) {
-                    if (rowid[j] < rows) {
-                        const size_t o = ((size_t)pos0 * nsq + rowid[j]) * F + ch;
-                        f32x4 v = acc[j][c] + bv;
-                        if (res) v += *(const f32x4*)&res[o];
-                        if (relu) { v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f); }
-                        *(f32x4*)&out[o] = v;
-                        if (stats_part && !bnb.y) {
-#pragma unroll
-                            for (int t = 0; t < 4; t++) { const double d = (double)v[t]; s1[c][t] += d; s2[c][t] = fma(d, d, s2[c][t]); }
-                        } else if (stats_part) {
-                            const f32x4 yy = *(const f32x4*)&bnb.y[o], zz = *(const f32x4*)&bnb.z[o];
-#pragma unroll
-                            for (int t = 0; t < 4; t++) {
-                                const float g = yy[t] > 0.0f ? v[t] : 0.0f;
-                                s1[c][t] += (double)g;
-                                s2[c][t] += (double)(g * ((zz[t] - bn_mu[t]) * bn_is[t]));
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        TG_STAMP(img, 4);
-        if (stats_part) {  // one partial row per (workgroup, image, group) — zeros where the batch ended before this image
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1)
-#pragma unroll
-                for (int c = 0; c < 2; c++)
-#pragma unroll
-                    for (int t = 0; t < 4; t++) { s1[c][t] += __shfl_xor(s1[c][t], d); s2[c][t] += __shfl_xor(s2[c][t], d); }
-            if (r16 == 0) {
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    double* dst = stats_part + ((size_t)(stats_row0 + 2 * img + group) * 2) * F + ch0 + 16 * c + 4 * q;
-#pragma unroll
-                    for (int t = 0; t < 4; t++) { dst[t] = s1[c][t]; dst[F + t] = s2[c][t]; }
-                }
-            }
-        }
-    }
-}
-
-template <int CH, int NB, int PA, int PB, int PSC, int IMGS>
-__global__ __launch_bounds__(512) void k_conv_pair(const float* __restrict__ in, const float* __restrict__ Wp, const float* __restrict__ bias,
-                                                   const float* __restrict__ res, float* __restrict__ out, const uint32_t* __restrict__ mapA,
-                                                   const uint32_t* __restrict__ mapB, int B, int relu, double* __restrict__ stats_part,
-                                                   const ConvBnBwdIn bnb) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int nsq = NB * NB, RS = NB + 1, LEAD = NB + 2, P4 = 4 * CH + 1;
-    constexpr int CELLS_A = LEAD + PA * PSC + 1, CELLS_B = LEAD + PB * PSC + 1;
-    constexpr int RTA = (PA * nsq + 15) / 16, RTB = (PB * nsq + 15) / 16;
-    f32x4* lds4 = (f32x4*)lds;
-    uint32_t* flags = (uint32_t*)(lds4 + (size_t)(CELLS_A + CELLS_B) * P4);  // staged[2], consumed[2]
-    const uint32_t flag0 = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)flags;
-    const int tid = threadIdx.x;
-    // the zero cells of both images, once: behind every board row, the zero row behind every position, lead and tail (staging
-    // writes squares only)
-    for (int idx = tid; idx < (CELLS_A + CELLS_B) * P4; idx += 512) {
-        int cell = idx / P4;
-        const int pw = cell < CELLS_A ? PA : PB;
-        if (cell >= CELLS_A) cell -= CELLS_A;
-        const int c = cell - LEAD;
-        const int o = c < 0 || c >= pw * PSC ? NB * RS : c % PSC;
-        if (o >= NB * RS || o % RS == NB) lds4[idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    }
-    if (tid < 4) flags[tid] = 0u;
-    __syncthreads();  // the only workgroup-wide barrier
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int group = wave >> 2, gw = wave & 3, gtid = tid & 255;
-    const int pos_wg = (int)blockIdx.x * IMGS * (PA + PB);
-    const int stats_row0 = (int)blockIdx.x * IMGS * 2;
-    if (group == 0)
-        conv_pair_group<RTA, PA, CH, NB, PSC>(lds4, flag0, flag0 + 8, 0, gw, gtid, in, Wp, bias, res, out, mapA, B, pos_wg, PA + PB, IMGS, relu,
-                                              stats_part, stats_row0, bnb);
-    else
-        conv_pair_group<RTB, PB, CH, NB, PSC>(lds4 + (size_t)CELLS_A * P4, flag0 + 4, flag0 + 12, 1, gw, gtid, in, Wp, bias, res, out, mapB, B,
-                                              pos_wg + PA, PA + PB, IMGS, relu, stats_part, stats_row0, bnb);
-}
-
 // Plain GEMM out[M][N] = A[M][K]·W[K][N] + bias for the 5×5 policy FC (net5.rs:56-61,108): the same
 // fragments, A staged through LDS in K-chunks of 32.
 template <int RT, int CT>
@@ -1724,38 +1537,11 @@ static hipError_t launch_conv_halo_t(hipStream_t st, const float* in, const floa
     return hipGetLastError();
 }
 
-// k_conv_pair for the 5×5, 128 → 128 layers of the training step at full chunks
-static hipError_t launch_conv_pair_5x5_128(hipStream_t st, const float* in, const float* Wp, const float* bias, const float* res, float* out, int B,
-                                           bool relu, double* stats_part, int* stats_blocks, const ConvBnBwdIn* bnb) {
-    constexpr int CH = 8, NB = 5, PA = 5, PB = 3, PS = 36, IMGS = 2;
-    const uint32_t* mapA = conv_halo_slotmap(NB, 16 * CH, PA, PS);
-    const uint32_t* mapB = conv_halo_slotmap(NB, 16 * CH, PB, PS);
-    if (!mapA || !mapB) return hipErrorOutOfMemory;
-    constexpr size_t cells = (NB + 2 + PA * PS + 1) + (NB + 2 + PB * PS + 1);
-    constexpr size_t lds = cells * (16 * CH + 4) * sizeof(float) + 16;
-    static_assert(lds <= 160 * 1024, "both images and the flags fit the LDS");
-    static LdsAttr lds_attr;
-    if (hipError_t e = lds_attr.ensure((const void*)k_conv_pair<CH, NB, PA, PB, PS, IMGS>, lds); e != hipSuccess) return e;
-    const int grid = (B + IMGS * (PA + PB) - 1) / (IMGS * (PA + PB));
-    ConvBnBwdIn bn{nullptr, nullptr, nullptr, nullptr};
-    if (bnb && stats_part) bn = *bnb;
-    else if (bnb) stats_part = nullptr;
-    hipLaunchKernelGGL((k_conv_pair<CH, NB, PA, PB, PS, IMGS>), dim3(grid), dim3(512), lds, st, in, Wp, bias, res, out, mapA, mapB, B, relu ? 1 : 0,
-                       stats_part, bn);
-    if (stats_blocks) *stats_blocks = stats_part ? grid * IMGS * 2 : 0;
-    return hipGetLastError();
-}
-
 hipError_t launch_conv3x3(hipStream_t st, const float* in, const float* Wp, const float* bias, const float* res, float* out,
                           int M, int n, int Cpad, int CoutP, int out_stride, int cout_valid, bool relu, double* stats_part,
                           int* stats_blocks, const ConvBnBwdIn* bnb) {
     const int B = M / (n * n);
     if (stats_blocks) *stats_blocks = 0;
-    {   // round 5: two wave groups with an image each (staging and epilogue under the other group's MFMAs), same z / dy bits as k_conv_halo
-        static const bool off = getenv("TG_NO_HALO_CONV") != nullptr || getenv("TG_NO_PAIR_CONV") != nullptr;
-        if (!off && n == 5 && Cpad == 128 && CoutP == 128 && out_stride == 128 && cout_valid == 128 && B >= 1024)
-            return launch_conv_pair_5x5_128(st, in, Wp, bias, res, out, B, relu, stats_part, stats_blocks, bnb);
-    }
     {   // F → F (and F → 2F) layers of the BASELINE topologies at full batches: the halo image (k_conv_halo), same bits as k_conv_pos
         static const bool off = getenv("TG_NO_HALO_CONV") != nullptr;
         int pw, ps;

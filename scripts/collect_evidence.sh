@@ -19,6 +19,9 @@ rocprofv3 --kernel-trace --output-format csv -d $O/kt_train2 -o kt -- python3 $R
 python3 $R/scripts/probes/train_overlap.py $(find $O/kt_train2 -name '*kernel_trace.csv' | head -1) > $O/train_overlap_default.txt 2>&1
 step "training step timings (no profiler): tg_train, tg_train_chunk, one stream"
 { python3 $R/scripts/train_step_ab.py 40 --driver; python3 $R/scripts/train_step_ab.py 40; TG_TRAIN_ONE_STREAM=1 python3 $R/scripts/train_step_ab.py 40 --driver; } > $O/train_step.jsonl 2>> $O/kt_train.err
+step "training step's forward error budget per layer, and the full gradient audit (fp64 with the engine's / its own / PyTorch-f32's ReLU decisions)"
+python3 $R/scripts/train_error_budget.py $O/train_error_budget.json > $O/train_error_budget.txt 2>&1
+( cd $R && TG_C5_FULL_AUDIT=1 python3 -m pytest tests/test_gpu_c5_realsize.py -m gpu -x -q -s > $O/c5_realsize_full_audit.log 2>&1; cp gpurun_out/c5_realsize_gradient_parity.json $O/c5_realsize_gradient_parity_full_audit.json; cp gpurun_out/c5_realsize_layerwise_backward.json $O/ )
 step "HBM traffic counters, forward C2"
 rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_WRREQ --output-format csv -d $O/pmc_traffic -o p -- python3 $R/scripts/ab_forward.py c2 > $O/ab_forward_c2_under_pmc.json 2> $O/pmc_traffic.err
 step "HBM traffic counters, policy FC inside the search loop (gather epilogue)"

@@ -435,7 +435,8 @@ int tg_train_chunk(TgEngine* e, int n, const void* states, const int32_t* n_move
  * data-parallel caller of tg_train_chunk must agree on errors across ranks itself before the chunk that completes an
  * optimiser step.
  * Execution: the weight gradients of a chunk run on a stream of their own beside the data-gradient chain
- * (TG_TRAIN_ONE_STREAM=1: on the chain's stream); the result is the same, bit for bit. */
+ * (TG_TRAIN_ONE_STREAM=1: on the chain's stream); while chunk k runs, tg_train gathers and uploads chunk k + 1 on a copy stream and
+ * enqueues it behind chunk k.  The chunks still execute one after the other: the result is that of tg_train_chunk per chunk, bit for bit. */
 int tg_train(TgEngine* e, int n, const void* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
              const float* results, uint64_t seed, float* mean_loss_p, float* mean_loss_z, int32_t* steps);
 /* opt.step(); opt.zero_grad() now (network.rs:92-96), whatever the chunk counter says */

@@ -60,6 +60,11 @@ struct Chunk {
         std::vector<uint32_t> h_visits;
         std::vector<float> h_z8;
         hipEvent_t uploaded = nullptr;   // recorded on the copy stream behind the set's five copies
+        // the chunk that runs on this set: issued, not yet collected.  `done` stands behind its loss sums (and its optimiser step, if one
+        // fell due) on the chain's stream: chunk_collect waits for IT, not for the stream — tg_train has the next chunk enqueued by then
+        hipEvent_t done = nullptr;
+        bool in_flight = false;
+        int B_flight = 0, did_step = 0;
     } ex[2];
     hipStream_t up = nullptr;            // the copy stream
     DevBuf states_aug, pi, planes;
@@ -79,15 +84,12 @@ struct Chunk {
     // before the ReLU mask), dz and the data gradient it hands down
     int cap_layer = -1;
     DevBuf cap_dy, cap_dz, cap_dx;
-    // the chunk in flight: issued, not yet collected
-    bool in_flight = false;
-    int B_flight = 0, did_step = 0;
     ~Chunk() {
         for (hipEvent_t ev : ev_dz) if (ev) (void)hipEventDestroy(ev);
         if (ev_head) (void)hipEventDestroy(ev_head);
         for (hipEvent_t ev : ev_wgl) if (ev) (void)hipEventDestroy(ev);
         if (wg) (void)hipStreamDestroy(wg);
-        for (Examples& x : ex) if (x.uploaded) (void)hipEventDestroy(x.uploaded);
+        for (Examples& x : ex) { if (x.uploaded) (void)hipEventDestroy(x.uploaded); if (x.done) (void)hipEventDestroy(x.done); }
         if (up) (void)hipStreamDestroy(up);
     }
 };
@@ -457,7 +459,7 @@ int chunk_issue(TgEngine* e, Chunk& w, int n, int slot) {
     Trainer* t = e->trainer;
     hipStream_t st = w.st;
     const int B = n * 8;
-    const Chunk::Examples& x = w.ex[slot];
+    Chunk::Examples& x = w.ex[slot];
     TG_HIP(hipStreamWaitEvent(st, x.uploaded, 0));
     TG_HIP(hipMemsetAsync(w.pi.p, 0, (size_t)B * e->policy_size * 4, st));
     launch_augment(st, x.states.as<uint8_t>(), x.nmoves.as<int32_t>(), x.moves.as<uint16_t>(), x.visits.as<uint32_t>(), n,
@@ -469,29 +471,33 @@ int chunk_issue(TgEngine* e, Chunk& w, int n, int slot) {
     if (rc) return rc;
     rc = backward_train(e, w, B);
     if (rc) return rc;
-    TG_HIP(launch_sum_rows(st, w.loss_p_rows.as<float>(), B, w.loss_sums.as<double>()));
-    TG_HIP(launch_sum_rows(st, w.loss_z_rows.as<float>(), B, w.loss_sums.as<double>() + 1));
-    w.did_step = 0;
-    w.B_flight = B;
-    w.in_flight = true;
+    TG_HIP(launch_sum_rows(st, w.loss_p_rows.as<float>(), B, w.loss_sums.as<double>() + 2 * slot));
+    TG_HIP(launch_sum_rows(st, w.loss_z_rows.as<float>(), B, w.loss_sums.as<double>() + 2 * slot + 1));
+    x.did_step = 0;
+    x.B_flight = B;
+    x.in_flight = true;
     t->chunk_num++;
     if (t->chunk_num % t->cfg.chunks_in_step == 0) {  // network.rs:92
         rc = optimizer_step(e, st);
         if (rc) return rc;
-        w.did_step = 1;
+        x.did_step = 1;
     }
+    TG_HIP(hipEventRecord(x.done, st));
     return TG_OK;
 }
-int chunk_collect(TgEngine* e, Chunk& w, float* loss_p, float* loss_z, int32_t* stepped) {
+int chunk_collect(TgEngine* e, Chunk& w, int slot, float* loss_p, float* loss_z, int32_t* stepped) {
     (void)e;
-    if (!w.in_flight) return fail(TG_ERR_STATE, "internal: no chunk in flight");
-    w.in_flight = false;
+    Chunk::Examples& x = w.ex[slot];
+    if (!x.in_flight) return fail(TG_ERR_STATE, "internal: no chunk in flight on this example set");
+    x.in_flight = false;
     double sums[2];
-    TG_HIP(hipMemcpyAsync(sums, w.loss_sums.p, 16, hipMemcpyDeviceToHost, w.st));
-    TG_HIP(hipStreamSynchronize(w.st));  // the chain's stream stands behind the weight-gradient stream (backward_train)
-    if (loss_p) *loss_p = (float)(sums[0] / w.B_flight);
-    if (loss_z) *loss_z = (float)(sums[1] / w.B_flight);
-    if (stepped) *stepped = w.did_step;
+    // behind the chunk's own `done` event, on the copy stream: the chain's stream may already hold the next chunk
+    TG_HIP(hipStreamWaitEvent(w.up, x.done, 0));
+    TG_HIP(hipMemcpyAsync(sums, w.loss_sums.as<double>() + 2 * slot, 16, hipMemcpyDeviceToHost, w.up));
+    TG_HIP(hipStreamSynchronize(w.up));
+    if (loss_p) *loss_p = (float)(sums[0] / x.B_flight);
+    if (loss_z) *loss_z = (float)(sums[1] / x.B_flight);
+    if (stepped) *stepped = x.did_step;
     return TG_OK;
 }
 // after an error in the middle of a chunk: nothing of this trainer is left running
@@ -500,7 +506,7 @@ void chunk_drain(Trainer* t) {
     if (w.up) (void)hipStreamSynchronize(w.up);
     if (w.wg) (void)hipStreamSynchronize(w.wg);
     if (w.st) (void)hipStreamSynchronize(w.st);
-    w.in_flight = false;
+    for (Chunk::Examples& x : w.ex) x.in_flight = false;
 }
 
 // The complete host-side check of ONE example (index s of the caller's arrays), used by tg_train_chunk's upload and by
@@ -686,6 +692,7 @@ int tg_train_create(TgEngine* e, const TgTrainConfig* cfg) {
             TG_HIP(hipMemset(x.visits.p, 0, (size_t)cfg->chunk_size * TG_MAX_MOVES * 4));
             TG_HIP(x.zt.ensure(B * 4));
             TG_HIP(hipEventCreateWithFlags(&x.uploaded, hipEventDisableTiming));
+            TG_HIP(hipEventCreateWithFlags(&x.done, hipEventDisableTiming));
         }
         TG_HIP(w.states_aug.ensure(B * e->g.bytes));
         TG_HIP(w.pi.ensure(B * P * 4));
@@ -698,7 +705,7 @@ int tg_train_create(TgEngine* e, const TgTrainConfig* cfg) {
         TG_HIP(w.dpre.ensure(B * 4));
         TG_HIP(w.loss_p_rows.ensure(B * 4));
         TG_HIP(w.loss_z_rows.ensure(B * 4));
-        TG_HIP(w.loss_sums.ensure(16));
+        TG_HIP(w.loss_sums.ensure(32));
         TG_HIP(w.d_a.ensure(M * F * 4));
         TG_HIP(w.d_b.ensure(M * F * 4));
         TG_HIP(w.dz.ensure(M * F * 4));
@@ -731,7 +738,9 @@ int tg_train_chunk(TgEngine* e, int n, const void* states, const int32_t* n_move
         chunk_drain(e->trainer);
         return rc;
     }
-    return chunk_collect(e, w, loss_p, loss_z, stepped);
+    rc = chunk_collect(e, w, 0, loss_p, loss_z, stepped);
+    if (rc == TG_OK) TG_HIP(hipStreamSynchronize(w.st));  // (tg_train_chunk returns with the engine stream idle, as it always did)
+    return rc;
 }
 
 int tg_train(TgEngine* e, int n, const void* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
@@ -780,27 +789,29 @@ int tg_train(TgEngine* e, int n, const void* states, const int32_t* n_moves, con
     double sp = 0.0, sz = 0.0;
     int chunks = 0, nsteps = 0;
     Chunk& w = t->chunk;
-    // chunks_exact: the remainder is dropped.  Chunk k + 1 is gathered and uploaded (copy stream, the other example set) while the GPU
-    // works on chunk k; the chunks themselves run one after the other, as before.
+    // chunks_exact: the remainder is dropped.  While the GPU works on chunk k the host gathers and uploads chunk k + 1 (copy stream, the other
+    // example set) and ENQUEUES it behind chunk k, then waits for chunk k's losses only (its `done` event): the chunks run one after
+    // the other on the same streams as before, with no host round trip between them.
     const int total = n / cs;
-    if (total > 0) rc = upload_chunk(e, w, 0, cs, (const uint8_t*)states, n_moves, moves, visits, results, order.data(), true);
+    if (total > 0) {
+        rc = upload_chunk(e, w, 0, cs, (const uint8_t*)states, n_moves, moves, visits, results, order.data(), true);
+        if (rc == TG_OK) rc = chunk_issue(e, w, cs, 0);
+    }
     for (int k = 0; k < total && rc == TG_OK; k++) {
-        rc = chunk_issue(e, w, cs, k & 1);
-        if (rc == TG_OK && k + 1 < total)
+        if (k + 1 < total) {
             rc = upload_chunk(e, w, (k + 1) & 1, cs, (const uint8_t*)states, n_moves, moves, visits, results, order.data() + (size_t)(k + 1) * cs, true);
+            if (rc == TG_OK) rc = chunk_issue(e, w, cs, (k + 1) & 1);
+        }
         float lp = 0.0f, lz = 0.0f;
         int32_t did = 0;
-        if (rc == TG_OK) rc = chunk_collect(e, w, &lp, &lz, &did);
-        if (rc) {
-            chunk_drain(t);
-            return rc;
-        }
-        sp += lp; sz += lz; chunks++; nsteps += did;
+        if (rc == TG_OK) rc = chunk_collect(e, w, k & 1, &lp, &lz, &did);
+        if (rc == TG_OK) { sp += lp; sz += lz; chunks++; nsteps += did; }
     }
     if (rc) {
         chunk_drain(t);
         return rc;
     }
+    TG_HIP(hipStreamSynchronize(w.st));
     if (mean_loss_p) *mean_loss_p = chunks ? (float)(sp / chunks) : 0.0f;
     if (mean_loss_z) *mean_loss_z = chunks ? (float)(sz / chunks) : 0.0f;
     if (steps) *steps = nsteps;

@@ -5,9 +5,11 @@
 // linear [out,in], BN vectors) in the creation order of net5.rs:29-62, so Adam is one elementwise kernel and
 // the data-parallel gradient exchange is ONE RCCL all-reduce of the flat gradient buffer per optimiser step.
 // Before a forward the parameters are re-packed (cheap, ≤ 8 M floats) into the MFMA fragment layouts of the
-// forward and data-gradient convolutions.  Schedule per chunk (everything on the engine stream):
+// forward and data-gradient convolutions.  Schedule per chunk:
 //   augment ×8 → encode NHWC → [conv → BN(batch stats) → ReLU(+skip)]×(1+2R) → heads → losses
-//   → head gradients → per layer in reverse: BN backward → weight gradient (TN implicit GEMM) → data gradient.
+//   → head gradients → per layer in reverse: BN backward → weight gradient (TN implicit GEMM) → data gradient
+// on three streams: the chain on the engine stream, everything that only produces gradients (weight gradients, bias finalisations)
+// on a second one beside it, the next chunk's examples on a copy stream (tg_train).
 #include <dlfcn.h>
 
 #include <cmath>

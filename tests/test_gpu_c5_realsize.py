@@ -49,61 +49,6 @@ def _examples(orc, n, count, seed):
     return sts, cnt.astype(np.int32), mv, visits, results
 
 
-def _fp64_gradients(net, planes, pi, z, mask_sets):
-    """fp64 forward of train_inner's loss, then one backward pass per entry of mask_sets: None = the fp64 network's own ReLU
-    decisions, a float t = the decisions taken at y > t, a list of 21 bool arrays [B, F, n, n] = those decisions (layer order
-    conv0, res0.conv1, res0.conv2, …).  → ([{name: gradient}], [pre-activation of every ReLU as float64 numpy arrays])"""
-    import copy
-
-    import torch
-
-    class Relu(torch.autograd.Function):
-        mode = None
-        layer = 0
-
-        @staticmethod
-        def forward(ctx, x, layer):
-            ctx.save_for_backward(x)
-            ctx.layer = layer
-            return x.clamp_min(0.0)
-
-        @staticmethod
-        def backward(ctx, g):
-            (x,) = ctx.saved_tensors
-            m = Relu.mode
-            if m is None:
-                return g * (x > 0.0), None
-            if isinstance(m, float):
-                return g * (x > m), None
-            return g * m[ctx.layer], None
-
-    n64 = copy.deepcopy(net).double().train()
-    x = torch.from_numpy(planes.astype(np.float64))
-    pres = []
-
-    def relu(t):
-        pres.append(t.detach())
-        return Relu.apply(t, len(pres) - 1)
-
-    s = relu(n64.bn0(n64.conv0(x)))
-    for blk in n64.res:  # res_block.rs:13-24
-        y = relu(blk.bn1(blk.conv1(s)))
-        s = relu(blk.bn2(blk.conv2(y)) + s)
-    flat = s.reshape(s.shape[0], -1)
-    logp = torch.log_softmax(n64.policy(flat), dim=1)
-    v = torch.tanh(n64.value(flat))
-    b = x.shape[0]
-    loss = -(torch.from_numpy(pi.astype(np.float64)) * logp).sum() / b + (torch.from_numpy(np.asarray(z, np.float64))[:, None] - v).square().sum() / b
-    params = list(n64.named_parameters())
-    out = []
-    for i, m in enumerate(mask_sets):
-        Relu.mode = m
-        gs = torch.autograd.grad(loss, [p for _, p in params], retain_graph=i + 1 < len(mask_sets))
-        print(f"  fp64 backward pass {i + 1} of {len(mask_sets)} done", flush=True)
-        out.append({torch_ref.abi_name(k): g.numpy().copy() for (k, _), g in zip(params, gs)})
-    return out, pres
-
-
 def _f32_masks(net, planes):
     """the ReLU decisions PyTorch f32 takes on this chunk (a no-grad forward in training mode: the arithmetic of its autograd run)"""
     import copy
@@ -235,7 +180,7 @@ def test_c5_chunk_gradients_and_adam_at_the_reference_chunk_size(orc, c5):
     g_eng = c5["g_eng"]
     L = 1 + 2 * blocks
     # the engine's ReLU decisions, layer by layer ([rows][F] NHWC → [B, F, n, n])
-    m_eng = [torch.from_numpy(e.train_debug_read("y", l, (c5["rows"], filters)) > 0).reshape(B, n, n, filters).permute(0, 3, 1, 2) for l in range(L)]
+    m_eng = torch_ref.engine_relu_decisions(e, L, B, n, filters)
 
     lp_ref, lz_ref = torch_ref.train_chunk(net, planes, pi, z)  # PyTorch f32 autograd
     g32 = torch_ref.named_grads(net)
@@ -246,7 +191,7 @@ def test_c5_chunk_gradients_and_adam_at_the_reference_chunk_size(orc, c5):
     # under fixed decisions; each pass costs a minute of CPU time.
     full = os.environ.get("TG_C5_FULL_AUDIT", "0") != "0"
     print(f"PyTorch f32 done; fp64 forward and {3 if full else 1} backward pass(es) …", flush=True)
-    gs, pres = _fp64_gradients(net, planes, pi, z, [m_eng, None, m_t32] if full else [m_eng])
+    gs, pres = torch_ref.fp64_gradients(net, planes, pi, z, [m_eng, None, m_t32] if full else [m_eng], verbose=True)
     g64e = gs[0]
     g64, g64t = (gs[1], gs[2]) if full else (None, None)
 

@@ -139,3 +139,70 @@ def make_adam(net, lr=1e-4, wd=1e-4):
 
 def named_grads(net):
     return {abi_name(k): v.grad.detach().numpy().copy() for k, v in net.named_parameters()}
+
+
+def fp64_gradients(net, planes, pi, z, mask_sets, verbose=False):
+    """fp64 forward of train_inner's loss (network.rs:58-91) on a copy of `net`, then one backward pass per entry of mask_sets:
+    None = the fp64 network's own ReLU decisions, a float t = the decisions taken at y > t, a list of 1 + 2·blocks bool tensors
+    [B, F, n, n] = THOSE decisions (layer order conv0, res0.conv1, res0.conv2, …).  The backward pass of a ReLU network is the exact
+    derivative of a piecewise-linear function once the decisions are fixed, and the forward pass takes them: with an
+    implementation's own decisions on the reference side its gradients have to agree to rounding, with no allowance for "flips".
+    → ([{ABI name: gradient}], [pre-activation of every ReLU, float64 tensors])"""
+    import copy
+
+    class Relu(torch.autograd.Function):
+        mode = None
+
+        @staticmethod
+        def forward(ctx, x, layer):
+            ctx.save_for_backward(x)
+            ctx.layer = layer
+            return x.clamp_min(0.0)
+
+        @staticmethod
+        def backward(ctx, g):
+            (x,) = ctx.saved_tensors
+            m = Relu.mode
+            if m is None:
+                return g * (x > 0.0), None
+            if isinstance(m, float):
+                return g * (x > m), None
+            return g * m[ctx.layer], None
+
+    n64 = copy.deepcopy(net).double().train()
+    for p in n64.parameters():
+        p.grad = None
+    x = torch.from_numpy(np.ascontiguousarray(planes, np.float64))
+    pres = []
+
+    def relu(t):
+        pres.append(t.detach())
+        return Relu.apply(t, len(pres) - 1)
+
+    s = relu(n64.bn0(n64.conv0(x)))
+    for blk in n64.res:  # res_block.rs:13-24
+        y = relu(blk.bn1(blk.conv1(s)))
+        s = relu(blk.bn2(blk.conv2(y)) + s)
+    flat = s.reshape(s.shape[0], -1)
+    logits = n64.policy(flat) if n64.head == "fc5" else n64.policy(s).reshape(s.shape[0], -1)
+    logp = torch.log_softmax(logits, dim=1)
+    v = torch.tanh(n64.value(flat))
+    b = x.shape[0]
+    loss = -(torch.from_numpy(np.ascontiguousarray(pi, np.float64)) * logp).sum() / b + (torch.from_numpy(np.asarray(z, np.float64))[:, None] - v).square().sum() / b
+    params = list(n64.named_parameters())
+    out = []
+    for i, m in enumerate(mask_sets):
+        Relu.mode = m
+        gs = torch.autograd.grad(loss, [p for _, p in params], retain_graph=i + 1 < len(mask_sets))
+        out.append({abi_name(k): g.numpy().copy() for (k, _), g in zip(params, gs)})
+        if verbose:
+            print(f"  fp64 backward pass {i + 1} of {len(mask_sets)} done", flush=True)
+    return out, pres
+
+
+def engine_relu_decisions(engine, layers, positions, n, filters):
+    """the ReLU decisions an engine took in its last training chunk / forward — y > 0 of every conv layer, read back through
+    tg_train_debug_read ([rows][F] NHWC) — as bool tensors [B, F, n, n] for fp64_gradients"""
+    rows = positions * n * n
+    return [torch.from_numpy(engine.train_debug_read("y", l, (rows, filters)) > 0).reshape(positions, n, n, filters).permute(0, 3, 1, 2)
+            for l in range(layers)]

@@ -228,10 +228,14 @@ def run_c5_phase(args, rank, world, out, phase, want_result=False, dist=None):
     printed = threading.Lock()
 
     def print_marked(error):
-        if rank == 0 and out is not None and printed.acquire(blocking=False):
+        if rank != 0 or not printed.acquire(blocking=False):
+            return
+        if out is not None:
             out["train_c5_failed"] = True
             out.setdefault("extra", {})["train_c5"] = {"error": error}
             print(json.dumps(out), flush=True)
+        elif args.train:  # C5 alone: there is no headline yet — say so in the one line
+            print(json.dumps(failed_train_line(world, error)), flush=True)
 
     def give_up():
         print(f"bench.py: rank {rank}: the C5 phase did not finish within {args.train_timeout:.0f} s", file=sys.stderr, flush=True)
@@ -275,6 +279,13 @@ def run_c5_phase(args, rank, world, out, phase, want_result=False, dist=None):
         if failed:
             out["train_c5_failed"] = True
     return (out, failed, c5) if want_result else (out, failed)
+
+
+def failed_train_line(world, error):
+    """the JSON line of `bench.py --train` when the phase failed: no value, marked"""
+    return {"metric": "training positions/s (forward + backward + Adam; 8-fold augmented examples)", "value": None, "per_gpu_value": None,
+            "unit": "positions/s", "n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "train_c5_failed": True, "train_c5": {"error": error}}
 
 
 def finish(rank, world, out, c5_failed, dist):
@@ -690,7 +701,9 @@ def main():
     c5_failed = False
     if args.train or not (args.no_train or args.no_extras or args.precision != "f32"):
         out, c5_failed, c5 = run_c5_phase(args, rank, world, out, lambda: train_c5(args, rank, world, local_rank, dist, backend, barrier), want_result=True, dist=dist)
-        if rank == 0 and args.train:
+        if rank == 0 and args.train and (c5_failed or "error" in c5):
+            out = failed_train_line(world, c5.get("error"))
+        elif rank == 0 and args.train:
             out = {
                 "metric": c5["metric"], "value": c5["value"], "per_gpu_value": c5["value"] / world, "unit": c5["unit"], "n_gpus": world,
                 "ranks_reporting": c5["ranks_reporting"], "steps": c5["optimizer_steps"], "warmup": 0,

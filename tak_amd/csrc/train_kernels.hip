@@ -615,7 +615,11 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_halo(const float* __restrict__
     constexpr int n = NB, nsq = NB * NB, RS = NB + 1, LEAD = NB + 2, PS = (NB + 1) * RS;
     constexpr int ROWS = PWC * nsq, ROWS_PAD = (ROWS + 3) & ~3, NSTEPS = ROWS_PAD / 4;
     constexpr int CELLS = LEAD + PWC * PS + 1;
-    constexpr int XLS4 = 17, GLS4 = 17;
+    // X cells at a pitch of exactly 16 slots: a wave's ds_read_b128 takes slot j of four rows' cells, and the hardware serves lanes
+    // {0-3, 12-15} of one row together with {4-11} of the next — at pitch 16 those are 16 different bank quads whatever the two cells
+    // are; at 17 (rounds 3 – 4) neighbouring cells met on one quad: SQ_LDS_BANK_CONFLICT was 49 % of the kernel's LDS cycles
+    // (profiles/r05_r_pmc_sq_train_kernels.txt).  The LDS is only 23 % busy, so it buys 0.8 % (240.3 → 238.3 µs, r05_s).
+    constexpr int XLS4 = 16, GLS4 = 17;
     constexpr int PF = (ROWS * 16 + 255) / 256;  // float4 slots per thread of the register prefetch
     static_assert(ROWS <= 64, "the register prefetch carries at most 64 rows");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -944,10 +948,10 @@ hipError_t launch_wgrad_conv(hipStream_t st, const float* X, int xs, int I, cons
     const int gvalid = gs < ncob * 64 ? gs : ncob * 64;
     static const bool no_halo = getenv("TG_NO_HALO_WGRAD") != nullptr || getenv("TG_WGRAD_PW") != nullptr;
     if (!no_halo && n == 5 && pw == 2) {
-        constexpr size_t hl = ((size_t)(5 + 2 + 2 * 36 + 1) * 17 + 52 * 17) * 16;
+        constexpr size_t hl = ((size_t)(5 + 2 + 2 * 36 + 1) * 16 + 52 * 17) * 16;
         hipLaunchKernelGGL((k_wgrad_halo<5, 2>), dim3(splits, ncib * ncob), dim3(256), hl, st, X, xs, xvalid, G, gs, gvalid, B * nsq, cps, ncob, part);
     } else if (!no_halo && n == 6 && pw == 1) {
-        constexpr size_t hl = ((size_t)(6 + 2 + 1 * 49 + 1) * 17 + 36 * 17) * 16;
+        constexpr size_t hl = ((size_t)(6 + 2 + 1 * 49 + 1) * 16 + 36 * 17) * 16;
         hipLaunchKernelGGL((k_wgrad_halo<6, 1>), dim3(splits, ncib * ncob), dim3(256), hl, st, X, xs, xvalid, G, gs, gvalid, B * nsq, cps, ncob, part);
     } else if (rows_chunk <= 64)
         hipLaunchKernelGGL((k_wgrad<true, 4>), dim3(splits, ncib * ncob), dim3(256), lds, st, X, xs, xvalid, G, gs, gvalid, B * nsq, n, nsq,

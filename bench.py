@@ -140,6 +140,13 @@ def tak_amd_supports_bf16x3(args):
     return (args.board == 5 and args.filters in (64, 128)) or (args.board == 6 and args.filters == 128)
 
 
+def switches_set():
+    """the TG_* A/B switches that are ON in this process's environment, as libtakgpu itself reads them (tg_debug_switches; no GPU needed)"""
+    import tak_amd
+
+    return tak_amd.debug_switches()
+
+
 def free_port():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
@@ -213,6 +220,17 @@ class Watchdog:
         return False
 
 
+_LINE = threading.Lock()  # taken by whoever prints this process's ONE JSON line; never released
+
+
+def print_line(obj):
+    """print the JSON line unless this process has already printed one (the C5 phase's watcher thread or watchdog may have) → printed?"""
+    if not _LINE.acquire(blocking=False):
+        return False
+    print(json.dumps(obj), flush=True)
+    return True
+
+
 def run_c5_phase(args, rank, world, out, phase, want_result=False, dist=None):
     """Config C5's phase — the only part of the bench with a data-path collective — under the rules that keep a bad day
     visible: an exception is caught (rank 0's headline line survives, marked `train_c5_failed`), and at N > 1
@@ -225,21 +243,22 @@ def run_c5_phase(args, rank, world, out, phase, want_result=False, dist=None):
         by then.  → (out, failed[, result])"""
     from tak_amd import dist as tdist
 
-    printed = threading.Lock()
+    progress = {"stage": "not started"}  # the phase reports where it is (train_c5's `note`): a timeout names the stage it hung in
 
     def print_marked(error):
-        if rank != 0 or not printed.acquire(blocking=False):
+        if rank != 0:
             return
+        where = {"error": error, "stage": progress["stage"], **{k: v for k, v in progress.items() if k != "stage"}}
         if out is not None:
-            out["train_c5_failed"] = True
-            out.setdefault("extra", {})["train_c5"] = {"error": error}
-            print(json.dumps(out), flush=True)
+            marked = dict(out, train_c5_failed=True)
+            marked["extra"] = dict(out.get("extra", {}), train_c5=where)
+            print_line(marked)
         elif args.train:  # C5 alone: there is no headline yet — say so in the one line
-            print(json.dumps(failed_train_line(world, error)), flush=True)
+            print_line(failed_train_line(world, error, where))
 
     def give_up():
         print(f"bench.py: rank {rank}: the C5 phase did not finish within {args.train_timeout:.0f} s", file=sys.stderr, flush=True)
-        print_marked(f"timed out after {args.train_timeout:.0f} s (world {world})")
+        print_marked(f"timed out after {args.train_timeout:.0f} s (world {world}) in stage '{progress['stage']}'")
 
     board = tdist.FailureBoard(dist) if world > 1 else None
     stop = threading.Event()
@@ -255,15 +274,17 @@ def run_c5_phase(args, rank, world, out, phase, want_result=False, dist=None):
                 os._exit(EXIT_C5_FAILED)
 
     failed = False
+    watcher = None
     try:
         if world > 1:
             if rank == 0 and board.store is not None:
-                threading.Thread(target=watch_peers, daemon=True).start()
+                watcher = threading.Thread(target=watch_peers, daemon=True)
+                watcher.start()
             # (rank 0 first, so that its line is out before the launcher sees another rank's exit code and ends the rest)
             with Watchdog(args.train_timeout + (0.0 if rank == 0 else 15.0), give_up, EXIT_C5_FAILED):
-                c5 = phase()
+                c5 = phase(progress)
         else:
-            c5 = phase()
+            c5 = phase(progress)
     except Exception as ex:
         if args.train and world == 1:
             raise
@@ -274,6 +295,10 @@ def run_c5_phase(args, rank, world, out, phase, want_result=False, dist=None):
             board.wait_acknowledged(20.0)  # rank 0 prints first (or is past the phase already and prints in finish())
     finally:
         stop.set()
+        # the watcher is either idle (it leaves at its next wait) or about to print the marked line and end the process itself:
+        # the main thread does not go on to print a second line beside it
+        if watcher is not None:
+            watcher.join(timeout=30.0)
     if rank == 0 and out is not None and not args.train:
         out.setdefault("extra", {})["train_c5"] = c5
         if failed:
@@ -281,18 +306,18 @@ def run_c5_phase(args, rank, world, out, phase, want_result=False, dist=None):
     return (out, failed, c5) if want_result else (out, failed)
 
 
-def failed_train_line(world, error):
+def failed_train_line(world, error, where=None):
     """the JSON line of `bench.py --train` when the phase failed: no value, marked"""
     return {"metric": "training positions/s (forward + backward + Adam; 8-fold augmented examples)", "value": None, "per_gpu_value": None,
             "unit": "positions/s", "n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "train_c5_failed": True, "train_c5": {"error": error}}
+            "train_c5_failed": True, "train_c5": where or {"error": error}}
 
 
 def finish(rank, world, out, c5_failed, dist):
     """rank 0 prints THE line; then a clean shutdown — or, if config C5 failed at N > 1, a non-zero exit on every rank (the
     headline is out, but a data-parallel run whose collective phase failed must not look green)"""
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print_line(out)  # (skipped if the C5 phase's watcher or watchdog has already printed the marked line)
     if c5_failed and world > 1:
         sys.stdout.flush()
         if rank != 0:
@@ -306,7 +331,7 @@ EXIT_C5_FAILED = 4  # N > 1: the C5 phase (the only collective data path) hung o
 C5_FLOPS_FWD = 161_689_600  # 5x5, 10 blocks x 128 filters, FC-1575 head, 2·MAC per position (forward)
 
 
-def train_c5(args, rank, world, local_rank, dist, backend, barrier_fn):
+def train_c5(args, rank, world, local_rank, dist, backend, barrier_fn, progress=None):
     """BASELINE config C5 on this rank's GPU: the 10-block x 128-filter network plays 5x5 self-play (games sharded by rank, no
     collective), then trains data-parallel on the examples it just produced: tg_train = Network::train (shuffle, chunks of 500
     examples x 8 symmetries, an Adam step every 20 chunks).  With world > 1 every optimiser step all-reduces the flat
@@ -322,7 +347,12 @@ def train_c5(args, rank, world, local_rank, dist, backend, barrier_fn):
     games = args.train_games
     dev = "cuda" if backend == "nccl" else "cpu"
 
-    stage = tdist.Stages(dist, rank, dev).run  # rank-local work, then all ranks agree that it succeeded everywhere
+    progress = {} if progress is None else progress
+    stages = tdist.Stages(dist, rank, dev)
+
+    def stage(name, fn):  # rank-local work, then all ranks agree that it succeeded everywhere; the phase's watchdog names the stage it hung in
+        progress["stage"] = name
+        return stages.run(name, fn)
 
     def setup():
         net, weights = make_weights(n, blocks, filters, "fc5", seed=args.seed)  # the same weights on every rank
@@ -352,6 +382,14 @@ def train_c5(args, rank, world, local_rank, dist, backend, barrier_fn):
         return info
 
     rccl = stage("communicator check", communicator)
+
+    # One float through the reduction the optimiser step will use — RCCL's first collective on this communicator (ring / tree set-up over
+    # xGMI) or the host hook — BEFORE anything of a training step is enqueued: "RCCL could not form a ring on this box" ends here, in a
+    # stage of its own, and reads differently from "our step hung".  Not a Stages.run: the call itself is the collective.
+    progress["stage"] = "reduction preflight (tg_train_comm_preflight: 4 bytes through " + transport + ")"
+    preflight_ms = eng.train_comm_preflight()
+    progress["preflight_ms_rank0"] = preflight_ms
+    preflight = tdist.per_rank_times(dist, preflight_ms, scale=1.0)
 
     # 1. self-play on the C5 network at the headline search settings (2 plies timed after 1 warm-up ply)
     def warm_up():
@@ -390,13 +428,17 @@ def train_c5(args, rank, world, local_rank, dist, backend, barrier_fn):
     t_gen, (hdr, states, moves, visits) = stage("example generation", examples)
 
     # 3. the training step(s), timed
+    progress["stage"] = "tg_train (data-parallel optimiser steps; the gradient all-reduce of every step)"
     barrier_fn(eng)
     t0 = time.perf_counter()
     lp, lz, steps = eng.train(states, hdr["n_moves"], moves, visits, hdr["result"], seed=args.seed + rank)
     eng.sync()
     dt_local = time.perf_counter() - t0
     barrier_fn(eng)
+    progress["stage"] = "after tg_train (reductions of the timings, parameter comparison, tg_train_commit)"
     dt, positions = tdist.reduce_time_and_count(dist, dt_local, need * 8, device=dev)
+    step_ms = tdist.per_rank_times(dist, dt_local / max(steps, 1))
+    sp_ms = tdist.per_rank_times(dist, dt_sp_local / 2)
     reporting = tdist.ranks_reporting(dist, device=dev)
     ar_ms, ar_n = eng.train_comm_stats()
     # identical parameters on every rank after the all-reduced steps
@@ -415,15 +457,19 @@ def train_c5(args, rank, world, local_rank, dist, backend, barrier_fn):
     return {
         "metric": "training positions/s (forward + backward + Adam; 8-fold augmented examples)", "value": positions / dt, "unit": "positions/s",
         "per_gpu_value": per_gpu, "n_gpus": world, "ranks_reporting": reporting, "seconds": dt, "optimizer_steps": steps, "ms_per_optimizer_step": 1000.0 * dt / max(steps, 1),
+        "ms_per_optimizer_step_by_rank": step_ms,  # every rank's own time; `value` uses the slowest
         "positions_per_rank": need * 8, "loss_p": lp, "loss_z": lz,
         "frac_of_f32_mfma_peak": (per_gpu * flops / 1e12 / F32_MFMA_PEAK_TFLOPS) if flops else None,
         "gradient_allreduce": {"transport": transport, "bytes": None if world == 1 else int(eng_param_bytes(blocks, filters, n)),
                                "count": ar_n, "ms_per_step_rank0": (ar_ms / ar_n) if ar_n else 0.0,
+                               # the 4-byte reduction before the first chunk, wall clock per rank (RCCL: includes the communicator's
+                               # first-collective set-up); 0.0 on a single rank
+                               "preflight_ms": preflight["max"], "preflight_ms_by_rank": preflight,
                                # rank 0's view of the communicator (every rank checked its own above): ncclCommCount,
                                # ncclCommUserRank, ncclGetVersion, and the file ncclAllReduce was bound from
                                "rccl": rccl},
         "parameters_identical_on_all_ranks": same,
-        "selfplay_c5net": {"value": sp_total / dt_sp, "unit": "node-expansions/s", "ms_per_step": 1000.0 * dt_sp / 2,
+        "selfplay_c5net": {"value": sp_total / dt_sp, "unit": "node-expansions/s", "ms_per_step": 1000.0 * dt_sp / 2, "ms_per_step_by_rank": sp_ms,
                            "games_per_gpu": games, "sims_per_move": args.rollouts},
         "example_generation_s": t_gen,
         "workload": f"BASELINE config C5: 5x5 Tak, {blocks}-block x {filters}-filter resnet (fc5 head): self-play, then Network::train on its own examples — "
@@ -508,17 +554,29 @@ def main():
         if dist is not None:
             dist.barrier()
         dt, total = tdist.reduce_time_and_count(dist, 1.0 + rank, 1 + rank)
+        devices = tdist.gather(dist, tdist.device_record(rank))
+        t0 = time.perf_counter()
+        tdist.ranks_reporting(dist)  # the rehearsal's stand-in for the reduction preflight: one small all-reduce, timed per rank
+        preflight = tdist.per_rank_times(dist, time.perf_counter() - t0)
         out = {"metric": "launcher rehearsal (no measurement)", "value": None, "per_gpu_value": None, "unit": "node-expansions/s", "n_gpus": world,
                "ranks_reporting": tdist.ranks_reporting(dist), "steps": args.steps, "warmup": args.warmup, "rehearsal": True,
-               "max_over_ranks": dt, "sum_over_ranks": total}
+               "max_over_ranks": dt, "sum_over_ranks": total,
+               # the self-describing fields of a real run, through the same code: per-rank device records, per-rank times, preflight
+               "ms_per_step_by_rank": tdist.per_rank_times(dist, 1.0 + rank),
+               "config": {"devices": devices, "devices_distinct": tdist.check_devices(devices, "gloo"), "backend": "gloo",
+                          "switches_set": sorted(set(sum(tdist.gather(dist, switches_set()), [])))},
+               "preflight_ms_by_rank": preflight}
         if args.rehearse_hang_rank >= 0 or args.rehearse_fail_rank >= 0 or args.rehearse_fail_in_collective_rank >= 0:
             # the two ways config C5 can go wrong at N > 1, acted out with the code the real phase uses: a rank that fails before
             # the collective (Stages: every rank leaves, nobody waits) and a collective that never completes (Watchdog)
-            def phase():
+            def phase(progress):
+                progress["stage"] = "rehearsed stage"
+
                 def local():
                     if rank == args.rehearse_fail_rank:
                         raise RuntimeError("rehearsed local failure")
                 tdist.Stages(dist, rank).run("rehearsed stage", local)
+                progress["stage"] = "rehearsed collective"
                 if rank == args.rehearse_hang_rank:
                     time.sleep(3600.0)
                 if rank == args.rehearse_fail_in_collective_rank:
@@ -546,6 +604,23 @@ def main():
     dist = tdist.init(backend, rank, world, device=torch.device("cuda", local_rank) if backend == "nccl" else None)
 
     import tak_amd
+
+    # who sits where: every rank's card as ITS engine sees it (tg_device_info), gathered; two ranks on one card under the RCCL
+    # backend end the run here, on every rank, before anything is measured
+    probe = tak_amd.Engine(args.board, evaluator=tak_amd.EVAL_DUMMY, max_batch=1, device=local_rank)
+    devices = tdist.gather(dist, tdist.device_record(rank, probe))
+    probe.close()
+    try:
+        distinct = tdist.check_devices(devices, backend)
+    except RuntimeError as ex:
+        print(f"bench.py: rank {rank}: {ex}", file=sys.stderr, flush=True)
+        sys.exit(2)
+    switches = sorted(set(sum(tdist.gather(dist, switches_set()), [])))
+    launch_config = {"devices": devices, "devices_distinct": distinct, "backend": backend if world > 1 else None,
+                     # TG_* A/B switches that are ON in some rank's environment (tg_debug_switches): [] on a measured run
+                     "switches_set": switches}
+    if switches:
+        print(f"bench.py: rank {rank}: A/B switches are set: {switches} — the line does not describe the default path", file=sys.stderr, flush=True)
 
     net, tensors = make_weights(args.board, args.blocks, args.filters, args.head, seed=args.seed)
     steps_total = args.steps + args.warmup
@@ -602,6 +677,7 @@ def main():
         dt_local, expansions, evals, prof = run(args.precision, args.profile_every)
         dt, total_exp = tdist.reduce_time_and_count(dist, dt_local, expansions, device="cuda" if backend == "nccl" else "cpu")
         reporting = tdist.ranks_reporting(dist, device="cuda" if backend == "nccl" else "cpu")
+        by_rank = tdist.per_rank_times(dist, dt_local / max(args.steps, 1))
 
         if rank == 0:
             out = {
@@ -614,6 +690,7 @@ def main():
                 "steps": args.steps,
                 "warmup": args.warmup,
                 "ms_per_step": 1000.0 * dt / max(args.steps, 1),
+                "ms_per_step_by_rank": by_rank,   # every rank's own time (ms); `ms_per_step` is the slowest (a straggler shows here)
                 "higher_is_better": True,
                 "scaling": "weak",
                 "vs_baseline": None,
@@ -625,6 +702,7 @@ def main():
                     "games_per_gpu": args.games, "sims_per_move": args.rollouts, "board": args.board,
                     "parallelism": f"games sharded x{world}, no data-path collective",
                     "expansions_timed": total_exp, "network_evals_rank0": evals,
+                    **launch_config,
                 },
             }
             if prof and prof["conv_launches"]:
@@ -700,7 +778,7 @@ def main():
     # config C5 on every rank (the only part of the bench with a data-path collective)
     c5_failed = False
     if args.train or not (args.no_train or args.no_extras or args.precision != "f32"):
-        out, c5_failed, c5 = run_c5_phase(args, rank, world, out, lambda: train_c5(args, rank, world, local_rank, dist, backend, barrier), want_result=True, dist=dist)
+        out, c5_failed, c5 = run_c5_phase(args, rank, world, out, lambda progress: train_c5(args, rank, world, local_rank, dist, backend, barrier, progress), want_result=True, dist=dist)
         if rank == 0 and args.train and (c5_failed or "error" in c5):
             out = failed_train_line(world, c5.get("error"))
         elif rank == 0 and args.train:
@@ -709,7 +787,8 @@ def main():
                 "ranks_reporting": c5["ranks_reporting"], "steps": c5["optimizer_steps"], "warmup": 0,
                 "ms_per_step": c5["ms_per_optimizer_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                 "data": "synthetic (examples from the network's own self-play)",
-                "config": {"workload": c5["workload"], "parallelism": f"data parallel x{world}, one gradient all-reduce per optimiser step"},
+                "ms_per_step_by_rank": c5["ms_per_optimizer_step_by_rank"],
+                "config": {"workload": c5["workload"], "parallelism": f"data parallel x{world}, one gradient all-reduce per optimiser step", **launch_config},
                 "roofline": {"bound": "mfma", "kernel": "whole training step (forward + data gradients + weight gradients + BatchNorm + Adam)",
                              "achieved": None if c5["frac_of_f32_mfma_peak"] is None else c5["frac_of_f32_mfma_peak"] * F32_MFMA_PEAK_TFLOPS,
                              "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": c5["frac_of_f32_mfma_peak"], "traffic": None},

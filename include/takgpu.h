@@ -28,7 +28,14 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 4
+#define TG_ABI_VERSION 5
+
+/* The library is built with -fvisibility=hidden: the entry points below are ALL it exports. */
+#if defined(__GNUC__) || defined(__clang__)
+#define TG_API __attribute__((visibility("default")))
+#else
+#define TG_API
+#endif
 
 /* ---------------------------------------------------------------------------------------
  * Status codes.  TG_PLAY_* mirror reference tak/src/error.rs:4-15 (PlayError) and
@@ -130,7 +137,7 @@ typedef struct TgState6 {
 #define TG_META_TOP(m) ((m) >> 6)
 
 /* size in bytes of one packed state for board size n (256 for n ≤ 5, 384 for n = 6) */
-size_t tg_state_bytes(int n);
+TG_API size_t tg_state_bytes(int n);
 
 /* ---------------------------------------------------------------------------------------
  * Move code (replaces takparse 0.5.5 `Move{square, kind}`; reference call sites
@@ -174,17 +181,32 @@ typedef struct TgConfig {
     int32_t max_batch;     /* largest n passed to tg_policy_eval / number of concurrent games */
 } TgConfig;
 
-int tg_engine_create(const TgConfig* cfg, TgEngine** out);
-void tg_engine_destroy(TgEngine* e);
-const char* tg_last_error(void);
-int tg_sync(TgEngine* e);
+TG_API int tg_engine_create(const TgConfig* cfg, TgEngine** out);
+TG_API void tg_engine_destroy(TgEngine* e);
+TG_API const char* tg_last_error(void);
+TG_API int tg_sync(TgEngine* e);
 /* the hipStream_t the engine launches on (as void*), for callers timing with HIP events */
-void* tg_stream(TgEngine* e);
+TG_API void* tg_stream(TgEngine* e);
+
+/* Which card the engine runs on, as the HIP runtime names it — so that a multi-process launch (one rank per GPU, reference
+ * train/src/self_play.rs:98,102-104: one shard per process) can show that its N ranks sat on N DISTINCT devices: two ranks that
+ * were handed the same card report the same pci_bus_id. */
+typedef struct TgDeviceInfo {
+    int32_t hip_device;     /* TgConfig.device: the ordinal inside this process (after HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES) */
+    int32_t cu_count;       /* hipDeviceProp_t.multiProcessorCount: 256 on an MI355X                              */
+    int32_t clock_khz;      /* hipDeviceProp_t.clockRate                                                           */
+    int32_t reserved;
+    uint64_t total_mem;     /* bytes of device memory                                                              */
+    char pci_bus_id[32];    /* hipDeviceGetPCIBusId: "domain:bus:device.function"                                   */
+    char name[128];         /* hipDeviceProp_t.name                                                                 */
+    char arch[64];          /* hipDeviceProp_t.gcnArchName, e.g. "gfx950:sramecc+:xnack-"                          */
+} TgDeviceInfo;
+TG_API int tg_device_info(TgEngine* e, TgDeviceInfo* out);
 
 /* sizes — reference alpha-tak/src/repr/game.rs:12-15 (input_channels) and repr/moves.rs:6-31
  * (possible_moves / output_size).  policy_size depends on the head. */
-int tg_input_channels(int n);
-int tg_policy_size(int n, int policy_head);
+TG_API int tg_input_channels(int n);
+TG_API int tg_policy_size(int n, int policy_head);
 
 /* ---------------------------------------------------------------------------------------
  * Board operators on batches (host buffers).  `states` is n packed states of
@@ -193,34 +215,34 @@ int tg_policy_size(int n, int policy_head);
 
 /* Game::possible_moves (tak/src/move_gen.rs:7-30), same order.  moves: n*TG_MAX_MOVES codes,
  * counts: n.  A position with more than TG_MAX_MOVES moves yields TG_ERR_INVALID_ARG. */
-int tg_movegen(TgEngine* e, int n, const void* states, TgMove* moves, int32_t* counts);
+TG_API int tg_movegen(TgEngine* e, int n, const void* states, TgMove* moves, int32_t* counts);
 
 /* Game::play (tak/src/game.rs:121-130) in place; status[i] = TgPlayError.  Returns
  * TG_ERR_ILLEGAL_MOVE if any item failed (failed items are left unchanged — the behaviour of
  * Game::safe_play, game.rs:136-145). */
-int tg_play(TgEngine* e, int n, void* states, const TgMove* moves, uint8_t* status);
+TG_API int tg_play(TgEngine* e, int n, void* states, const TgMove* moves, uint8_t* status);
 
 /* Game::result (tak/src/game.rs:220-267); results[i] = TgResult */
-int tg_result(TgEngine* e, int n, const void* states, uint8_t* results);
+TG_API int tg_result(TgEngine* e, int n, const void* states, uint8_t* results);
 
 /* game_repr (alpha-tak/src/repr/game.rs:19-51): planes n × C_in × N × N f32, NCHW like the
  * reference tensor (index c*N² + row*N + col). */
-int tg_encode(TgEngine* e, int n, const void* states, float* planes);
+TG_API int tg_encode(TgEngine* e, int n, const void* states, float* planes);
 
 /* move_index (alpha-tak/src/search/move_map.rs:19-48) for k moves; -1 where the reference
  * would panic ("could not map turn to index"). */
-int tg_move_index(TgEngine* e, int k, const TgMove* moves, int32_t* index);
+TG_API int tg_move_index(TgEngine* e, int k, const TgMove* moves, int32_t* index);
 
 /* Example::to_tensors (alpha-tak/src/example.rs:62-78) over Symmetry (tak/src/symm.rs:7-97): the 8 dihedral
  * images of n examples.  In: n states, per example n_moves[i] (move, visits) pairs in rows of TG_MAX_MOVES.
  * Out: 8n packed states (image order of symm.rs:11-20; feed them to tg_encode for the input planes) and 8n
  * policy targets of P floats: visits/total at move_index of the transformed move, 0 elsewhere. */
-int tg_augment_examples(TgEngine* e, int n, const void* states, const int32_t* n_moves, const TgMove* moves,
+TG_API int tg_augment_examples(TgEngine* e, int n, const void* states, const int32_t* n_moves, const TgMove* moves,
                         const uint32_t* visits, void* out_states, float* pi);
 
 /* perft of tak/tests/perft.rs:3-18 evaluated on the GPU: one count per input state.
  * depth ≥ 0.  Expands level by level on the device (movegen+play+result kernels). */
-int tg_perft(TgEngine* e, int n, const void* states, int depth, uint64_t* counts);
+TG_API int tg_perft(TgEngine* e, int n, const void* states, int depth, uint64_t* counts);
 
 /* ---------------------------------------------------------------------------------------
  * Network (replaces Network<N>, alpha-tak/src/model/network.rs:26-35, without tch types)
@@ -231,15 +253,15 @@ int tg_perft(TgEngine* e, int n, const void* states, int depth, uint64_t* counts
  * "bn0.running_var"; "res{i}.conv1.weight" … "res{i}.bn2.running_var" (i = 0..R-1);
  * "policy.weight" "policy.bias" (FC5: [1575, F*25]; CONV: [ch, F, 3, 3]); "value.weight"
  * "value.bias" ([1, F*N*N]).  Creation order of net5.rs:29-62 / net6.rs:29-57. */
-int tg_net_set_tensor(TgEngine* e, const char* name, const float* data, size_t count);
+TG_API int tg_net_set_tensor(TgEngine* e, const char* name, const float* data, size_t count);
 /* Network::default() (net5.rs:29-73 / net6.rs:29-69): fill every tensor with tch's default initialisers (conv: weight
  * U(±1/sqrt(fan_in)), bias 0; BatchNorm: weight U(0,1), bias 0, mean 0, var 1; linear: weight and bias U(±1/sqrt(in))),
  * drawn from Philox(seed).  The reference draws from libtorch's global generator: same distribution, other values. */
-int tg_net_init_random(TgEngine* e, uint64_t seed);
+TG_API int tg_net_init_random(TgEngine* e, uint64_t seed);
 /* read back a tensor (tch layout) as last set / initialised / committed by the trainer — what Network::save writes */
-int tg_net_get_tensor(TgEngine* e, const char* name, float* out, size_t count);
+TG_API int tg_net_get_tensor(TgEngine* e, const char* name, float* out, size_t count);
 /* Fold BN (eval mode, eps 1e-5) into the convs, re-layout for the MFMA kernels, upload. */
-int tg_net_finalize(TgEngine* e);
+TG_API int tg_net_finalize(TgEngine* e);
 /* Arithmetic of the residual tower (call before tg_net_finalize).
  * TG_PRECISION_F32 (default): f32 operands on v_mfma_f32_16x16x4_f32 — exact f32 fmaf chains.
  * TG_PRECISION_BF16X3: every f32 operand is carried as hi + lo bf16 halves and a product is the sum of three bf16
@@ -247,19 +269,19 @@ int tg_net_finalize(TgEngine* e);
  *   Measured deviation from the f32 forward ≤ 1e-5 relative on the policy and ≤ 3e-6 on the eval, inside the 1e-4 the
  *   reference comparison allows; supported for 5×5 (64 / 128 filters) and 6×6 (128 filters).  Heads stay f32. */
 typedef enum TgPrecision { TG_PRECISION_F32 = 0, TG_PRECISION_BF16X3 = 1 } TgPrecision;
-int tg_net_set_precision(TgEngine* e, int precision);
+TG_API int tg_net_set_precision(TgEngine* e, int precision);
 
 /* Network::policy_eval (net5.rs:120-130 / net6.rs:124-138): n states → policy n×P
  * (full softmax, not masked) and eval n (tanh).  n = 0 is allowed (returns TG_OK). */
-int tg_policy_eval(TgEngine* e, int n, const void* states, float* policy, float* eval);
+TG_API int tg_policy_eval(TgEngine* e, int n, const void* states, float* policy, float* eval);
 
 /* Network::forward_mcts (net5.rs:106-111) on already-encoded planes (n × C_in × N × N, NCHW,
  * host).  Same outputs as tg_policy_eval. */
-int tg_forward_mcts(TgEngine* e, int n, const float* planes, float* policy, float* eval);
+TG_API int tg_forward_mcts(TgEngine* e, int n, const float* planes, float* policy, float* eval);
 
 /* Device-resident variants used by bench.py: d_states / d_policy / d_eval are device
  * pointers; no synchronisation. */
-int tg_policy_eval_dev(TgEngine* e, int n, const void* d_states, float* d_policy, float* d_eval);
+TG_API int tg_policy_eval_dev(TgEngine* e, int n, const void* d_states, float* d_policy, float* d_eval);
 
 /* ---------------------------------------------------------------------------------------
  * Search (replaces Node + Node::{virtual_rollout, devirtualize_path, select, apply_dirichlet,
@@ -295,31 +317,31 @@ typedef struct TgSearchConfig {
     int32_t reserved;
 } TgSearchConfig;
 
-int tg_search_create(TgEngine* e, const TgSearchConfig* cfg);
+TG_API int tg_search_create(TgEngine* e, const TgSearchConfig* cfg);
 /* (re)start every tree as Node::default() with the given root states (host, games packed states).  The states are checked
  * on the host (board size, heights, colour bits, reserves): one no game can reach → TG_ERR_INVALID_ARG naming it. */
-int tg_search_reset(TgEngine* e, const void* states);
+TG_API int tg_search_reset(TgEngine* e, const void* states);
 /* run `iters` lock-step iterations (virtual_rollout → policy_eval → devirtualize_path).
  * active: optional host mask (games bytes, 0 = skip this game), NULL = all. */
-int tg_search_run(TgEngine* e, int iters, const uint8_t* active);
+TG_API int tg_search_run(TgEngine* e, int iters, const uint8_t* active);
 /* Node::apply_dirichlet (noise.rs:6-16) on every active root with engine RNG
  * (stream = (seed, game, ply)). */
-int tg_search_apply_dirichlet(TgEngine* e, float alpha, float ratio, const uint8_t* active);
+TG_API int tg_search_apply_dirichlet(TgEngine* e, float alpha, float ratio, const uint8_t* active);
 /* Node::apply_dirichlet with caller-supplied noise (games × TG_MAX_MOVES f32, row g holds one
  * sample per child of root g) — lets a test feed the same samples to the oracle. */
-int tg_search_apply_noise(TgEngine* e, const float* noise, float ratio, const uint8_t* active);
+TG_API int tg_search_apply_noise(TgEngine* e, const float* noise, float ratio, const uint8_t* active);
 /* Node::improved_policy (play.rs:13-21) + root stats: per game the root's children in
  * possible_moves order.  moves/visits/prior/q: games × TG_MAX_MOVES; counts: games;
  * root_visits / root_q: games (any pointer may be NULL). */
-int tg_search_root(TgEngine* e, TgMove* moves, uint32_t* visits, float* prior, float* q,
+TG_API int tg_search_root(TgEngine* e, TgMove* moves, uint32_t* visits, float* prior, float* q,
                    int32_t* counts, uint32_t* root_visits, float* root_q);
 /* Node::play (play.rs:26-43) + Game::play: advance each active game by moves[g] with tree reuse: the chosen child's
  * subtree is copied breadth-first into fresh chunks of the shared node pool and the game's old chunks return to the pool.
  * The returned chunks become available to allocators only at the next launch, so WHILE a move is played the pool holds the
  * old trees and the kept subtrees at once (see arena_nodes: headroom). */
-int tg_search_play(TgEngine* e, const TgMove* moves, const uint8_t* active);
+TG_API int tg_search_play(TgEngine* e, const TgMove* moves, const uint8_t* active);
 /* current root states (games packed states) */
-int tg_search_states(TgEngine* e, void* states);
+TG_API int tg_search_states(TgEngine* e, void* states);
 /* canonical serialisation of game g's whole tree, depth-first in child order, one record per
  * initialised node: {move u16, n_children u16, visits u32, virtual u32, result u32,
  * prior f32 bits, q f32 bits}.  Returns record count through *n_records (cap = capacity). */
@@ -332,13 +354,13 @@ typedef struct TgNodeRecord {
     uint32_t prior_bits;
     uint32_t q_bits;
 } TgNodeRecord;
-int tg_search_dump(TgEngine* e, int game, TgNodeRecord* records, size_t capacity, size_t* n_records);
+TG_API int tg_search_dump(TgEngine* e, int game, TgNodeRecord* records, size_t capacity, size_t* n_records);
 /* counters since tg_search_create: expansions = completed rollouts (terminal ones included,
  * as in the reference's ROLLOUTS loop), evals = leaves sent to the network */
-int tg_search_counters(TgEngine* e, uint64_t* expansions, uint64_t* evals);
+TG_API int tg_search_counters(TgEngine* e, uint64_t* expansions, uint64_t* evals);
 /* occupancy of the node pool (for sizing TgSearchConfig.arena_nodes): nodes the pool holds, nodes in chunks currently owned
  * by trees, and the largest number of nodes ever owned at once since tg_search_create / tg_search_reset.  Synchronises. */
-int tg_search_pool(TgEngine* e, uint64_t* nodes_total, uint64_t* nodes_in_use, uint64_t* nodes_peak);
+TG_API int tg_search_pool(TgEngine* e, uint64_t* nodes_total, uint64_t* nodes_in_use, uint64_t* nodes_peak);
 
 /* ---------------------------------------------------------------------------------------
  * Self-play driver (replaces self_play_parallel, train/src/self_play.rs:96-262).
@@ -369,10 +391,10 @@ typedef struct TgExampleHeader {
     int32_t reserved;
 } TgExampleHeader;
 
-int tg_selfplay_create(TgEngine* e, const TgSearchConfig* scfg, const TgSelfPlayConfig* cfg);
+TG_API int tg_selfplay_create(TgEngine* e, const TgSearchConfig* scfg, const TgSelfPlayConfig* cfg);
 /* run `plies` lock-step plies of self_play_parallel's outer loop (opening → instant-win scan
  * → noise → rollouts → pick/play/recycle).  Asynchronous; tg_sync() to wait. */
-int tg_selfplay_step(TgEngine* e, int plies);
+TG_API int tg_selfplay_step(TgEngine* e, int plies);
 /* statistics: finished games, emitted examples, expansions, network evals */
 typedef struct TgSelfPlayStats {
     uint64_t games_finished;
@@ -388,12 +410,12 @@ typedef struct TgSelfPlayStats {
     uint64_t alive_games;      /* slots still playing: 0 once every slot has retired (completed + games ≥ total_games) —
                                   the end of self_play_parallel's `while` loop (self_play.rs:107) */
 } TgSelfPlayStats;
-int tg_selfplay_stats(TgEngine* e, TgSelfPlayStats* out);
+TG_API int tg_selfplay_stats(TgEngine* e, TgSelfPlayStats* out);
 /* copy out up to `cap` finished examples (headers + states + moves + visits) and remove them
  * from the ring.  states: cap packed states; moves/visits: cap × TG_MAX_MOVES.  Examples the ring has already
  * overwritten (more than max_examples finished since the last drain) are skipped and counted in
  * TgSelfPlayStats.dropped_examples: size max_examples ≥ games × expected plies per drain interval. */
-int tg_selfplay_drain(TgEngine* e, int cap, TgExampleHeader* headers, void* states, TgMove* moves,
+TG_API int tg_selfplay_drain(TgEngine* e, int cap, TgExampleHeader* headers, void* states, TgMove* moves,
                       uint32_t* visits, int32_t* n_out);
 
 /* ---------------------------------------------------------------------------------------
@@ -419,12 +441,12 @@ typedef struct TgTrainConfig {
 
 /* Adam{wd}.build(vs, lr) (network.rs:40-45): creates the trainer from the tensors given to tg_net_set_tensor
  * (all of them, as for tg_net_finalize) with zero optimiser state and zero gradients. */
-int tg_train_create(TgEngine* e, const TgTrainConfig* cfg);
+TG_API int tg_train_create(TgEngine* e, const TgTrainConfig* cfg);
 /* train_inner (network.rs:58-97) on one chunk of n ≤ chunk_size examples (layout of tg_selfplay_drain:
  * states, n_moves, rows of TG_MAX_MOVES moves / visits; results = Example::result).  Returns the two losses
  * the reference prints (loss_p, loss_z); *stepped = 1 when this chunk completed an optimiser step.  Examples are validated on
  * the host (a reachable state, 1 ≤ n_moves ≤ TG_MAX_MOVES, at least one visit) → TG_ERR_INVALID_ARG. */
-int tg_train_chunk(TgEngine* e, int n, const void* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
+TG_API int tg_train_chunk(TgEngine* e, int n, const void* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
                    const float* results, float* loss_p, float* loss_z, int32_t* stepped);
 /* Network::train (network.rs:37-56): fresh Adam state and zeroed gradients, shuffle (Philox keyed by seed; the reference
  * uses thread_rng), chunks_exact(chunk_size) → tg_train_chunk each.  mean losses over the chunks are returned.  Every
@@ -437,16 +459,19 @@ int tg_train_chunk(TgEngine* e, int n, const void* states, const int32_t* n_move
  * Execution: the weight gradients of a chunk run on a stream of their own beside the data-gradient chain
  * (TG_TRAIN_ONE_STREAM=1: on the chain's stream); while chunk k runs, tg_train gathers and uploads chunk k + 1 on a copy stream and
  * enqueues it behind chunk k.  The chunks still execute one after the other: the result is that of tg_train_chunk per chunk, bit for bit. */
-int tg_train(TgEngine* e, int n, const void* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
+TG_API int tg_train(TgEngine* e, int n, const void* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
              const float* results, uint64_t seed, float* mean_loss_p, float* mean_loss_z, int32_t* steps);
 /* opt.step(); opt.zero_grad() now (network.rs:92-96), whatever the chunk counter says */
-int tg_train_step(TgEngine* e);
+TG_API int tg_train_step(TgEngine* e);
+/* the permutation tg_train(seed) visits n examples in (refs.shuffle, network.rs:49-50 — Philox here, thread_rng there): chunk k of
+ * tg_train = examples order[k·chunk_size … (k+1)·chunk_size) handed to tg_train_chunk in that order.  Host only, no engine. */
+TG_API int tg_train_order(uint64_t seed, int n, int32_t* order);
 /* forward_training (net5.rs:113-118): n ≤ 8·chunk_size states → log_softmax policy (n × P) and eval (n),
  * BatchNorm on the statistics of this batch (running statistics are updated, as in libtorch). */
-int tg_train_forward(TgEngine* e, int n, const void* states, float* logp, float* eval);
+TG_API int tg_train_forward(TgEngine* e, int n, const void* states, float* logp, float* eval);
 /* current value of a parameter / BN buffer (names of tg_net_set_tensor) and of its accumulated gradient */
-int tg_train_get_tensor(TgEngine* e, const char* name, float* out, size_t count);
-int tg_train_get_grad(TgEngine* e, const char* name, float* out, size_t count);
+TG_API int tg_train_get_tensor(TgEngine* e, const char* name, float* out, size_t count);
+TG_API int tg_train_get_grad(TgEngine* e, const char* name, float* out, size_t count);
 /* Intermediate tensors of the training step, for parity tests and error budgets (no counterpart in the reference; libtorch users
  * would register hooks).  tg_train_debug_read: what = "planes" (NHWC input [rows][cin_pad]); "z" / "y" (conv output / activation
  * of conv layer `layer` = 0 conv0, 1 + 2i res{i}.conv1, 2 + 2i res{i}.conv2; [rows][filters]); "mean" / "invstd" (the batch
@@ -454,15 +479,15 @@ int tg_train_get_grad(TgEngine* e, const char* name, float* out, size_t count);
  * w.r.t. y before the ReLU mask, w.r.t. z, and the data gradient handed to the layer below — for conv1 of a block with the skip
  * path's gradient added; [rows][filters]) of the layer armed with tg_train_debug_capture BEFORE the chunk (layer < 0 disarms;
  * three device copies per chunk while armed).  count = floats to read (≤ the tensor). */
-int tg_train_debug_capture(TgEngine* e, int layer);
-int tg_train_debug_read(TgEngine* e, const char* what, int layer, float* out, size_t count);
+TG_API int tg_train_debug_capture(TgEngine* e, int layer);
+TG_API int tg_train_debug_read(TgEngine* e, const char* what, int layer, float* out, size_t count);
 /* make the trained parameters the ones tg_policy_eval / search / self-play use (tg_net_set_tensor of every
  * tensor + tg_net_finalize).  With a communicator the BN running statistics are averaged over the ranks first. */
-int tg_train_commit(TgEngine* e);
+TG_API int tg_train_commit(TgEngine* e);
 /* RCCL communicator for the gradient all-reduce: rank 0 calls tg_comm_unique_id (128 bytes) and hands the id
  * to every rank (any host transport); then every rank calls tg_train_comm_init. */
-int tg_comm_unique_id(void* id128);
-int tg_train_comm_init(TgEngine* e, int rank, int world_size, const void* id128);
+TG_API int tg_comm_unique_id(void* id128);
+TG_API int tg_train_comm_init(TgEngine* e, int rank, int world_size, const void* id128);
 /* The same reduction through a caller-supplied function instead of RCCL — ranks that share one GPU (RCCL refuses duplicate
  * devices), a host transport (gloo, MPI, a socket from Rust), or a test.  The optimiser step calls
  * fn(ctx, d_buf, count, stream) with the flat gradient buffer (device memory, `count` floats); on return — or, if fn only
@@ -471,14 +496,14 @@ int tg_train_comm_init(TgEngine* e, int rank, int world_size, const void* id128)
  * tg_train_commit reduces the BatchNorm running statistics through the same function.  fn returns 0 or an error code
  * (→ TG_ERR_STATE).  fn = NULL removes the hook.  Mutually exclusive with tg_train_comm_init. */
 typedef int (*TgAllReduceFn)(void* ctx, float* d_buf, size_t count, void* hip_stream);
-int tg_train_set_allreduce(TgEngine* e, TgAllReduceFn fn, void* ctx, int world_size);
+TG_API int tg_train_set_allreduce(TgEngine* e, TgAllReduceFn fn, void* ctx, int world_size);
 /* device address and length (floats) of the flat gradient buffer the reduction operates on: parameters in the creation
  * order of tg_net_set_tensor's names, BatchNorm buffers excluded */
-int tg_train_grad_buffer(TgEngine* e, float** d_grads, size_t* count);
+TG_API int tg_train_grad_buffer(TgEngine* e, float** d_grads, size_t* count);
 /* Measurement: every gradient all-reduce an optimiser step issues (RCCL or the hook) is bracketed
  * with HIP events on the engine stream; this call synchronises the stream and returns their total duration in
  * milliseconds and their number since tg_train_create.  Zero reductions on a single-rank trainer. */
-int tg_train_comm_stats(TgEngine* e, double* ms_total, int64_t* reductions);
+TG_API int tg_train_comm_stats(TgEngine* e, double* ms_total, int64_t* reductions);
 
 /* What is attached to the optimiser step's reduction, as the library itself sees it — so that a launch log can answer "did
  * RCCL see N ranks, and which RCCL": ncclCommCount / ncclCommUserRank of the communicator, ncclGetVersion, and the file
@@ -495,7 +520,14 @@ typedef struct TgCommInfo {
     int32_t reserved;
     char lib_path[256];     /* the shared object ncclAllReduce resolves into; "" if librccl was never loaded */
 } TgCommInfo;
-int tg_train_comm_info(TgEngine* e, TgCommInfo* out);
+TG_API int tg_train_comm_info(TgEngine* e, TgCommInfo* out);
+/* Preflight of the reduction the optimiser step will use (RCCL communicator or the caller's function), before the first chunk:
+ * every rank contributes 1.0f, ONE float is summed over the ranks on the engine stream, and the call returns when the result is
+ * back on the host — TG_ERR_STATE if it is not world_size.  *ms = wall-clock milliseconds of that round trip (the first
+ * collective on a communicator also pays RCCL's connection set-up: ring / tree construction over xGMI).  A launch that
+ * cannot form a ring stops HERE, with nothing of a training step enqueued, and reads differently from a step that hangs.
+ * Collective: every rank must call it.  Single-rank trainer (nothing attached): *ms = 0, returns TG_OK. */
+TG_API int tg_train_comm_preflight(TgEngine* e, double* ms);
 
 /* ---------------------------------------------------------------------------------------
  * Pit (replaces `pit`, train/src/pit.rs:15-96): the new network against the old one,
@@ -534,7 +566,7 @@ typedef struct TgPitResult {
     uint32_t ref_pairs;           /* openings counted (= pairs when the loop never breaks) */
     double ref_win_rate;
 } TgPitResult;
-int tg_pit(TgEngine* e_new, TgEngine* e_old, const TgPitConfig* cfg, TgPitResult* out);
+TG_API int tg_pit(TgEngine* e_new, TgEngine* e_old, const TgPitConfig* cfg, TgPitResult* out);
 
 /* ---------------------------------------------------------------------------------------
  * Text formats at the edge of the path (host only).  PTN moves / TPS positions follow takparse 0.5.5's
@@ -543,13 +575,13 @@ int tg_pit(TgEngine* e_new, TgEngine* e_old, const TgPitConfig* cfg, TgPitResult
  * {move:visits,…}"), so drained examples can be written as the reference's `_examples/{time}.data` files.
  * format functions return the text length (≥ 0) or a negative TgStatus.
  * ------------------------------------------------------------------------------------- */
-int tg_format_move(int n, TgMove mv, char* buf, size_t cap);
-int tg_parse_move(int n, const char* text, TgMove* out);
-int tg_format_tps(int n, const void* state, char* buf, size_t cap);
-int tg_parse_tps(int n, const char* text, void* state); /* reserves derived from the board, half_komi 0 */
-int tg_format_example(int n, const void* state, int n_moves, const TgMove* moves, const uint32_t* visits, float result,
+TG_API int tg_format_move(int n, TgMove mv, char* buf, size_t cap);
+TG_API int tg_parse_move(int n, const char* text, TgMove* out);
+TG_API int tg_format_tps(int n, const void* state, char* buf, size_t cap);
+TG_API int tg_parse_tps(int n, const char* text, void* state); /* reserves derived from the board, half_komi 0 */
+TG_API int tg_format_example(int n, const void* state, int n_moves, const TgMove* moves, const uint32_t* visits, float result,
                       char* buf, size_t cap);
-int tg_parse_example(int n, const char* line, void* state, int cap_moves, TgMove* moves, uint32_t* visits,
+TG_API int tg_parse_example(int n, const char* line, void* state, int cap_moves, TgMove* moves, uint32_t* visits,
                      int32_t* n_moves, float* result);
 
 /* ---------------------------------------------------------------------------------------
@@ -569,14 +601,21 @@ typedef struct TgProfile {
                                  takes the per-position constant input planes (reserves, colour, fcd) as a bias and runs
                                  layer 0 over the board planes only — price the MFMA pipe against THIS figure       */
 } TgProfile;
-int tg_profile_enable(TgEngine* e, int sample_every); /* 0 disables */
+TG_API int tg_profile_enable(TgEngine* e, int sample_every); /* 0 disables */
 /* Board-path micro-benchmark: uploads n states + one legal move each, then runs `reps`
  * fused passes (Game::play → Game::result → possible_moves count → game_repr planes, all on the device,
  * inputs resident in HBM) bracketed by HIP events.  Returns the average pass time; out_* (host, optional)
  * receive the outputs of the last pass: stepped states, results, move counts. */
-int tg_board_pass_bench(TgEngine* e, int n, const void* states, const TgMove* moves, int reps, double* avg_ms,
+TG_API int tg_board_pass_bench(TgEngine* e, int n, const void* states, const TgMove* moves, int reps, double* avg_ms,
                         void* out_states, uint8_t* out_results, int32_t* out_counts);
-int tg_profile_read(TgEngine* e, TgProfile* out);     /* synchronises; resets the totals */
+TG_API int tg_profile_read(TgEngine* e, TgProfile* out);     /* synchronises; resets the totals */
+
+/* A/B switches.  The library reads a fixed set of TG_* environment variables (every one is read through ONE
+ * function: a switch is on when the variable is set to anything but "" or "0"; the two numeric ones — TG_TOWER_VARIANT,
+ * TG_WGRAD_PW — take their value, 0 = off).  tg_debug_switches writes the switches that are ON in this process's
+ * environment as "NAME=value NAME=value …" into buf (always NUL-terminated, truncated to cap) and returns their number:
+ * 0 on a measured run — bench.py prints the list as config.switches_set.  Needs no engine and no GPU. */
+TG_API int tg_debug_switches(char* buf, size_t cap);
 
 #ifdef __cplusplus
 }

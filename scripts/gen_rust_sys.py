@@ -5,7 +5,7 @@ The header is the single source of truth of the C ABI; this script is its only r
 `parse_header()` — the tiny C-declaration parser tests/test_rust_binding.py uses to compare the header with the
 committed lib.rs field by field, so a header edit without a regenerated binding fails the CPU test suite.
 
-    python scripts/gen_rust_sys.py            # rewrite rust/takgpu-sys/src/lib.rs
+    python scripts/gen_rust_sys.py            # rewrite rust/takgpu-sys/src/lib.rs and the entry-point count in INTEGRATION.md
     python scripts/gen_rust_sys.py --check    # exit 1 if the committed file differs
 """
 import os
@@ -63,6 +63,7 @@ def parse_header(path=HEADER):
     """→ dict(defines=[(name, value)], enums=[(name, [(item, value)])], structs=[(name, [(field, ctype, array)])],
     aliases=[(name, ctype)], opaque=[name], fnptrs=[(name, ret, [(ctype, argname)])], functions=[(name, ret, [(ctype, argname)])])"""
     text = strip_comments(open(path).read())
+    text = re.sub(r"\bTG_API\s+", "", text)  # the export attribute of the 60-odd entry points: not part of a signature
     out = dict(defines=[], enums=[], structs=[], aliases=[], opaque=[], fnptrs=[], functions=[])
     for m in re.finditer(r"^#define\s+(TG_[A-Z0-9_]+)\s+(.+)$", text, flags=re.M):
         name, val = m.group(1), m.group(2).strip()
@@ -170,13 +171,27 @@ def generate(h):
     return "\n".join(L) + "\n"
 
 
+INTEGRATION = os.path.join(ROOT, "INTEGRATION.md")
+COUNT_RE = re.compile(r"(<!-- abi-entry-points -->)\d+(<!-- /abi-entry-points -->)")
+
+
+def integration_text(h, path=INTEGRATION):
+    """INTEGRATION.md with the number of entry points taken from the header (the figure between the abi-entry-points markers)"""
+    text = open(path).read()
+    assert COUNT_RE.search(text), "INTEGRATION.md has lost its <!-- abi-entry-points --> markers"
+    return COUNT_RE.sub(lambda m: f"{m.group(1)}{len(h['functions'])}{m.group(2)}", text)
+
+
 def main():
-    text = generate(parse_header())
+    h = parse_header()
+    text = generate(h)
+    doc = integration_text(h)
     if "--check" in sys.argv:
-        sys.exit(0 if os.path.exists(OUT) and open(OUT).read() == text else 1)
+        sys.exit(0 if os.path.exists(OUT) and open(OUT).read() == text and open(INTEGRATION).read() == doc else 1)
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     open(OUT, "w").write(text)
-    print(f"wrote {OUT} ({text.count(chr(10))} lines)")
+    open(INTEGRATION, "w").write(doc)
+    print(f"wrote {OUT} ({text.count(chr(10))} lines); INTEGRATION.md: {len(h['functions'])} entry points")
 
 
 if __name__ == "__main__":

@@ -10,5 +10,6 @@ from .engine import (  # noqa: F401
     Engine, TgError, HEAD_FC5, HEAD_CONV, EVAL_RESNET, EVAL_DUMMY, EVAL_HASH, TG_MAX_MOVES,
     state_bytes, input_channels, policy_size, load_library, build_library, LIB_PATH,
     format_move, parse_move, format_tps, parse_tps, format_example, parse_example, read_examples, comm_unique_id, pit, tensor_shapes,
+    debug_switches, train_order,
 )
 from .player import Player  # noqa: E402,F401

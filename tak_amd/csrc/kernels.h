@@ -7,6 +7,11 @@
 
 namespace tg {
 
+// The ONE reader of the library's TG_* environment switches (engine.hip: the table of names is there, and tg_debug_switches lists
+// the ones that are on).  env_on: set to anything but "" or "0".  env_int: the value, 0 = off / unset.
+bool env_on(const char* name);
+int env_int(const char* name);
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): one `static LdsAttr` per launcher remembers the
 // largest size it has set on each device of the process, under a lock (engines on several devices, trainers on several host threads).
 struct LdsAttr {

@@ -275,7 +275,7 @@ int net_finalize(TgEngine* e) {
             auto wv = find(n, "value.weight", K, err);
             auto bv = wv ? find(n, "value.bias", 1, err) : nullptr;
             if (!bv) return fail(TG_ERR_WEIGHTS, err);
-            if (NP > P && !getenv("TG_SEPARATE_VALUE_HEAD")) {
+            if (NP > P && !env_on("TG_SEPARATE_VALUE_HEAD")) {
                 bp[P] = (*bv)[0];
                 for (int c = 0; c < F; c++)
                     for (int sq = 0; sq < nsq; sq++) {
@@ -315,14 +315,14 @@ int net_finalize(TgEngine* e) {
         TG_HIP(n->value_w.ensure(K * 4));
         TG_HIP(hipMemcpy(n->value_w.p, wv.data(), K * 4, hipMemcpyHostToDevice));
     }
-    n->fused = tower_supported(e->g.n, F, n->cin_pad) && 1 + 2 * R <= 48 && !getenv("TG_NO_FUSED_TOWER");
+    n->fused = tower_supported(e->g.n, F, n->cin_pad) && 1 + 2 * R <= 48 && !env_on("TG_NO_FUSED_TOWER");
     if (n->fused) {
         TowerParams& T = n->tower;
         T.nlayers = 1 + 2 * R; T.cin_pad = n->cin_pad; T.F = F;
         // layer 0: 72 of 80 (5×5) / 92 of 96 (6×6) input channels are real; with the last chunk permuted 2 of 20 / 1 of 24
         // MFMAs per tile and tap multiply padding only and are skipped — the towers get their own copy of the weights
         const int tail = n->cin - (n->cin_pad - 16);
-        T.cin_last_t = (tail > 0 && tail <= 12 && !getenv("TG_NO_CIN_PERM")) ? (tail + 3) / 4 : 4;
+        T.cin_last_t = (tail > 0 && tail <= 12 && !env_on("TG_NO_CIN_PERM")) ? (tail + 3) / 4 : 4;
         if (T.cin_last_t < 2) T.cin_last_t = 4;
         {
             Folded f0;
@@ -335,7 +335,7 @@ int net_finalize(TgEngine* e) {
         T.cb = 0; T.cb_cin_pad = 32; T.cb_last_t = 3; T.w0_board = nullptr; T.cplane_sums = nullptr;
         {
             const int N = e->g.n, bc = board_channels(N), nconst = n->cin - bc;
-            if (!getenv("TG_NO_CONST_BIAS") && bc > 16 && bc <= 28 && nconst > 0) {
+            if (!env_on("TG_NO_CONST_BIAS") && bc > 16 && bc <= 28 && nconst > 0) {
                 Folded f0, fb;
                 if (!fold_conv_bn(n, "conv0", "bn0", F, n->cin, f0, err)) return fail(TG_ERR_WEIGHTS, err);
                 fb.b = f0.b;
@@ -371,7 +371,7 @@ int net_finalize(TgEngine* e) {
         // FC-head networks whose value head rides in the FC's padding column: nothing but the policy FC reads the tower's
         // output, so it is written in the FC's fragment order
         T.frag_out = (e->cfg.policy_head == TG_HEAD_FC5 && n->value_in_fc && fc_frag_supported(nsq * F, n->policy_np) &&
-                      !getenv("TG_NO_FRAG_OUT")) ? 1 : 0;
+                      !env_on("TG_NO_FRAG_OUT")) ? 1 : 0;
         int pw, ps;
         if (tower_halo_geometry(e->g.n, F, &pw, &ps)) {
             std::vector<uint32_t> map((size_t)((pw * nsq + 15) / 16) * 16);
@@ -429,7 +429,7 @@ int net_finalize(TgEngine* e) {
         n->s3_fc_on = false;
         T.head_w = nullptr; T.head_b = nullptr; T.head_out = nullptr; T.head_cout = 0;
         n->s3_head_on = false;
-        if (e->cfg.policy_head == TG_HEAD_CONV && n->policy_conv.cout_pad % 32 == 0 && !getenv("TG_S3_NO_HEAD")) {
+        if (e->cfg.policy_head == TG_HEAD_CONV && n->policy_conv.cout_pad % 32 == 0 && !env_on("TG_S3_NO_HEAD")) {
             const int ch = P / nsq;
             if (!fold_conv_bn(n, "policy", "", ch, F, g, err)) return fail(TG_ERR_WEIGHTS, err);
             TG_HIP(upload_conv_s3(g, ch, F, F / 32, n->s3_head, n->policy_conv.cout_pad));
@@ -437,7 +437,7 @@ int net_finalize(TgEngine* e) {
             n->s3_head_on = true;
         }
         const int s3np = round_up(P, 112);  // column blocks of 112 outputs (k_fc_s3b); TG_S3_FC_WIDE=1 keeps the 208-wide kernel
-        n->s3_np = getenv("TG_S3_FC_WIDE") ? n->policy_np : s3np;
+        n->s3_np = env_on("TG_S3_FC_WIDE") ? n->policy_np : s3np;
         if (e->cfg.policy_head == TG_HEAD_FC5 && fc_s3_supported(F * nsq, n->s3_np)) {
             // Linear [P, F·nsq] → split bf16 fragments, k = sq·F + c (the order of the activations)
             const size_t K = (size_t)F * nsq;
@@ -515,7 +515,7 @@ int net_finalize(TgEngine* e) {
     const bool s3fc = n->s3 && n->s3_fc_on;
     // (one statistics geometry — softmax.cuh — on both precisions since round 4: the split-bf16 FC's ring kernel emits it from its
     // epilogue, k_fc_stats computes it behind k_fc_s3b for ≤ 512 rows)
-    n->fc_stats_on = e->cfg.policy_head == TG_HEAD_FC5 && n->value_in_fc && !getenv("TG_NO_FC_STATS") && e->policy_size + 1 <= FC_TILES * 16 &&
+    n->fc_stats_on = e->cfg.policy_head == TG_HEAD_FC5 && n->value_in_fc && !env_on("TG_NO_FC_STATS") && e->policy_size + 1 <= FC_TILES * 16 &&
                      (s3fc ? n->s3_np >= FC_TILES * 16 : fc_stats_supported(nsq * F, n->policy_np, n->policy_np));
     n->fc_stat_blocks = n->fc_stats_on ? FC_STAT_BLOCKS : 0;
     n->fc_stat_stride = n->fc_stats_on ? FC_STAT_STRIDE : 0;
@@ -562,9 +562,9 @@ const float* net_fc_stats(const TgEngine* e, int* blocks, int* stride) {
 bool net_gather_ok(const TgEngine* e, int leaves) {
     if (!net_ready(e)) return false;
     const Net* n = e->net;
-    static const bool off = getenv("TG_NO_FC_GATHER") != nullptr;  // A/B: logits rows + the backup's own gather (same bits)
+    static const bool off = env_on("TG_NO_FC_GATHER");  // A/B: logits rows + the backup's own gather (same bits)
     if (off || e->cfg.policy_head != TG_HEAD_FC5 || !n->fc_stats_on || !n->value_in_fc) return false;
-    if (n->s3) return n->s3_fc_on && n->s3_fc_ring_on && !getenv("TG_S3_NO_FC_RING") && fc_s3_ring_supported(leaves, e->g.nsq * n->F, e->policy_size + 1);
+    if (n->s3) return n->s3_fc_on && n->s3_fc_ring_on && !env_on("TG_S3_NO_FC_RING") && fc_s3_ring_supported(leaves, e->g.nsq * n->F, e->policy_size + 1);
     return fc_gather_supported(leaves, e->g.nsq * n->F, n->policy_np);
 }
 void net_set_gather(TgEngine* e, const FcGatherArgs* g) {
@@ -666,7 +666,7 @@ static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const ui
     } else {
         float* stats = n->fc_stats_on ? n->fc_stats.as<float>() + (size_t)pos0 * n->fc_stat_stride * 2 : nullptr;
         const bool gather = !d_policy && pos0 == 0 && n->gather_on && net_gather_ok(e, nb);
-        static const bool lin_src = getenv("TG_FC_PERMUTED_SRC") == nullptr;  // A/B: the ring's LDS-DMA reads the [chunk][column][q] layout (same bits)
+        static const bool lin_src = !env_on("TG_FC_PERMUTED_SRC");  // A/B: the ring's LDS-DMA reads the [chunk][column][q] layout (same bits)
         TG_HIP(launch_gemm(st, x, nsq * F, n->policy_w.as<float>(), n->policy_b.as<float>(), logits, nb, nsq * F, n->policy_np,
                            n->policy_np, e->policy_size + (n->value_in_fc ? 1 : 0), !n->s3 && n->fused && n->tower.frag_out,
                            stats, e->policy_size, gather ? &n->gather : nullptr, lin_src ? n->policy_w_lin.as<float>() : nullptr));

@@ -1543,7 +1543,7 @@ hipError_t launch_conv3x3(hipStream_t st, const float* in, const float* Wp, cons
     const int B = M / (n * n);
     if (stats_blocks) *stats_blocks = 0;
     {   // F → F (and F → 2F) layers of the BASELINE topologies at full batches: the halo image (k_conv_halo), same bits as k_conv_pos
-        static const bool off = getenv("TG_NO_HALO_CONV") != nullptr;
+        static const bool off = env_on("TG_NO_HALO_CONV");
         int pw, ps;
         if (!off && B >= 1024 && tower_halo_geometry(n, Cpad, &pw, &ps)) {
             const uint32_t* map = conv_halo_slotmap(n, Cpad, pw, ps);
@@ -1665,7 +1665,7 @@ static hipError_t launch_tower_halo_t(hipStream_t st, const float* in, const Tow
 // full batches of the three BASELINE topologies run on the halo image (identical bits, see k_tower_halo)
 template <bool FROM_STATES>
 static bool launch_tower_halo(hipStream_t st, const float* in, const TowerParams& T, float* out, int B, int n, hipError_t* err) {
-    static const bool off = getenv("TG_NO_HALO_TOWER") != nullptr;
+    static const bool off = env_on("TG_NO_HALO_TOWER");
     if (off || !T.slotmap) return false;
     if (FROM_STATES && T.cb) {  // layer 0 over the board planes, constant planes as a bias (CH0 = 2)
         if (n == 5 && T.F == 64 && B > 2048) { *err = launch_tower_halo_t<13, 8, 2, 4, 5, FROM_STATES, FROM_STATES>(st, in, T, out, B, 4); return true; }
@@ -1750,7 +1750,7 @@ hipError_t launch_tower_states(hipStream_t st, const uint8_t* states, const Towe
         if (B <= 512) return launch_tower_t<4, 4, 5, 4, true>(st, in, T, out, B, n, 2, 4);
         if (B <= 1024) return launch_tower_t<7, 4, 5, 4, true>(st, in, T, out, B, n, 4, 4);
         if (B <= 2048) return launch_tower_t<13, 4, 5, 4, true>(st, in, T, out, B, n, 8, 4);
-        static const int variant = getenv("TG_TOWER_VARIANT") ? atoi(getenv("TG_TOWER_VARIANT")) : 0;
+        static const int variant = env_int("TG_TOWER_VARIANT");
         if (variant == 16) return launch_tower_t<7, 16, 5, 4, true>(st, in, T, out, B, n, 16, 4);
         if (variant == 4) return launch_tower_t<25, 4, 5, 4, true>(st, in, T, out, B, n, 16, 4);
         return launch_tower_t<13, 8, 5, 4, true>(st, in, T, out, B, n, 16, 4);
@@ -1802,7 +1802,7 @@ hipError_t launch_gemm(hipStream_t st, const float* A, int lda, const float* Wp,
     }
     // Round 4: plain row-major GEMMs whose 25x output tiles split into 2x blocks of 12 + x leftover tiles take the ring too — the FC
     // head's data gradient in the training step (dlogits[4000 × 1600] · Wᵀ → 3200 columns = 200 tiles): 465 µs in k_gemm below
-    static const bool ring_gemm = getenv("TG_NO_RING_GEMM") == nullptr;
+    static const bool ring_gemm = !env_on("TG_NO_RING_GEMM");
     if (ring_gemm && K % FC_KSTEP == 0 && NP % 400 == 0 && M > FC_SMALL_ROWS && !a_frag && !stats && !gather) {
         static LdsAttr lds_attr;
         if (hipError_t e = lds_attr.ensure((const void*)k_fc_ring<1>, FC_RING_LDS); e != hipSuccess) return e;

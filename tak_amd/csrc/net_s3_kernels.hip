@@ -1316,7 +1316,7 @@ bool tower_s3_supported(int n, int F) { return (n == 5 && (F == 64 || F == 128))
 
 template <bool FROM_STATES, bool OUT_SPLIT>
 static hipError_t launch_s3(hipStream_t st, const void* in, const TowerS3Params& T, float* out, int B, int n) {
-    static const bool no_halo = getenv("TG_NO_HALO_TOWER") != nullptr;
+    static const bool no_halo = env_on("TG_NO_HALO_TOWER");
     if (FROM_STATES && T.cb) {  // layer 0 over one chunk of board planes, constant planes as a bias (KC0 = 1): the same tilings
         if (T.slotmap && !no_halo && B >= 256) {
             if (n == 5 && T.F == 64) return launch_s3_halo_t<7, 1, 2, 5, FROM_STATES, OUT_SPLIT, 4, FROM_STATES>(st, in, T, out, B, 8, 2);
@@ -1335,7 +1335,7 @@ static hipError_t launch_s3(hipStream_t st, const void* in, const TowerS3Params&
     }
     // 5×5, F = 64: 8 positions = 13 row tiles = 2 row groups (7,6) × 2 channel groups, 4 waves, two workgroups per CU
     if (n == 5 && T.F == 64) {
-        static const bool wide = getenv("TG_S3_WIDE") != nullptr;  // A/B switch: one 8-wave workgroup of 16 positions per CU
+        static const bool wide = env_on("TG_S3_WIDE");  // A/B switch: one 8-wave workgroup of 16 positions per CU
         if (wide) return launch_s3_t<7, 3, 2, FROM_STATES, OUT_SPLIT, 8>(st, in, T, out, B, n, 16, 2);
         return launch_s3_t<7, 3, 2, FROM_STATES, OUT_SPLIT, 4>(st, in, T, out, B, n, 8, 2);
     }
@@ -1360,7 +1360,7 @@ bool fc_s3_ring_supported(int M, int K, int n_valid) { return K % 64 == 0 && n_v
 hipError_t launch_fc_s3(hipStream_t st, const float* act_split, const void* Wp, const void* Wr, const float* bias, float* out, int M, int K, int NP,
                         int out_stride, int n_valid, float* stats, int n_soft, const FcGatherArgs* gather) {
     if (stats && (n_valid > FC_TILES * 16 || out_stride < FC_TILES * 16)) return hipErrorInvalidValue;
-    static const bool no_ring = getenv("TG_S3_NO_FC_RING") != nullptr;  // A/B: k_fc_s3b at every batch (same bits)
+    static const bool no_ring = env_on("TG_S3_NO_FC_RING");  // A/B: k_fc_s3b at every batch (same bits)
     if (Wr && !no_ring && fc_s3_ring_supported(M, K, n_valid)) {
         static LdsAttr lds_attr;
         if (hipError_t e = lds_attr.ensure((const void*)k_fc_s3_ring, FSR_LDS); e != hipSuccess) return e;

@@ -251,7 +251,7 @@ static void bind_logits(TgEngine* e) {
     s->d.fc_stride = 0;
     s->d.child_logit = nullptr;
     net_set_gather(e, nullptr);
-    static const bool off = getenv("TG_DUAL_STREAM") != nullptr || getenv("TG_NO_FUSED_SOFTMAX") != nullptr;
+    static const bool off = env_on("TG_DUAL_STREAM") || env_on("TG_NO_FUSED_SOFTMAX");
     if (off || e->cfg.evaluator != TG_EVAL_RESNET) return;
     int ld = 0;
     const float* lg = net_fc_logits(e, &ld);
@@ -320,7 +320,7 @@ static SearchDev half_view(const SearchDev& d, int g0, int count, size_t state_b
 static bool dual_stream_ok(TgEngine* e) {
     // measured on MI355X at C2: no gain (exact f32 4.06 M vs 4.11 M expansions/s single-stream, bf16x3 11.8 M vs 12.4 M) —
     // the half-batch MFMA kernels fill the chip less well than they overlap; kept opt-in
-    static const bool on = getenv("TG_DUAL_STREAM") != nullptr;
+    static const bool on = env_on("TG_DUAL_STREAM");
     Search* s = e->search;
     return on && s->d.batch == 1 && e->cfg.evaluator == TG_EVAL_RESNET && !s->d.planes && net_takes_states(e) && s->d.G >= 512;
 }
@@ -331,7 +331,7 @@ static int search_iterate_many(TgEngine* e, int iters) {
     bind_logits(e);
     GatherScope scope{e};
     if (!dual_stream_ok(e)) {
-        if (s->d.batch == 1 && iters > 1 && !getenv("TG_NO_FUSED_BACKUP_SELECT")) {
+        if (s->d.batch == 1 && iters > 1 && !env_on("TG_NO_FUSED_BACKUP_SELECT")) {
             // select(0) | net | backup(0)+select(1) | net | … | backup(iters-1): one tree kernel per iteration
             SearchDev d = s->d;
             d.pass = 0;

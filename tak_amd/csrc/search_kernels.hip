@@ -999,7 +999,7 @@ __global__ void k_sp_count_ply(SelfPlayDev P) { P.stats[ST_PLIES] += 1; }
 static inline dim3 wgrid(int G) { return dim3((G + WPB - 1) / WPB); }
 
 // the tree kernels are compiled for the board sizes of the BASELINE configs (n as a constant) and once for any size
-static const bool g_runtime_n = getenv("TG_RUNTIME_N") != nullptr;  // A/B: the generic instantiation for every size (same results)
+static const bool g_runtime_n = env_on("TG_RUNTIME_N");  // A/B: the generic instantiation for every size (same results)
 #define TG_BY_BOARD(KERNEL, ...)                                                                          \
     do {                                                                                                  \
         if (S.n == 5 && !g_runtime_n) hipLaunchKernelGGL(KERNEL<5>, wgrid(S.G), dim3(WPB * 64), 0, st, __VA_ARGS__);      \

@@ -12,6 +12,7 @@
 // on a second one beside it, the next chunk's examples on a copy stream (tg_train).
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <numeric>
@@ -27,8 +28,6 @@ struct Id128 { char bytes[128]; };  // ncclUniqueId
 namespace {
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
-// A/B switches: set and not "0"
-bool env_on(const char* name) { const char* v = getenv(name); return v && atoi(v) != 0; }
 
 struct ParamInfo {
     std::string name;
@@ -168,23 +167,27 @@ struct Trainer {
     int world = 1, rank = 0;
     TgAllReduceFn hook = nullptr;
     void* hook_ctx = nullptr;
-    // gradient all-reduces timed with HIP events on the engine stream (tg_train_comm_stats): ONE event pair, created at the first
-    // reduction and re-recorded by every step; the previous step's elapsed time is folded into ar_ms before the pair is reused
-    hipEvent_t ar_ev[2] = {nullptr, nullptr};
-    bool ar_pending = false;
+    // gradient all-reduces timed with HIP events on the engine stream (tg_train_comm_stats): TWO event pairs used in turn.  tg_train
+    // enqueues chunk k + 1 — with its optimiser step, if one falls due — before it collects chunk k, so with chunks_in_step = 1 the
+    // previous step's pair is still running when the next step is issued; the pair before THAT belongs to a chunk that has been
+    // collected (its `done` event stands behind the step), so folding it never blocks the host and no step is dropped from the count.
+    hipEvent_t ar_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    bool ar_pending[2] = {false, false};
+    int ar_next = 0;
     double ar_ms = 0.0;
     int64_t ar_count = 0;
-    // wait = false (between two steps): never blocks the host — a pair that has not completed yet is dropped from the statistics
-    void ar_fold(bool wait = false) {
-        if (!ar_pending) return;
+    void ar_fold(int pair) {
+        if (!ar_pending[pair]) return;
         float ms = 0.0f;
-        const bool done = wait ? hipEventSynchronize(ar_ev[1]) == hipSuccess : hipEventQuery(ar_ev[1]) == hipSuccess;
-        if (done && hipEventElapsedTime(&ms, ar_ev[0], ar_ev[1]) == hipSuccess) { ar_ms += ms; ar_count++; }
-        ar_pending = false;
+        if (hipEventSynchronize(ar_ev[pair][1]) == hipSuccess && hipEventElapsedTime(&ms, ar_ev[pair][0], ar_ev[pair][1]) == hipSuccess) {
+            ar_ms += ms;
+            ar_count++;
+        }
+        ar_pending[pair] = false;
     }
     DevBuf err_flag;  // one float: the ranks agree on an argument error before the first chunk of tg_train
     ~Trainer() {
-        for (hipEvent_t ev : ar_ev) if (ev) (void)hipEventDestroy(ev);
+        for (auto& pair : ar_ev) for (hipEvent_t ev : pair) if (ev) (void)hipEventDestroy(ev);
         if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
     }
 };
@@ -423,16 +426,20 @@ int optimizer_step(TgEngine* e, hipStream_t st) {
     {
         bool reduced;
         const bool timed = t->hook || t->comm;
+        const int pair = t->ar_next;
         if (timed) {
-            t->ar_fold();  // the previous step's pair, if it has completed (a whole step of chunks lies between)
-            if (!t->ar_ev[0]) {
-                TG_HIP(hipEventCreate(&t->ar_ev[0]));
-                TG_HIP(hipEventCreate(&t->ar_ev[1]));
+            t->ar_fold(pair);  // the step before the previous one: its chunk has been collected, the events are complete
+            if (!t->ar_ev[pair][0]) {
+                TG_HIP(hipEventCreate(&t->ar_ev[pair][0]));
+                TG_HIP(hipEventCreate(&t->ar_ev[pair][1]));
             }
-            TG_HIP(hipEventRecord(t->ar_ev[0], st));
+            TG_HIP(hipEventRecord(t->ar_ev[pair][0], st));
         }
         int rc = all_reduce_sum(e, st, t->grads.as<float>(), t->n_params, "gradients", &reduced);
-        if (timed) t->ar_pending = hipEventRecord(t->ar_ev[1], st) == hipSuccess;
+        if (timed) {
+            t->ar_pending[pair] = hipEventRecord(t->ar_ev[pair][1], st) == hipSuccess;
+            t->ar_next = pair ^ 1;
+        }
         if (rc) return rc;
         if (reduced) gscale = 1.0f / (float)t->world;
     }
@@ -556,6 +563,17 @@ int upload_chunk(TgEngine* e, Chunk& w, int slot, int n, const uint8_t* states, 
     TG_HIP(hipMemcpyAsync(x.zt.p, x.h_z8.data(), x.h_z8.size() * 4, hipMemcpyHostToDevice, up));
     TG_HIP(hipEventRecord(x.uploaded, up));
     return TG_OK;
+}
+
+// refs.shuffle (network.rs:49-50): Fisher–Yates driven by Philox(seed; i)
+void shuffle_order(uint64_t seed, int n, int* order) {
+    std::iota(order, order + n, 0);
+    for (int i = n - 1; i > 0; i--) {
+        U4 r = philox4x32_10(seed, (uint32_t)i, 0x7261696eu, 0, 0);
+        uint64_t x = ((uint64_t)r.v[0] << 32) | r.v[1];
+        int j = (int)(((unsigned __int128)x * (unsigned __int128)(i + 1)) >> 64);
+        std::swap(order[i], order[j]);
+    }
 }
 
 }  // namespace
@@ -741,8 +759,12 @@ int tg_train_chunk(TgEngine* e, int n, const void* states, const int32_t* n_move
         return rc;
     }
     rc = chunk_collect(e, w, 0, loss_p, loss_z, stepped);
-    if (rc == TG_OK) TG_HIP(hipStreamSynchronize(w.st));  // (tg_train_chunk returns with the engine stream idle, as it always did)
-    return rc;
+    if (rc) {  // the chunk (and an optimiser step that fell due) may still be running on both streams: nothing is left behind
+        chunk_drain(e->trainer);
+        return rc;
+    }
+    TG_HIP(hipStreamSynchronize(w.st));  // (tg_train_chunk returns with the engine stream idle, as it always did)
+    return TG_OK;
 }
 
 int tg_train(TgEngine* e, int n, const void* states, const int32_t* n_moves, const TgMove* moves, const uint32_t* visits,
@@ -778,15 +800,8 @@ int tg_train(TgEngine* e, int n, const void* states, const int32_t* n_moves, con
     TG_HIP(hipMemsetAsync(t->adam_v.p, 0, t->n_params * 4, e->stream));
     t->adam_t = 0;
     t->chunk_num = 0;
-    // refs.shuffle (network.rs:49-50): Fisher–Yates driven by Philox(seed; i)
     std::vector<int> order(n);
-    std::iota(order.begin(), order.end(), 0);
-    for (int i = n - 1; i > 0; i--) {
-        U4 r = philox4x32_10(seed, (uint32_t)i, 0x7261696eu, 0, 0);
-        uint64_t x = ((uint64_t)r.v[0] << 32) | r.v[1];
-        int j = (int)(((unsigned __int128)x * (unsigned __int128)(i + 1)) >> 64);
-        std::swap(order[i], order[j]);
-    }
+    shuffle_order(seed, n, order.data());
     const int cs = t->cfg.chunk_size;
     double sp = 0.0, sz = 0.0;
     int chunks = 0, nsteps = 0;
@@ -817,6 +832,12 @@ int tg_train(TgEngine* e, int n, const void* states, const int32_t* n_moves, con
     if (mean_loss_p) *mean_loss_p = chunks ? (float)(sp / chunks) : 0.0f;
     if (mean_loss_z) *mean_loss_z = chunks ? (float)(sz / chunks) : 0.0f;
     if (steps) *steps = nsteps;
+    return TG_OK;
+}
+
+int tg_train_order(uint64_t seed, int n, int32_t* order) {
+    if (n < 0 || (n > 0 && !order)) return fail(TG_ERR_INVALID_ARG, "tg_train_order: bad arguments");
+    shuffle_order(seed, n, order);
     return TG_OK;
 }
 
@@ -963,7 +984,8 @@ int tg_train_comm_stats(TgEngine* e, double* ms_total, int64_t* reductions) {
     if (rc) return rc;
     Trainer* t = e->trainer;
     TG_HIP(hipStreamSynchronize(e->stream));
-    t->ar_fold(true);
+    t->ar_fold(t->ar_next);  // the older pair first
+    t->ar_fold(t->ar_next ^ 1);
     if (ms_total) *ms_total = t->ar_ms;
     if (reductions) *reductions = t->ar_count;
     return TG_OK;
@@ -991,6 +1013,30 @@ int tg_train_comm_info(TgEngine* e, TgCommInfo* out) {
         v = -1;
         if (g_rccl.CommUserRank && g_rccl.CommUserRank(t->comm, &v) == 0) out->nccl_rank = v;
     }
+    return TG_OK;
+}
+
+int tg_train_comm_preflight(TgEngine* e, double* ms) {
+    int rc = need_trainer(e);
+    if (rc) return rc;
+    Trainer* t = e->trainer;
+    if (ms) *ms = 0.0;
+    if (!t->hook && !t->comm) return TG_OK;
+    TG_HIP(t->err_flag.ensure(16));
+    const float one[4] = {1.0f, 0.0f, 0.0f, 0.0f};
+    float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    TG_HIP(hipStreamSynchronize(e->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    TG_HIP(hipMemcpyAsync(t->err_flag.p, one, 16, hipMemcpyHostToDevice, e->stream));
+    bool reduced;
+    rc = all_reduce_sum(e, e->stream, t->err_flag.as<float>(), 1, "preflight", &reduced);
+    if (rc) return rc;
+    TG_HIP(hipMemcpyAsync(sum, t->err_flag.p, 16, hipMemcpyDeviceToHost, e->stream));
+    TG_HIP(hipStreamSynchronize(e->stream));
+    if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (sum[0] != (float)t->world)
+        return fail(TG_ERR_STATE, "tg_train_comm_preflight: the sum of one 1.0f per rank is " + std::to_string(sum[0]) + ", expected " +
+                                      std::to_string(t->world) + " — the reduction does not span the ranks it was set up for");
     return TG_OK;
 }
 

@@ -922,7 +922,7 @@ static void wgrad_plan_conv(int B, int nsq, int ntiles, int* pw, int* cps, int* 
     // = 25 rows padded to 28 wasted 11 % of the MFMAs and paid a pair of barriers every 7 k-steps: 23.2 → 22.4 ms per chunk of the
     // C5 network); 4 positions = 100 rows need PF = 7, which leaves one wave per SIMD (112 + 144 registers) and is no faster
     // (23.2 ms).  TG_WGRAD_PW overrides (A/B).
-    static const int forced = getenv("TG_WGRAD_PW") ? atoi(getenv("TG_WGRAD_PW")) : 0;
+    static const int forced = env_int("TG_WGRAD_PW");
     *pw = forced > 0 ? forced : 64 / nsq;
     if (*pw * nsq > 112) *pw = 112 / nsq;
     if (*pw < 1) *pw = 1;
@@ -946,7 +946,7 @@ hipError_t launch_wgrad_conv(hipStream_t st, const float* X, int xs, int I, cons
     size_t lds = ((size_t)(rows_chunk + 1) * 17 + (size_t)rows_pad * 17) * 16 + (size_t)rows_pad * 4;
     const int xvalid = xs < ncib * 64 ? xs : ncib * 64;  // columns that exist in memory
     const int gvalid = gs < ncob * 64 ? gs : ncob * 64;
-    static const bool no_halo = getenv("TG_NO_HALO_WGRAD") != nullptr || getenv("TG_WGRAD_PW") != nullptr;
+    static const bool no_halo = env_on("TG_NO_HALO_WGRAD") || env_int("TG_WGRAD_PW") != 0;
     if (!no_halo && n == 5 && pw == 2) {
         constexpr size_t hl = ((size_t)(5 + 2 + 2 * 36 + 1) * 16 + 52 * 17) * 16;
         hipLaunchKernelGGL((k_wgrad_halo<5, 2>), dim3(splits, ncib * ncob), dim3(256), hl, st, X, xs, xvalid, G, gs, gvalid, B * nsq, cps, ncob, part);

@@ -63,6 +63,64 @@ def reduce_min(dist, value, device="cpu"):
     return t.item()
 
 
+def gather(dist, obj):
+    """[obj of rank 0, obj of rank 1, …] on every rank (all_gather_object; a one-element list without a process group)"""
+    if dist is None:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def device_record(rank, engine=None):
+    """what one rank reports about the card it sits on (config.devices of the bench line): the engine's own view through
+    tg_device_info — HIP ordinal, PCI bus id, name, CU count — plus host and pid; without an engine (launcher rehearsals on a
+    machine without a GPU) the device fields are None"""
+    import socket
+
+    rec = {"rank": rank, "hip_device": None, "pci_bus_id": None, "name": None, "cu_count": None, "host": socket.gethostname(), "pid": os.getpid()}
+    if engine is not None:
+        info = engine.device_info()
+        rec.update({k: info[k] for k in ("hip_device", "pci_bus_id", "name", "cu_count")})
+        rec["arch"] = info["arch"]
+    return rec
+
+
+def devices_distinct(records):
+    """True when no two ranks of one host report the same PCI bus id (ranks without a device record — rehearsals — count as distinct)"""
+    seen = set()
+    for r in records:
+        if r.get("pci_bus_id") is None:
+            continue
+        key = (r.get("host"), r["pci_bus_id"])
+        if key in seen:
+            return False
+        seen.add(key)
+    return True
+
+
+def check_devices(records, backend):
+    """One rank per GPU is the launch contract (reference train/src/self_play.rs:98,102-104: one shard per process): under the RCCL
+    backend two ranks on one card are an error — `ranks_reporting` alone cannot show it, the whole-job figure would count one
+    card twice.  Under gloo (several ranks share a card on purpose: one-GPU rehearsals) the line just says devices_distinct = false."""
+    distinct = devices_distinct(records)
+    if backend == "nccl" and not distinct:
+        by = {}
+        for r in records:
+            by.setdefault((r.get("host"), r.get("pci_bus_id")), []).append(r["rank"])
+        shared = {f"{k[1]}": v for k, v in by.items() if len(v) > 1}
+        raise RuntimeError(f"ranks share a GPU under the RCCL backend: {shared} (PCI bus id → ranks); check HIP_VISIBLE_DEVICES / LOCAL_RANK")
+    return distinct
+
+
+def per_rank_times(dist, seconds, scale=1000.0):
+    """every rank's own time beside the max the headline is computed from: a straggler is otherwise invisible under the
+    max-reduce → {"all": [ms of rank 0, …], "min", "max", "fastest_rank", "slowest_rank"}"""
+    all_ms = [scale * float(t) for t in gather(dist, float(seconds))]
+    lo, hi = min(all_ms), max(all_ms)
+    return {"all": all_ms, "min": lo, "max": hi, "fastest_rank": all_ms.index(lo), "slowest_rank": all_ms.index(hi)}
+
+
 class Stages:
     """Rank-local pieces of work in front of a collective.  `run(name, fn)` executes fn on this rank, then all ranks agree
     (one MIN all-reduce of an ok flag — which is also the barrier in front of the next piece): the rank that failed re-raises its

@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TAKGPU_LIB") or os.path.join(_HERE, "libtakgpu.so")  # TAKGPU_LIB: probe builds (scripts/probes)
 
-TG_ABI_VERSION = 4
+TG_ABI_VERSION = 5
 TG_MAX_MOVES = 512
 HEAD_FC5, HEAD_CONV = 0, 1
 EVAL_RESNET, EVAL_DUMMY, EVAL_HASH = 0, 1, 2
@@ -93,9 +93,19 @@ class TgCommInfo(C.Structure):
         return d
 
 
+class TgDeviceInfo(C.Structure):
+    _fields_ = [("hip_device", C.c_int32), ("cu_count", C.c_int32), ("clock_khz", C.c_int32), ("reserved", C.c_int32),
+                ("total_mem", C.c_uint64), ("pci_bus_id", C.c_char * 32), ("name", C.c_char * 128), ("arch", C.c_char * 64)]
+
+    def as_dict(self):
+        return {"hip_device": int(self.hip_device), "pci_bus_id": self.pci_bus_id.decode(errors="replace"),
+                "name": self.name.decode(errors="replace"), "arch": self.arch.decode(errors="replace"),
+                "cu_count": int(self.cu_count), "clock_khz": int(self.clock_khz), "total_mem": int(self.total_mem)}
+
+
 # every symbol include/takgpu.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
-    "tg_state_bytes", "tg_engine_create", "tg_engine_destroy", "tg_last_error", "tg_sync", "tg_stream",
+    "tg_state_bytes", "tg_engine_create", "tg_engine_destroy", "tg_last_error", "tg_sync", "tg_stream", "tg_device_info", "tg_debug_switches",
     "tg_input_channels", "tg_policy_size", "tg_movegen", "tg_play", "tg_result", "tg_encode", "tg_move_index",
     "tg_perft", "tg_net_set_tensor", "tg_net_init_random", "tg_net_get_tensor", "tg_net_finalize", "tg_net_set_precision", "tg_policy_eval", "tg_forward_mcts", "tg_policy_eval_dev",
     "tg_search_create", "tg_search_reset", "tg_search_run", "tg_search_apply_dirichlet", "tg_search_apply_noise",
@@ -105,7 +115,7 @@ ABI_SYMBOLS = [
     "tg_augment_examples",
     "tg_train_create", "tg_train_chunk", "tg_train", "tg_train_step", "tg_train_forward", "tg_train_get_tensor",
     "tg_train_get_grad", "tg_train_debug_capture", "tg_train_debug_read", "tg_train_commit", "tg_comm_unique_id", "tg_train_comm_init", "tg_train_set_allreduce",
-    "tg_train_grad_buffer", "tg_train_comm_stats", "tg_train_comm_info", "tg_pit",
+    "tg_train_grad_buffer", "tg_train_comm_stats", "tg_train_comm_info", "tg_train_comm_preflight", "tg_train_order", "tg_pit",
     "tg_format_move", "tg_parse_move", "tg_format_tps", "tg_parse_tps", "tg_format_example", "tg_parse_example",
 ]
 
@@ -259,6 +269,23 @@ def comm_unique_id():
     return uid.tobytes()
 
 
+def debug_switches():
+    """the TG_* A/B switches that are ON in this process's environment, as the library reads them → ["NAME=value", …];
+    [] on a measured run (tg_debug_switches; needs no GPU)"""
+    buf = C.create_string_buffer(4096)
+    n = load_library().tg_debug_switches(buf, C.c_size_t(4096))
+    out = buf.value.decode().split()
+    assert n == len(out), (n, out)
+    return out
+
+
+def train_order(seed, n):
+    """the permutation tg_train(seed) visits n examples in (tg_train_order)"""
+    order = np.zeros(n, np.int32)
+    _text_check(load_library().tg_train_order(C.c_uint64(seed), n, _p(order)))
+    return order
+
+
 def pit(new, old, pairs=128, rollouts=50, batch=16, idle_rollouts=1, random_plies=2, komi=2, max_plies=0, arena_nodes=0, seed=0):
     """`pit(new, old)` of train/src/pit.rs on two engines (one per weight set) → dict(wins, losses, draws, win_rate, …; the
     ref_* entries are the counts with the reference's early exit, pit.rs:20-23, applied);
@@ -320,6 +347,12 @@ class Engine:
         self.cin = input_channels(board_size)
         self.psize = policy_size(board_size, policy_head)
         self.games = 0
+
+    def device_info(self):
+        """the card this engine runs on as the HIP runtime names it: {hip_device, pci_bus_id, name, arch, cu_count, …}"""
+        info = TgDeviceInfo()
+        self._check(self.lib.tg_device_info(self.h, C.byref(info)))
+        return info.as_dict()
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
@@ -497,6 +530,13 @@ class Engine:
         info = TgCommInfo()
         self._check(self.lib.tg_train_comm_info(self.h, C.byref(info)))
         return info.as_dict()
+
+    def train_comm_preflight(self):
+        """one float summed over the ranks through the optimiser step's reduction, before any training work is enqueued →
+        wall-clock milliseconds of the round trip (0.0 on a single-rank trainer); raises if the sum is not world_size"""
+        ms = C.c_double(0)
+        self._check(self.lib.tg_train_comm_preflight(self.h, C.byref(ms)))
+        return ms.value
 
     def train_comm_init(self, rank, world, unique_id):
         uid = np.frombuffer(bytes(unique_id), np.uint8).copy()

@@ -30,6 +30,62 @@ def test_exports_every_declared_symbol(lib):
     assert declared == set(ABI_SYMBOLS)
 
 
+def test_the_library_exports_the_c_abi_and_nothing_else(lib):
+    """-fvisibility=hidden + the linker's version script (tak_amd/csrc/exports.map): `nm -D` shows the header's entry points, no tg::
+    C++ symbol, no kernel handle, no std:: instantiation"""
+    import tak_amd
+    from tak_amd.engine import ABI_SYMBOLS
+
+    out = subprocess.run(["nm", "-D", "--defined-only", tak_amd.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    defined = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert defined == set(ABI_SYMBOLS), sorted(defined ^ set(ABI_SYMBOLS))[:10]
+
+
+def _csrc_sources():
+    d = os.path.join(ROOT, "tak_amd", "csrc")
+    return {f: open(os.path.join(d, f)).read() for f in sorted(os.listdir(d)) if f.endswith((".hip", ".h", ".cuh"))}
+
+
+def test_every_switch_goes_through_the_one_reader_and_is_in_the_table(lib, monkeypatch):
+    """A/B switches: nothing in csrc calls getenv but env_on / env_int (engine.hip), every call site names an entry of the table
+    tg_debug_switches walks, and `=0` / an empty value leave a switch off"""
+    import tak_amd
+
+    src = _csrc_sources()
+    table = set(re.findall(r'"(TG_[A-Z0-9_]+)"', src["engine.hip"].split("k_switch_names[] = {")[1].split("};")[0]))
+    used = set()
+    for f, text in src.items():
+        code = re.sub(r"//[^\n]*", "", text)
+        if f != "engine.hip":
+            assert "getenv" not in code, f"{f} reads the environment itself"
+        used |= set(re.findall(r'env_(?:on|int)\("(TG_[A-Z0-9_]+)"\)', code))
+    assert len(table) >= 20 and used == table, sorted(used ^ table)
+    for name in table:
+        monkeypatch.delenv(name, raising=False)
+    assert tak_amd.debug_switches() == []
+    monkeypatch.setenv("TG_NO_HALO_TOWER", "0")
+    monkeypatch.setenv("TG_NO_FC_GATHER", "")
+    monkeypatch.setenv("TG_WGRAD_PW", "0")
+    assert tak_amd.debug_switches() == []
+    monkeypatch.setenv("TG_NO_HALO_TOWER", "1")
+    monkeypatch.setenv("TG_WGRAD_PW", "2")
+    assert sorted(tak_amd.debug_switches()) == ["TG_NO_HALO_TOWER=1", "TG_WGRAD_PW=2"]
+    # DESIGN.md documents every switch of the table
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    assert not [n for n in table if n not in design], [n for n in table if n not in design]
+
+
+def test_train_order_is_a_permutation_and_stable():
+    import numpy as np
+
+    import tak_amd
+
+    a, b = tak_amd.train_order(7, 1000), tak_amd.train_order(7, 1000)
+    assert np.array_equal(a, b) and np.array_equal(np.sort(a), np.arange(1000))
+    assert not np.array_equal(a, tak_amd.train_order(8, 1000))
+    assert tak_amd.train_order(1, 0).size == 0
+
+
 def test_sizes(lib):
     import tak_amd
 

@@ -77,6 +77,40 @@ def test_eight_ranks_at_the_real_fan_out():
     assert out["n_gpus"] == 8 and out["max_over_ranks"] == 8.0 and out["sum_over_ranks"] == 36
     # the line explains itself on the day the scaling runs happen: who contributed, and the per-GPU figure beside the whole-job one
     assert out["ranks_reporting"] == 8 and "per_gpu_value" in out
+    # round 6 — who sat where, every rank's own time, the reduction preflight, the A/B switches in effect: gathered over the 8 ranks
+    dev = out["config"]["devices"]
+    assert [d["rank"] for d in dev] == list(range(8)) and len({d["pid"] for d in dev}) == 8
+    assert all(set(d) >= {"rank", "hip_device", "pci_bus_id", "name", "cu_count", "host", "pid"} for d in dev)
+    assert out["config"]["devices_distinct"] is True and out["config"]["switches_set"] == []
+    by = out["ms_per_step_by_rank"]
+    assert by["all"] == [1000.0 * (1 + r) for r in range(8)] and by["slowest_rank"] == 7 and by["fastest_rank"] == 0 and by["max"] == 8000.0
+    pf = out["preflight_ms_by_rank"]
+    assert len(pf["all"]) == 8 and pf["max"] >= pf["min"] >= 0.0
+
+
+def test_a_switch_in_one_ranks_environment_shows_in_the_line():
+    env = dict(_clean_env(), TG_NO_HALO_TOWER="1", TG_NO_FC_GATHER="0")
+    p = subprocess.run([sys.executable, BENCH, "--rehearse-launch", "--gpus", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    out = json.loads([l for l in p.stdout.decode().splitlines() if l.strip()][0])
+    assert out["config"]["switches_set"] == ["TG_NO_HALO_TOWER=1"]  # `=0` is off and is not listed
+
+
+def test_two_ranks_on_one_card_are_refused_under_rccl():
+    from tak_amd import dist as tdist
+
+    def rec(rank, bus, host="box"):
+        return {"rank": rank, "hip_device": rank, "pci_bus_id": bus, "name": "AMD Instinct MI355X", "cu_count": 256, "host": host, "pid": 100 + rank}
+
+    eight = [rec(r, f"0000:{0x05 + 0x10 * r:02x}:00.0") for r in range(8)]
+    assert tdist.check_devices(eight, "nccl") is True
+    shared = eight[:6] + [rec(6, eight[2]["pci_bus_id"]), eight[7]]
+    with pytest.raises(RuntimeError, match=r"ranks share a GPU.*\[2, 6\]"):
+        tdist.check_devices(shared, "nccl")
+    assert tdist.check_devices(shared, "gloo") is False  # several ranks on one card on purpose: reported, not refused
+    # the same bus id on two HOSTS is two cards
+    assert tdist.check_devices([rec(0, "0000:05:00.0", "a"), rec(1, "0000:05:00.0", "b")], "nccl") is True
+    assert tdist.per_rank_times(None, 0.25) == {"all": [250.0], "min": 250.0, "max": 250.0, "fastest_rank": 0, "slowest_rank": 0}
 
 
 @pytest.mark.parametrize("world", [2, 8])
@@ -94,6 +128,7 @@ def test_a_hung_collective_ends_non_zero_with_the_headline_printed(world):
     assert len(lines) == 1, lines
     out = json.loads(lines[0])
     assert out["train_c5_failed"] is True and "timed out" in out["extra"]["train_c5"]["error"] and out["n_gpus"] == world
+    assert out["extra"]["train_c5"]["stage"] == "rehearsed collective"  # the line names the stage the phase hung in
     assert "did not finish within 8 s" in err
 
 

@@ -158,6 +158,17 @@ def test_bench_gpus_2_runs_unaided_on_one_card():
     assert c5["n_gpus"] == 2 and c5["optimizer_steps"] == 2 and c5["parameters_identical_on_all_ranks"] is True
     assert c5["gradient_allreduce"]["count"] == 2 and c5["gradient_allreduce"]["ms_per_step_rank0"] > 0
     assert c5["value"] > 0 and c5["selfplay_c5net"]["value"] > 0
+    # round 6: the line proves where the ranks sat and how each of them fared — here both on the one card (gloo: reported, not refused)
+    dev = out["config"]["devices"]
+    assert [d["rank"] for d in dev] == [0, 1] and dev[0]["pci_bus_id"] == dev[1]["pci_bus_id"] and len(dev[0]["pci_bus_id"]) >= 7
+    assert all(d["cu_count"] == 256 and d["name"] and d["arch"].startswith("gfx950") and d["hip_device"] == 0 for d in dev)
+    assert dev[0]["pid"] != dev[1]["pid"]
+    assert out["config"]["devices_distinct"] is False and out["config"]["backend"] == "gloo" and out["config"]["switches_set"] == []
+    by = out["ms_per_step_by_rank"]
+    assert len(by["all"]) == 2 and abs(by["max"] - out["ms_per_step"]) < 1e-6 and by["min"] > 0
+    pf = c5["gradient_allreduce"]["preflight_ms_by_rank"]
+    assert len(pf["all"]) == 2 and pf["min"] > 0 and c5["gradient_allreduce"]["preflight_ms"] == pf["max"]
+    assert len(c5["ms_per_optimizer_step_by_rank"]["all"]) == 2 and len(c5["selfplay_c5net"]["ms_per_step_by_rank"]["all"]) == 2
 
 
 def test_bench_gpus_4_runs_unaided_on_one_card():
@@ -199,6 +210,7 @@ e.train_create(learning_rate=1e-3, chunk_size=8, chunks_in_step=1)
 before = e.train_comm_info()
 e.train_comm_init(0, 1, tak_amd.comm_unique_id())
 info = e.train_comm_info()
+preflight_ms = e.train_comm_preflight()   # the communicator's first collective: 4 bytes, before any training work
 sts = orc.random_positions(5, 64, seed=2, max_plies=40, half_komi=4)
 sts = sts[orc.result(5, sts) == 0][:8]
 mv, cnt = orc.movegen(5, sts)
@@ -207,8 +219,14 @@ for i in range(8):
     visits[i, : cnt[i]] = 1
 lp, lz, stepped = e.train_chunk(sts, cnt.astype(np.int32), mv, visits, np.zeros(8, np.float32))   # one all-reduced optimiser step
 ms, count = e.train_comm_stats()
+# tg_train with a step after EVERY chunk: chunk k + 1 and its step are enqueued before chunk k is collected, and still every
+# reduction is counted (two event pairs used in turn)
+rep = lambda a: np.concatenate([a] * 5)
+_, _, steps5 = e.train(rep(sts), rep(cnt.astype(np.int32)), rep(mv), rep(visits), np.zeros(40, np.float32), seed=3)
+ms5, count5 = e.train_comm_stats()
 e.close()
-print("INFO", json.dumps(dict(before=before, info=info, stepped=bool(stepped), reductions=int(count), torch="torch" in sys.modules)))
+print("INFO", json.dumps(dict(before=before, info=info, stepped=bool(stepped), reductions=int(count), torch="torch" in sys.modules,
+                              preflight_ms=preflight_ms, steps5=int(steps5), reductions5=int(count5), ms5=ms5)))
 """
 
 
@@ -232,6 +250,8 @@ def test_comm_info_names_the_rccl_that_is_bound(with_torch):
     assert info["attached"] == 1 and info["world_size"] == 1 and info["rank"] == 0
     assert info["nccl_count"] == 1 and info["nccl_rank"] == 0 and info["nccl_version"] > 20000
     assert r["stepped"] and r["reductions"] == 1
+    assert r["preflight_ms"] > 0
+    assert r["steps5"] == 5 and r["reductions5"] == 1 + 5 and r["ms5"] > 0  # no step dropped from the statistics
     if with_torch:
         assert info["lib_was_mapped"] == 1 and info["lib_path"].endswith(os.path.join("torch", "lib", "librccl.so")), info
     else:

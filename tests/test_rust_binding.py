@@ -32,6 +32,8 @@ def _parse_lib_rs():
 
 def test_lib_rs_is_the_generated_binding_of_the_header():
     assert open(LIB_RS).read() == gen.generate(gen.parse_header()), "rust/takgpu-sys/src/lib.rs is stale: python scripts/gen_rust_sys.py"
+    assert open(gen.INTEGRATION).read() == gen.integration_text(gen.parse_header()), \
+        "INTEGRATION.md quotes a stale number of entry points: python scripts/gen_rust_sys.py"
 
 
 def test_every_declaration_matches_the_header():

@@ -17,6 +17,27 @@ def state_bytes(n):
     return 256 if n <= 5 else 384
 
 
+def distinct_positions(orc, n, count, seed, max_plies=60, half_komi=4):
+    """`count` DIFFERENT ongoing positions (round 6: the full-batch tests used to tile ≈ 2 930 distinct positions to 4096 rows — every
+    row was compared, but a quarter of them were repeats): random play-outs are drawn in rounds of 1.5 × what is still missing,
+    finished games dropped, duplicates removed by content, until `count` are there."""
+    have, seen = [], set()
+    rnd = 0
+    while len(have) < count:
+        batch = orc.random_positions(n, max(256, int(1.5 * (count - len(have))) + 64), seed=seed + 7919 * rnd, max_plies=max_plies, half_komi=half_komi)
+        batch = batch[orc.result(n, batch) == 0]
+        for st in batch:
+            key = st.tobytes()
+            if key not in seen:
+                seen.add(key)
+                have.append(st)
+                if len(have) == count:
+                    break
+        rnd += 1
+        assert rnd < 64, "distinct_positions: the generator keeps repeating itself"
+    return np.stack(have)
+
+
 def with_header(states, **fields):
     """copy of `states` with TgHeader fields replaced: to_move, ply, white_stones, …, half_komi, reversible_plies"""
     out = np.array(states, np.uint8, copy=True).reshape(-1, states.shape[-1])

@@ -310,3 +310,18 @@ def test_fused_backward_sums_and_two_streams_by_value_at_the_real_size(tmp_path)
         worst = max(worst, (k, r), key=lambda t: t[1])
         assert r <= 1e-5, (k, r)
     print("default vs plain backward at B = 4000: worst tensor", worst)
+
+
+def test_tg_train_at_the_real_size_equals_tg_train_chunk(orc):
+    """`extra.train_c5` of the bench line times tg_train — issue-ahead, copy stream — on the 10 × 128 network with chunks of 500
+    examples (B = 4000 positions); its bit-equality with tg_train_chunk was only ever tested on a 2 × 64 network with 128-example
+    chunks.  Here at the real size: 3 chunks of 500 examples, a step after every chunk, and again with a step after two chunks and
+    one left over — parameters, BatchNorm running statistics, left-over gradients and losses, bit for bit
+    (alpha-tak/src/model/network.rs:37-56, 89-96)."""
+    import test_gpu_train as T
+
+    n, blocks, filters, head, count = CFG
+    ex = T._examples(orc, n, 3 * count + 3, seed=43)
+    for per_step in (1, 2):
+        (lp, lz), compared = T.issue_ahead_against_chunk_by_chunk(orc, (n, blocks, filters, head, count, 3, per_step), seed=9, ex=ex)
+        print(f"C5 real size, {per_step} chunk(s) per step: tg_train == tg_train_chunk on {compared} tensors; mean losses {lp:.6f} / {lz:.6f}")

@@ -3,10 +3,12 @@ properties, plus bit-exact comparison of a slice against the oracle."""
 import numpy as np
 import pytest
 
+import posgen
 import torch_ref
 
 pytestmark = pytest.mark.gpu
 G = 4096
+G4 = 16384  # bench.py's extra.games_x4 and the north star's "≥ 10 k concurrent games": the widest engine a line of the bench reports
 
 
 @pytest.fixture(scope="module")
@@ -24,9 +26,8 @@ def c2(orc):
 
 
 def _roots(orc, count):
-    base = orc.random_positions(5, 3000, seed=21, max_plies=60, half_komi=4)
-    base = base[orc.result(5, base) == 0]
-    return np.tile(base, (count // len(base) + 1, 1))[:count]
+    """`count` DISTINCT ongoing 5×5 positions (round 6; rounds 1 – 5 tiled ≈ 2 930 to 4096)"""
+    return posgen.distinct_positions(orc, 5, count, seed=21, max_plies=60)
 
 
 def test_policy_eval_full_batch_properties(c2, orc):
@@ -34,13 +35,12 @@ def test_policy_eval_full_batch_properties(c2, orc):
     sts = _roots(orc, G)
     p, v = e.policy_eval(sts)
     assert np.abs(p.sum(1) - 1).max() < 1e-5 and (p > 0).all() and (np.abs(v) <= 1).all()
-    # identical positions in different batch slots get identical outputs (tiles are batch-position independent)
-    first = {}
-    for i in range(0, G, 97):
-        key = sts[i].tobytes()
-        if key in first:
-            assert np.array_equal(p[i], p[first[key]]) and v[i] == v[first[key]]
-        first.setdefault(key, i)
+    assert len({s.tobytes() for s in sts}) == G
+    # a position's output does not depend on the batch slot it sits in (tiles are batch-position independent): the same 4096
+    # positions in another order → the same rows, bit for bit
+    perm = np.random.default_rng(5).permutation(G)
+    p2, v2 = e.policy_eval(sts[perm])
+    assert np.array_equal(p2, p[perm]) and np.array_equal(v2, v[perm])
     # ALL 4096 rows of the full batch — the batch the benchmarked kernels (k_tower_halo, k_fc_ring) run on — against PyTorch
     # fp32 (north_star tolerance 1e-4), in chunks so the CPU reference stays in cache
     worst_p = worst_v = 0.0
@@ -63,9 +63,8 @@ def _all_rows_against_pytorch(orc, n, blocks, filters, head, precision, rows, se
     if precision != "f32":
         e.set_precision(precision)
     e.load_state_dict(torch_ref.abi_tensors(net))
-    base = orc.random_positions(n, 3000, seed=seed + 40, max_plies=70, half_komi=4)
-    base = base[orc.result(n, base) == 0]
-    sts = np.tile(base, (G // len(base) + 1, 1))[:G]
+    sts = posgen.distinct_positions(orc, n, G, seed=seed + 40, max_plies=70)
+    assert len({s.tobytes() for s in sts}) == G
     p, v = e.policy_eval(sts)
     e.close()
     assert np.abs(p.sum(1) - 1).max() < 2e-5 and (p > 0).all() and (np.abs(v) <= 1).all()
@@ -150,6 +149,81 @@ def test_selfplay_full_size_two_plies(c2, orc):
     assert len({s.tobytes() for s in states}) > G // 2
 
 
+def test_sixteen_thousand_games_forward_search_and_selfplay(orc):
+    """The width `extra.games_x4` of the bench line runs at — ONE engine with max_batch = games = 16 384 on the C2 network (other grids
+    of k_tower_halo / k_fc_ring: 1024 workgroups, another XCD dealing; another pool geometry) — held to what the 4096-game tests
+    hold: tg_policy_eval on all 16 384 DISTINCT rows against PyTorch fp32 (≤ 1e-4), 16 whole trees of a 24-iteration search bit for
+    bit against the oracle, and two self-play plies with the counter and stone-conservation invariants.
+    Reference semantics: train/src/self_play.rs:181-210 (one leaf per game into one batch), alpha-tak/src/model/network.rs:26-35."""
+    import tak_amd
+
+    net = torch_ref.make_net(5, 6, 64, "fc5", seed=0, randomize_bn=True)
+    tensors = torch_ref.abi_tensors(net)
+    e = tak_amd.Engine(5, res_blocks=6, filters=64, evaluator=tak_amd.EVAL_RESNET, max_batch=G4)
+    e.load_state_dict(tensors)
+    sts = _roots(orc, G4)
+    assert len({s.tobytes() for s in sts}) == G4
+    p, v = e.policy_eval(sts)
+    assert np.abs(p.sum(1) - 1).max() < 1e-5 and (p > 0).all() and (np.abs(v) <= 1).all()
+    worst_p = worst_v = 0.0
+    for lo in range(0, G4, 1024):
+        p_ref, v_ref = torch_ref.forward(net, orc.encode(5, sts[lo : lo + 1024]))
+        worst_p = max(worst_p, float(np.abs(p[lo : lo + 1024] - p_ref).max()))
+        worst_v = max(worst_v, float(np.abs(v[lo : lo + 1024] - v_ref).max()))
+    print(f"c2_f32 at 16384 rows: worst |dp| {worst_p:.3e}, worst |dv| {worst_v:.3e} over all {G4} distinct rows")
+    assert worst_p <= 1e-4 and worst_v <= 1e-4, (worst_p, worst_v)
+    # the 4096-row batch of the same positions returns the same bits: a row does not know how wide its batch is
+    p4, v4 = e.policy_eval(sts[5000 : 5000 + G])
+    assert np.array_equal(p4, p[5000 : 5000 + G]) and np.array_equal(v4, v[5000 : 5000 + G])
+    del p, p4
+    # search: 16 384 trees, 24 lock-step iterations
+    iters = 24
+    e.search_create(G4, arena_nodes=1 << 12)
+    e.search_reset(sts)
+    e.search_run(iters)
+    r = e.search_root()
+    exp, ev = e.search_counters()
+    assert exp == G4 * iters and ev <= exp
+    assert (r["root_visits"] == iters).all()
+    cs = np.array([r["visits"][g, : r["counts"][g]].sum() for g in range(G4)])
+    assert (cs == iters - 1).all()
+    assert np.array_equal(r["counts"], orc.movegen(5, sts)[1])
+    assert (np.abs(r["q"]) <= 1.0 + 1e-6).all() and (np.abs(r["root_q"]) <= 1.0 + 1e-6).all()
+    ev_eng = tak_amd.Engine(5, res_blocks=6, filters=64, evaluator=tak_amd.EVAL_RESNET, max_batch=64)
+    ev_eng.load_state_dict(tensors)
+    pick = np.arange(0, G4, G4 // 16) + np.arange(16) * 61  # spread over the workgroups AND over the slots inside one
+    s = orc.Search(5, head=orc.HEAD_FC5, py_eval=lambda st: ev_eng.policy_eval(st))
+    s.reset(sts[pick])
+    s.run(iters)
+    for k, g in enumerate(pick):
+        a, b = e.search_dump(int(g)), s.dump(k)
+        assert len(a) == len(b) and all(np.array_equal(a[f], b[f]) for f in a.dtype.names), g
+        assert (a["virtual_visits"] == 0).all()
+    ev_eng.close()
+    # self-play: two plies of all 16 384 games
+    rollouts = 16
+    e.selfplay_create(G4, arena_nodes=1 << 12, seed=9, rollouts=rollouts, max_examples=G4 * 4)
+    e.selfplay_step(2)
+    st = e.selfplay_stats()
+    assert st["plies"] == 2 and st["games_finished"] == 0 and st["instant_wins"] == 0 and st["aborted_games"] == 0 and st["dropped_examples"] == 0
+    assert st["expansions"] == 2 * G4 * (rollouts + 1) == st["evals"]
+    states = e.search_states()
+    plies = states[:, 256 - 16 + 2].astype(int) | (states[:, 256 - 16 + 3].astype(int) << 8)
+    assert (plies == 4).all()
+    heights = (states[:, 200:225] & 63).sum(1)
+    reserves = states[:, 256 - 16 + 4 : 256 - 16 + 8].astype(int).sum(1)
+    assert (heights + reserves == 44).all()
+    assert len({s.tobytes() for s in states}) > G4 // 2
+    # the shard property at this width: slots 4096 … 8191 of this engine are the games an engine with slot_base = 4096 plays
+    e2 = tak_amd.Engine(5, res_blocks=6, filters=64, evaluator=tak_amd.EVAL_RESNET, max_batch=G)
+    e2.load_state_dict(tensors)
+    e2.selfplay_create(G, arena_nodes=1 << 12, seed=9, rollouts=rollouts, max_examples=G * 4, slot_base=G)
+    e2.selfplay_step(2)
+    assert np.array_equal(e2.search_states(), states[G : 2 * G])
+    e2.close()
+    e.close()
+
+
 def test_board_pass_million_positions(orc):
     import tak_amd
 
@@ -222,9 +296,7 @@ def test_config_c3_full_size(orc):
     tensors = torch_ref.abi_tensors(net)
     e = tak_amd.Engine(n, res_blocks=blocks, filters=filters, evaluator=tak_amd.EVAL_RESNET, max_batch=G)
     e.load_state_dict(tensors)
-    base = orc.random_positions(n, 2000, seed=5, max_plies=70, half_komi=4)
-    base = base[orc.result(n, base) == 0]
-    sts = np.tile(base, (G // len(base) + 1, 1))[:G]
+    sts = posgen.distinct_positions(orc, n, G, seed=5, max_plies=70)
     p, v = e.policy_eval(sts)
     assert p.shape == (G, 9036) and np.abs(p.sum(1) - 1).max() < 2e-5 and (p > 0).all() and (np.abs(v) <= 1).all()
     # ALL 4096 rows of the full batch against PyTorch fp32 (round 4; it was every 4th row)
@@ -237,7 +309,8 @@ def test_config_c3_full_size(orc):
         worst_v = max(worst_v, float(np.abs(v[sel] - v_ref).max()))
     print(f"c3_f32 (randomised BatchNorm fold): worst |dp| {worst_p:.3e}, worst |dv| {worst_v:.3e} over all {G} rows")
     assert worst_p <= 1e-4 and worst_v <= 1e-4, (worst_p, worst_v)
-    assert np.array_equal(p[0], p[len(base)]) and v[0] == v[len(base)]  # same position, another slot of the batch
+    p2, v2 = e.policy_eval(np.roll(sts, 1000, axis=0)[:1024])              # the same positions in other slots of another batch size
+    assert np.array_equal(p2[1000:], p[:24]) and np.array_equal(v2[1000:], v[:24])
     iters = 12
     e.search_create(G, arena_nodes=1 << 13)
     e.search_reset(sts)

@@ -631,7 +631,7 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def run(precision, profile_every, cfg=None, steps=None, warmup=None, drain_every=0):
+    def run(precision, profile_every, cfg=None, steps=None, warmup=None, drain_every=0, rollouts=None):
         """W untimed + K timed plies of self-play on a fresh engine → (seconds, expansions, evals, profile).  cfg =
         (board, blocks, filters, head, games, weights) overrides the command line (the extra lines); drain_every > 0
         fetches the finished examples every so many plies inside the timed region, as a training loop would."""
@@ -645,7 +645,7 @@ def main():
             eng.set_precision(precision)
         eng.load_state_dict(weights)
         ring = games * (min(steps + warmup, drain_every + 8 if drain_every else steps + warmup) + 2)
-        eng.selfplay_create(games, arena_nodes=args.arena, seed=args.seed, rollouts=args.rollouts,
+        eng.selfplay_create(games, arena_nodes=args.arena, seed=args.seed, rollouts=args.rollouts if rollouts is None else rollouts,
                             max_examples=max(1 << 14, ring), slot_base=tdist.slot_base(rank, games))
         for _ in range(warmup):
             eng.selfplay_step(1)
@@ -772,6 +772,19 @@ def main():
                             c3["tower_frac_executed"] = p5.get("conv_flops_executed", p5["conv_flops"]) / t5 / 1e12 / F32_MFMA_PEAK_TFLOPS
                             c3["tower_avg_launch_ms"] = t5 * 1e3
                         extras["config_c3"] = c3
+                        # The reference's OWN constants, unchanged (train/src/self_play.rs:10-12,94: 32 lock-step games, ROLLOUTS = 10 000;
+                        # alpha-tak/src/model/net6.rs:16-17: 6x6, 16 blocks x 128 filters, conv head): one leaf per game → a 32-position
+                        # forward per iteration, the latency-bound end of the engine.  What a maintainer who changes no constant gets.
+                        net6, w6 = make_weights(6, 16, 128, "conv", seed=args.seed)
+                        dt6, exp6, _, p6 = run("f32", 16, cfg=(6, 16, 128, "conv", 32, w6), steps=2, warmup=1, rollouts=10_000)
+                        rc = {"value": exp6 / dt6, "unit": "node-expansions/s", "ms_per_step": 1000.0 * dt6 / 2, "us_per_iteration": 1e6 * dt6 / max(exp6 / 32, 1),
+                              "games": 32, "sims_per_move": 10_000,
+                              "workload": "the reference's constants: 6x6 Tak, 32 lock-step games, 10 000 rollouts per move, Net6 = 16-block x 128-filter resnet, "
+                                          "conv policy head; 2 plies timed after 1 warm-up ply"}
+                        if p6 and p6["forwards"]:
+                            rc["forward_us_at_32_leaves"] = 1000.0 * p6["forward_ms"] / p6["forwards"]  # HIP events around one network forward
+                            rc["tree_and_launch_us_per_iteration"] = rc["us_per_iteration"] - rc["forward_us_at_32_leaves"]
+                        extras["reference_constants"] = rc
                 except Exception as ex:
                     extras["error"] = repr(ex)
                 out["extra"] = extras

@@ -85,6 +85,7 @@ void net_destroy(Net* n);
 // search.hip
 void search_destroy(Search* s);
 int search_poll_errors(TgEngine* e);  // after a stream sync: device error flags → status
+int net_poll_errors(TgEngine* e);     // after a stream sync: the network kernels' error word → status
 int net_set_tensor(TgEngine* e, const char* name, const float* data, size_t count);
 int net_finalize(TgEngine* e);
 bool net_ready(const TgEngine* e);

@@ -87,13 +87,19 @@ struct TowerParams {
     int cb_last_t;        // 3: ten / twelve real channels in the last 16-channel chunk
     const float* w0_board;
     const float* cplane_sums;
+    // k_tower_split (small batches of 128-filter networks): one counter per position of a launch (zero between launches) and an
+    // error word a bounded wait raises; nullptr: the split path is not used
+    unsigned* split_flags;
+    int* split_err;
 };
+constexpr int TOWER_SPLIT_CTL_WORDS = 128 * 32 + 32;  // TowerParams.split_flags: a 128-byte line per position, then the error word's line
+constexpr int TOWER_SPLIT_MAX_BATCH = 128;  // 8 small workgroups per position: the whole grid (≤ 1024 of them on 5×5, ≤ 512 on 6×6) is resident at once
 // geometry of the halo image for a supported topology (positions per workgroup, position stride) and the slot table
 bool tower_halo_geometry(int n, int F, int* pw, int* ps);
 void tower_halo_slotmap(int n, int pw, int ps, uint32_t* out /* ceil(pw·n²/16)·16 entries */);
 bool tower_supported(int n, int F, int cin_pad);
 hipError_t launch_tower(hipStream_t st, const float* in, const TowerParams& T, float* out, int B, int n);
-hipError_t launch_tower_states(hipStream_t st, const uint8_t* states, const TowerParams& T, float* out, int B, int n);
+hipError_t launch_tower_states(hipStream_t st, const uint8_t* states, const TowerParams& T, float* out, int B, int n, float* scratch = nullptr);
 // net_s3_kernels.hip — split-bf16 ("bf16x3") tower
 struct TowerS3Params {
     const void* w[48];    // per layer: [chunk = tap·KC + kc][cout tile][hi|lo][q][cout in tile][8 bf16]

@@ -49,6 +49,8 @@ struct Net {
     DevBuf cplane_sums;                // S[constant plane][border class][F] (TowerParams.cb)
     int64_t conv_flops_exec = 0;       // MFMA FLOPs the timed launch actually issues (≤ conv_flops when constant planes are a bias)
     DevBuf halo_map;                   // tile slot → square table of the halo tower (k_tower_halo)
+    DevBuf split_ctl;                  // k_tower_split: a counter line per position, then the error word a bounded wait raises (TOWER_SPLIT_CTL_WORDS)
+    DevBuf split_buf;                  // k_tower_split: two exchange buffers of TOWER_SPLIT_MAX_BATCH positions × n² × F floats
     DevBuf s3_halo_map;                // the same for the split tower's workgroup (k_tower_s3_halo)
     size_t logit_row = 0;              // floats per position in `logits`
     int precision = TG_PRECISION_F32;  // tg_net_set_precision
@@ -368,6 +370,14 @@ int net_finalize(TgEngine* e) {
             T.w[2 + 2 * i] = n->res2[i].w.as<float>(); T.b[2 + 2 * i] = n->res2[i].b.as<float>();
         }
         T.slotmap = nullptr; T.halo_pw = 0; T.halo_ps = 0;
+        T.split_flags = nullptr; T.split_err = nullptr;
+        if (T.cb && (F == 128 || (F == 64 && e->g.n == 5))) {  // small batches split a position over several workgroups (k_tower_split)
+            TG_HIP(n->split_ctl.ensure((size_t)TOWER_SPLIT_CTL_WORDS * 4));
+            TG_HIP(hipMemset(n->split_ctl.p, 0, (size_t)TOWER_SPLIT_CTL_WORDS * 4));
+            TG_HIP(n->split_buf.ensure((size_t)2 * TOWER_SPLIT_MAX_BATCH * nsq * F * 4));
+            T.split_flags = n->split_ctl.as<unsigned>();
+            T.split_err = n->split_ctl.as<int>() + TOWER_SPLIT_CTL_WORDS - 32;
+        }
         // FC-head networks whose value head rides in the FC's padding column: nothing but the policy FC reads the tower's
         // output, so it is written in the FC's fragment order
         T.frag_out = (e->cfg.policy_head == TG_HEAD_FC5 && n->value_in_fc && fc_frag_supported(nsq * F, n->policy_np) &&
@@ -634,7 +644,9 @@ static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const ui
         if (chain) chain->push_back(prof_event(n, st));
     } else if (n->fused) {
         if (chain) chain->push_back(prof_event(n, st));
-        if (d_states) TG_HIP(launch_tower_states(st, d_states, n->tower, x, nb, N));
+        // (small batches of wide networks run split by channel tile through the exchange buffers; they and the position counters
+        // belong to the engine stream's launches)
+        if (d_states) TG_HIP(launch_tower_states(st, d_states, n->tower, x, nb, N, st == e->stream ? n->split_buf.as<float>() : nullptr));
         else TG_HIP(launch_tower(st, d_planes, n->tower, x, nb, N));
         if (chain) chain->push_back(prof_event(n, st));
     } else {
@@ -680,6 +692,17 @@ static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const ui
     else TG_HIP(launch_value_head(st, x, n->value_w.as<float>(), n->value_b, nb, nsq * F, d_eval));
     if (chain) chain->push_back(prof_event(n, st));
     return TG_OK;
+}
+
+// after a stream sync: has a bounded wait of k_tower_split given up?  (never seen; it would mean a sibling workgroup of a position
+// was not running — the counters are reset so that the next launch starts clean)
+int net_poll_errors(TgEngine* e) {
+    if (!e || !e->net || !e->net->split_ctl.p) return TG_OK;
+    int err = 0;
+    TG_HIP(hipMemcpy(&err, e->net->split_ctl.as<int>() + TOWER_SPLIT_CTL_WORDS - 32, 4, hipMemcpyDeviceToHost));
+    if (!err) return TG_OK;
+    TG_HIP(hipMemset(e->net->split_ctl.p, 0, (size_t)TOWER_SPLIT_CTL_WORDS * 4));
+    return fail(TG_ERR_HIP, "k_tower_split: a workgroup waited for its position's siblings beyond the bound; the forward's results are invalid");
 }
 
 int net_profile_enable(TgEngine* e, int sample_every) {
@@ -811,6 +834,8 @@ int tg_policy_eval(TgEngine* e, int n, const void* states, float* policy, float*
         TG_HIP(hipMemcpyAsync(policy + (size_t)off * P, e->s_policy.p, (size_t)k * P * 4, hipMemcpyDeviceToHost, e->stream));
         TG_HIP(hipMemcpyAsync(eval + off, e->s_eval.p, (size_t)k * 4, hipMemcpyDeviceToHost, e->stream));
         TG_HIP(hipStreamSynchronize(e->stream));
+        rc = net_poll_errors(e);
+        if (rc) return rc;
     }
     return TG_OK;
 }

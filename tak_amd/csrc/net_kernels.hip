@@ -503,6 +503,190 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// The fused tower for SMALL batches of wide networks (round 6): k_tower gives every position to one workgroup — at the reference's
+// own constants (32 lock-step games → 32 leaves per forward, Net6 = 16 blocks × 128 filters; train/src/self_play.rs:94,
+// alpha-tak/src/model/net6.rs:16-17) that is 32 busy CUs of 256, each issuing 8 channel tiles × 3 row tiles × 288 MFMAs per layer
+// (23 µs per layer, 882 µs per forward).  Here a position is SPLIT over G = 8 / 4 / 2 workgroups by output channel tile: workgroup
+// (position p, group g) holds the whole input image of p in LDS and computes CTW channel tiles × NRT row tiles, one (row tile, channel
+// tile) pair per wave = ONE chain of 9·16·CH/4 MFMAs — the shortest critical path the arithmetic allows (a chain cannot be cut: every
+// output element is accumulated over k in k_tower's order, so the results are bit-identical).  Between two layers the G workgroups of a
+// position exchange their 16·CTW-channel slices through global memory (two buffers used in turn; L2-resident: n²·F floats per
+// position) and meet at a counter per position: slice stored → release → flag += 1; wait for flag = G·(layer + 1) → acquire → stage the
+// next image.  The siblings of a position have the same blockIdx.x, so with B a multiple of 8 they sit on one XCD and the exchange
+// stays in that XCD's L2 (the fences make it correct wherever they sit).  Weights: a wave with one tile issues 4 MFMAs per 16-k chunk —
+// far less than an L2 round trip — so they are fetched a whole TAP ahead (CH quads per lane, two sets) instead of two chunks ahead.
+// A workgroup never waits for more than its own G − 1 siblings, all of one launch whose grid (≤ 512 small workgroups) is co-resident;
+// the wait is bounded all the same: after SPLIT_SPIN_LIMIT polls it raises T.split_err (→ TG_ERR_HIP on the host) and the waits stop.
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned SPLIT_SPIN_LIMIT = 1u << 21;
+constexpr int SPLIT_FLAG_STRIDE = 32;  // u32 words between two positions' counters (kernels.h: TOWER_SPLIT_CTL_WORDS)
+
+// one (row tile, channel tile) pair: the products of conv_mainloop<1, CHL> in the same order (tap, chunk, t); weights one tap ahead,
+// the tap's activation quads one tap ahead as well.  w0 = the first tap's CHL weight quads, requested by the caller (conv_tile_first_weights)
+// as early as it likes — they depend on nothing but the layer.  TAPCHAIN: every tap's products in a chain of their own that is added
+// to acc when the tap is complete (k_conv_pos / conv_mainloop_halo<SPLIT>: the stand-alone layers' order).
+template <int CHL>
+__device__ __forceinline__ void conv_tile_first_weights(const f32x4* __restrict__ wp, size_t wstride4, f32x4 (&w0)[CHL]) {
+#pragma unroll
+    for (int kc = 0; kc < CHL; kc++) w0[kc] = wp[(size_t)kc * wstride4];
+}
+template <int CHL, int LAST_T = 4, bool TAPCHAIN = false>
+__device__ __forceinline__ void conv_mainloop_tile(const f32x4* __restrict__ lds4, const f32x4* __restrict__ wp, size_t wstride4, int LS4,
+                                                   int rows, int n, int rho, int q, int vmask, f32x4& acc, const f32x4 (&w0)[CHL]) {
+    // LAST_T < 4 (layer 0): the last chunk's real channels fill MFMAs t < LAST_T, the others would multiply padding (conv_mainloop)
+    const int zero4 = rows * LS4 + q, base = rho * LS4 + q;
+    auto tap_addr = [&](int tap) { return ((vmask >> tap) & 1) ? base + ((tap / 3 - 1) * n + (tap % 3 - 1)) * LS4 : zero4; };
+    f32x4 w[2][CHL], a[2][CHL];
+#pragma unroll
+    for (int kc = 0; kc < CHL; kc++) w[0][kc] = w0[kc];
+    {
+        const int a0 = tap_addr(0);
+#pragma unroll
+        for (int kc = 0; kc < CHL; kc++) a[0][kc] = lds4[a0 + kc * 4];
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) {
+        const int cur = tap & 1, nxt = cur ^ 1;
+        if (tap + 1 < 9) {
+#pragma unroll
+            for (int kc = 0; kc < CHL; kc++) w[nxt][kc] = wp[(size_t)((tap + 1) * CHL + kc) * wstride4];
+            const int a1 = tap_addr(tap + 1);
+#pragma unroll
+            for (int kc = 0; kc < CHL; kc++) a[nxt][kc] = lds4[a1 + kc * 4];
+        }
+        // (left alone hipcc sinks every load next to its use: the chain would then wait out an L2 round trip per chunk)
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 part = TAPCHAIN ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : acc;
+#pragma unroll
+        for (int kc = 0; kc < CHL; kc++)
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                if (kc + 1 < CHL || t < LAST_T) part = __builtin_amdgcn_mfma_f32_16x16x4f32(w[cur][kc][t], a[cur][kc][t], part, 0, 0, 0);
+        if (TAPCHAIN) acc += part;
+        else acc = part;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// SAME_L2: the launcher has verified on this device that workgroup id i runs on XCD i mod 8 (k_xcc_probe), so a position's siblings
+// share one L2 and the exchange needs no agent-scope fences — those write back and INVALIDATE the XCD's whole L2 (buffer_wbl2 sc1 /
+// buffer_inv sc1: 256 workgroups × every layer), after which every weight load of the next layer misses it.  What it needs instead:
+// the slice's stores complete (the vector L1 writes through: s_waitcnt vmcnt(0) = in L2), the counter as an L2 atomic, and this CU's
+// L1 dropped before the image is staged (buffer_inv sc0).  Without the guarantee: the agent-scope fences, correct wherever the siblings sit.
+template <int NRT, int CTW, int CH, bool SAME_L2>
+__global__ __launch_bounds__(NRT * CTW * 64) void k_tower_split(const uint8_t* __restrict__ states, TowerParams T, float* __restrict__ out,
+                                                                float* __restrict__ scratch, int B, int n) {
+    constexpr int NW = NRT * CTW, F = 16 * CH, F4 = F / 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    f32x4* lds4 = (f32x4*)lds;
+    const int tid = threadIdx.x, nsq = n * n, rows = nsq;
+    // workgroup id → (position, channel group): ids come in blocks of 8·G — 8 consecutive positions × their G groups — with the
+    // position's low three bits in the id's low three bits: the G siblings of a position are dispatched within 8·G consecutive ids
+    // (they never wait for a workgroup far behind them in the dispatch order) and land on one XCD (id mod 8), so their exchange
+    // stays in that XCD's L2
+    constexpr int G = (CH / CTW);
+    const int blk = blockIdx.x / (8 * G), rem = blockIdx.x - blk * (8 * G);
+    const int p = blk * 8 + (rem & 7), g = rem >> 3;
+    if (p >= B) return;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int ct = wave % CTW, rt = wave / CTW;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int ch0 = (g * CTW + ct) * 16;
+    const int rho = rt * 16 + r16;  // this lane's row (square) of the position; ≥ rows: padding of the last row tile
+    unsigned* flag = T.split_flags + (size_t)p * SPLIT_FLAG_STRIDE;  // a 128-byte line per position: its 8 pollers contend with nobody else
+
+    // ---- layer 0's image: the board planes of position p, the per-class bias table behind it (as k_tower, CB) ----
+    int LS4 = (T.cb_cin_pad + LDS_PAD16) >> 2;
+    f32x4* pb4 = lds4 + (size_t)(nsq + 1) * LS4;
+    tower_stage_states_cb<NW>(lds4, pb4, states, p, 1, n, LS4, T);
+    for (int idx = tid; idx < LS4; idx += NW * 64) lds4[rows * LS4 + idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    __syncthreads();
+
+    int vmask[1];
+    conv_tap_masks<1>(rows, n, nsq, rho, vmask);
+    f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    bool failed = false;  // (thread 0) a wait ran into its bound: no further waits
+    const size_t wlane = (size_t)(ch0 + r16) * 4 + q;
+    f32x4 wf[CH];  // the first tap's weights of the NEXT layer: requested before the wait for the siblings, there when it ends
+    for (int layer = 0; layer < T.nlayers; layer++) {
+        const f32x4* wp = (const f32x4*)(layer == 0 ? T.w0_board : T.w[layer]) + wlane;
+        const f32x4 bv = *(const f32x4*)&T.b[layer][ch0 + 4 * q];
+        if (layer == 0) {  // (cb_last_t = 3, one 32-channel chunk pair: the launcher checks)
+            f32x4 wf0[2];
+            conv_tile_first_weights<2>(wp, (size_t)F * 4, wf0);
+            conv_mainloop_tile<2, 3>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho, q, vmask[0], acc, wf0);
+        } else conv_mainloop_tile<CH>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho, q, vmask[0], acc, wf);
+        f32x4 v = acc + (layer == 0 ? pb4[tower_cb_index(rho, rows, n, nsq, F4, (ch0 >> 2) + q)] : bv);
+        v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f);
+        if (layer + 1 == T.nlayers) {
+            if (rho < rows) {
+                if (T.frag_out) ((f32x4*)out)[((size_t)(p >> 4) * (nsq * CH) + rho * CH + (ch0 >> 4)) * 64 + (p & 15) * 4 + q] = v;
+                else *(f32x4*)&out[((size_t)p * nsq + rho) * F + ch0 + 4 * q] = v;
+            }
+            break;
+        }
+        // the block input of conv2's accumulator: this wave's own slice of the image conv1 has just read (k_tower's skip path)
+        f32x4 x0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if ((layer & 1) == 1 && rho < rows) x0 = lds4[rho * LS4 + (ch0 >> 2) + q];
+        acc = x0;
+        // two exchange buffers used in turn (`out` is written by the last layer only: in the FC's fragment order a position's output
+        // lies across the rows of 15 others)
+        float* xbuf = scratch + (size_t)(layer & 1) * TOWER_SPLIT_MAX_BATCH * nsq * F;
+        if (rho < rows) *(f32x4*)&xbuf[((size_t)p * nsq + rho) * F + ch0 + 4 * q] = v;
+        if (SAME_L2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();  // every wave's slice is in L2 (SAME_L2) / on its way and every wave has finished reading the image
+        conv_tile_first_weights<CH>((const f32x4*)T.w[layer + 1] + wlane, (size_t)F * 4, wf);
+        if (tid == 0) {
+            if (!SAME_L2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = (unsigned)G * (unsigned)(layer + 1);
+            unsigned spins = 0;
+            // (device scope: a group-scope load — sc0 — may hit this CU's L1 and then never sees the siblings' atomics: measured, the
+            // bounded wait fired)
+            auto poll = [&]() -> unsigned { return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+            while (!failed && poll() < target) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > SPLIT_SPIN_LIMIT || ((spins & 4095u) == 0 && __hip_atomic_load(T.split_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    __hip_atomic_store(T.split_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    failed = true;
+                }
+            }
+            if (!SAME_L2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        if (SAME_L2) asm volatile("buffer_inv sc0" ::: "memory");  // this CU's L1 may hold the buffer's lines of two layers ago
+        // ---- the next layer's image: all F channels of position p, pitch F + 8 floats ----
+        LS4 = (F + LDS_PAD16) >> 2;
+        const f32x4* src = (const f32x4*)(xbuf + (size_t)p * nsq * F);
+        const int total = nsq * F4;
+        constexpr int UNR = 8;
+        for (int base = 0; base < total; base += NW * 64 * UNR) {
+            f32x4 tmp[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int idx = base + u * NW * 64 + tid;
+                tmp[u] = src[idx < total ? idx : total - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int idx = base + u * NW * 64 + tid;
+                if (idx < total) lds4[(idx / F4) * LS4 + idx % F4] = tmp[u];
+            }
+        }
+        if (layer == 0)
+            for (int idx = tid; idx < LS4; idx += NW * 64) lds4[rows * LS4 + idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        __syncthreads();
+    }
+    // the counter returns to zero with the launch: the last of the position's G workgroups to finish resets it
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == (unsigned)G * (unsigned)T.nlayers) __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The fused tower for full batches: as k_tower, but from layer 1 on the resident image is the HALO image of
 // conv_mainloop.cuh (zero cells between board rows and between positions), so the 3×3 taps are immediates and the main
 // loop is nothing but ds_read_b128 / MFMA / one weight load per chunk.  Layer 0 (other pitch, once per launch) runs
@@ -849,6 +1033,58 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_halo(const float* __restri
 #ifdef TG_TOWER_STAMPS
     if (g_tower_stamps && tid == NWAVES * 64 - 64) g_tower_stamps[128 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
+}
+
+// ONE 3×3 layer for SMALL batches (round 6; the conv policy head of Net6 at the reference's 32 leaves: k_conv_pos gave a position to
+// one workgroup — 32 busy CUs — with 3 row tiles per wave and the weights one chunk ahead): workgroup = (position, 16-channel tile),
+// wave = row tile, ONE chain per wave with the weights a tap ahead (conv_mainloop_tile).  k_conv_pos's sums — a chain per tap, added in
+// tap order — so the same bits.  No residual, no statistics: the head and plain layers.
+template <int NRT, int CH>
+__global__ __launch_bounds__(NRT * 64) void k_conv_split(const float* __restrict__ in, const float* __restrict__ Wp, const float* __restrict__ bias,
+                                                         float* __restrict__ out, int n, int CoutP, int out_stride, int cout_valid, int relu) {
+    constexpr int F = 16 * CH, F4 = F / 4, LS4 = (F + LDS_PAD16) >> 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    f32x4* lds4 = (f32x4*)lds;
+    const int tid = threadIdx.x, nsq = n * n, rows = nsq;
+    const int p = blockIdx.x, ch0 = blockIdx.y * 16;
+    const int rt = tid >> 6, lane = tid & 63, r16 = lane & 15, q = lane >> 4;
+    const int rho = rt * 16 + r16;
+    const f32x4* wp = (const f32x4*)Wp + ((size_t)(ch0 + r16) * 4 + q);
+    const size_t wstride4 = (size_t)CoutP * 4;
+    f32x4 wf[CH];
+    conv_tile_first_weights<CH>(wp, wstride4, wf);  // in flight while the image is staged
+    {
+        const f32x4* src = (const f32x4*)(in + (size_t)p * nsq * F);
+        const int total = nsq * F4;
+        constexpr int UNR = 8;
+        for (int base = 0; base < total; base += NRT * 64 * UNR) {
+            f32x4 tmp[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int idx = base + u * NRT * 64 + tid;
+                tmp[u] = src[idx < total ? idx : total - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int idx = base + u * NRT * 64 + tid;
+                if (idx < total) lds4[(idx / F4) * LS4 + idx % F4] = tmp[u];
+            }
+        }
+        for (int idx = tid; idx < LS4; idx += NRT * 64) lds4[rows * LS4 + idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    __syncthreads();
+    int vmask[1];
+    conv_tap_masks<1>(rows, n, nsq, rho, vmask);
+    f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    conv_mainloop_tile<CH, 4, true>(lds4, wp, wstride4, LS4, rows, n, rho, q, vmask[0], acc, wf);
+    const int ch = ch0 + 4 * q;
+    if (rho < rows && ch < cout_valid) {
+        f32x4 v = acc + *(const f32x4*)&bias[ch];
+        if (relu) { v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f); }
+        const size_t o = ((size_t)p * nsq + rho) * out_stride + ch;
+        if (ch + 3 < cout_valid) *(f32x4*)&out[o] = v;
+        else for (int t = 0; t < 4; t++) if (ch + t < cout_valid) out[o + t] = v[t];
+    }
 }
 
 // Plain GEMM out[M][N] = A[M][K]·W[K][N] + bias for the 5×5 policy FC (net5.rs:56-61,108): the same
@@ -1555,6 +1791,16 @@ hipError_t launch_conv3x3(hipStream_t st, const float* in, const float* Wp, cons
             }
         }
     }
+    {   // small batches of a layer without residual and statistics (the conv policy head): (position, channel tile) workgroups
+        static const bool off = env_on("TG_NO_SPLIT_TOWER");
+        if (!off && !res && !stats_part && !bnb && B >= 1 && B <= TOWER_SPLIT_MAX_BATCH && Cpad == 128 && CoutP % 16 == 0 && (n == 5 || n == 6)) {
+            const size_t lds = (size_t)(n * n + 1) * (128 + LDS_PAD16) * sizeof(float);
+            const dim3 grid(B, CoutP / 16);
+            if (n == 6) hipLaunchKernelGGL((k_conv_split<3, 8>), grid, dim3(192), lds, st, in, Wp, bias, out, n, CoutP, out_stride, cout_valid, relu ? 1 : 0);
+            else hipLaunchKernelGGL((k_conv_split<2, 8>), grid, dim3(128), lds, st, in, Wp, bias, out, n, CoutP, out_stride, cout_valid, relu ? 1 : 0);
+            return hipGetLastError();
+        }
+    }
     // whole-positions kernel where the shape divides evenly (the BASELINE configs); generic tiles otherwise
     // small batches take fewer positions per workgroup (shorter critical path, same bits — see launch_tower)
 #define TG_CONV_POS(RTW, NW, PW, CTW) \
@@ -1716,12 +1962,80 @@ hipError_t launch_tower(hipStream_t st, const float* in, const TowerParams& T, f
     return hipErrorInvalidValue;
 }
 
-// same, with the input planes encoded in-kernel from packed game states
-hipError_t launch_tower_states(hipStream_t st, const uint8_t* states, const TowerParams& T, float* out, int B, int n) {
+// Does workgroup id i of a 1-D grid run on XCD i mod 8 on this device (every XCD its own L2)?  64 workgroups report HW_REG_XCC_ID.
+__global__ void k_xcc_probe(unsigned* __restrict__ out) {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    if (threadIdx.x == 0) out[blockIdx.x] = x & 15u;
+}
+static bool workgroups_round_robin_over_xcds() {
+    static std::mutex guard;
+    static int verdict[16] = {};  // per device: 0 unknown, 1 yes, 2 no
+    std::lock_guard<std::mutex> lock(guard);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+    if (verdict[dev]) return verdict[dev] == 1;
+    verdict[dev] = 2;
+    unsigned* d = nullptr;
+    unsigned h[64];
+    if (hipMalloc((void**)&d, sizeof(h)) != hipSuccess) return false;
+    bool ok = true;
+    for (int rep = 0; rep < 4 && ok; rep++) {  // (a fresh launch every time: the mapping must not depend on what ran before)
+        hipLaunchKernelGGL(k_xcc_probe, dim3(64), dim3(64), 0, nullptr, d);
+        ok = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess;
+        for (int i = 8; i < 64 && ok; i++) ok = h[i] == h[i & 7];
+    }
+    (void)hipFree(d);
+    if (ok) verdict[dev] = 1;
+    return ok;
+}
+
+template <int NRT, int CTW, int CH>
+static hipError_t launch_tower_split_t(hipStream_t st, const uint8_t* states, const TowerParams& T, float* out, float* scratch, int B, int n) {
+    const int nsq = n * n, F = 16 * CH;
+    const size_t first = (size_t)(nsq + 1) * (T.cb_cin_pad + LDS_PAD16) * sizeof(float) + tower_cb_table_bytes(1, F);
+    const size_t later = (size_t)(nsq + 1) * (F + LDS_PAD16) * sizeof(float);
+    const size_t lds = first > later ? first : later;
+    constexpr int G = CH / CTW;
+    const dim3 grid((B + 7) / 8 * 8 * G), block(NRT * CTW * 64);
+    static const bool agent_fences = env_on("TG_SPLIT_AGENT_FENCES");  // A/B: the exchange with agent-scope fences wherever the siblings sit (same bits)
+    if (!agent_fences && workgroups_round_robin_over_xcds()) {
+        static LdsAttr lds_attr;
+        if (hipError_t e = lds_attr.ensure((const void*)k_tower_split<NRT, CTW, CH, true>, lds); e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_tower_split<NRT, CTW, CH, true>), grid, block, lds, st, states, T, out, scratch, B, n);
+    } else {
+        static LdsAttr lds_attr;
+        if (hipError_t e = lds_attr.ensure((const void*)k_tower_split<NRT, CTW, CH, false>, lds); e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_tower_split<NRT, CTW, CH, false>), grid, block, lds, st, states, T, out, scratch, B, n);
+    }
+    return hipGetLastError();
+}
+
+// small batches of the 128-filter networks: a position split over 8 / 4 / 2 workgroups by channel tile (k_tower_split; identical bits);
+// scratch = TowerParams.split_buf's two exchange buffers
+static bool launch_tower_split(hipStream_t st, const uint8_t* states, const TowerParams& T, float* out, float* scratch, int B, int n,
+                               hipError_t* err) {
+    static const bool off = env_on("TG_NO_SPLIT_TOWER");
+    if (off || !scratch || !T.cb || T.cb_last_t != 3 || T.cb_cin_pad != 32 || !T.split_flags || B > TOWER_SPLIT_MAX_BATCH || (T.nlayers & 1) == 0)
+        return false;
+    if (n == 5 && T.F == 64) { *err = launch_tower_split_t<2, 1, 4>(st, states, T, out, scratch, B, n); return true; }  // G = 4
+    if (T.F != 128) return false;
+    // one (row tile, channel tile) pair per wave, G = 8 workgroups per position: 3-wave workgroups (6×6) fit twice on a CU at their
+    // 200 registers, 2-wave ones (5×5) four times — 512 / 1024 resident workgroups.  (2 and 4 channel tiles per workgroup — G = 4, 2 —
+    // were measured for the batches in between: a 12-wave workgroup per position pair gains nothing over k_tower.)
+    if (n == 6 && B <= TOWER_SPLIT_MAX_BATCH / 2) { *err = launch_tower_split_t<3, 1, 8>(st, states, T, out, scratch, B, n); return true; }
+    if (n == 5) { *err = launch_tower_split_t<2, 1, 8>(st, states, T, out, scratch, B, n); return true; }
+    return false;
+}
+
+// same, with the input planes encoded in-kernel from packed game states.  scratch (optional): a second activation buffer of the
+// batch's size — with it small batches of wide networks run split by channel tile (k_tower_split)
+hipError_t launch_tower_states(hipStream_t st, const uint8_t* states, const TowerParams& T, float* out, int B, int n, float* scratch) {
     const float* in = (const float*)states;
     {
         hipError_t herr;
         if (launch_tower_halo<true>(st, in, T, out, B, n, &herr)) return herr;
+        if (launch_tower_split(st, states, T, out, scratch, B, n, &herr)) return herr;
     }
     if (T.cb) {  // the same tilings with layer 0 over the board planes (identical bits for every batch size)
         if (n == 5 && T.F == 64) {

@@ -48,6 +48,7 @@ static int describe_errors(uint32_t bits) {
 }
 
 int search_poll_errors(TgEngine* e) {
+    if (int rc = net_poll_errors(e)) return rc;
     if (!e || !e->search) return TG_OK;
     uint32_t bits = 0;
     TG_HIP(hipMemcpy(&bits, e->search->err.p, 4, hipMemcpyDeviceToHost));

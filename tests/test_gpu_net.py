@@ -190,8 +190,10 @@ def test_c_host_runs_selfplay_through_the_abi(tmp_path):
 
 @pytest.mark.parametrize("n,blocks,filters,head,sizes", [
     (5, 6, 64, "fc5", (1, 200, 300, 700, 1500, 2500)),   # C2: every positions-per-workgroup variant of the tower + both FC kernels
-    (5, 2, 128, "fc5", (17, 300, 600, 1100)),             # C5 network shape
-    (6, 2, 128, "conv", (5, 260, 520)),                   # C3 shape, conv head
+    # C5 network shape; ≤ 128 positions of a 128-filter network run k_tower_split (round 6: a position split over 8 / 4 / 2
+    # workgroups by channel tile, slices exchanged through global memory between layers): 1 … 32, 33 … 64 and 65 … 128 positions
+    (5, 2, 128, "fc5", (1, 17, 32, 33, 64, 100, 128, 129, 255, 300, 600, 1100)),
+    (6, 2, 128, "conv", (5, 32, 40, 64, 65, 128, 129, 260, 520)), # C3 shape, conv head
     (5, 2, 64, "conv", (40, 500, 1100, 2100)),            # conv head on 5×5
 ])
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _digest(cfg, batch, **env):
     e = dict(os.environ)
-    for k in ("TG_NO_HALO_TOWER", "TG_NO_FC_GATHER", "TG_S3_NO_FC_RING", "TG_FC_PERMUTED_SRC", "TG_NO_FRAG_OUT", "TG_PRECISION", "TG_NO_CONST_BIAS", "TG_NO_FC_STATS"):
+    for k in ("TG_NO_SPLIT_TOWER", "TG_SPLIT_AGENT_FENCES", "TG_NO_HALO_TOWER", "TG_NO_FC_GATHER", "TG_S3_NO_FC_RING", "TG_FC_PERMUTED_SRC", "TG_NO_FRAG_OUT", "TG_PRECISION", "TG_NO_CONST_BIAS", "TG_NO_FC_STATS"):
         e.pop(k, None)
     e.update(env)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "ab_bits.py"), cfg, str(batch)], env=e, check=True,
@@ -41,6 +41,16 @@ def test_launcher_variants_return_identical_bits(cfg, batch):
     assert _digest(cfg, batch, TG_PRECISION="bf16x3", TG_NO_HALO_TOWER="1") == s3
     if cfg != "c3":  # the split-bf16 FC's ring kernel (full batches) against k_fc_s3b + k_fc_stats
         assert _digest(cfg, batch, TG_PRECISION="bf16x3", TG_S3_NO_FC_RING="1") == s3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,batch", [("c3", 32), ("c5", 24), ("c5", 61), ("c3", 128)])
+def test_split_tower_returns_the_bits_of_the_one_workgroup_tower(cfg, batch):
+    """Small batches of the 128-filter networks: k_tower_split (a position over 8 / 4 / 2 workgroups, slices exchanged between layers) against
+    k_tower (TG_NO_SPLIT_TOWER=1), and its exchange with agent-scope fences (TG_SPLIT_AGENT_FENCES=1) against the same-L2 fast path"""
+    base = _digest(cfg, batch)
+    assert _digest(cfg, batch, TG_NO_SPLIT_TOWER="1") == base
+    assert _digest(cfg, batch, TG_SPLIT_AGENT_FENCES="1") == base
 
 
 TREE_DIGEST = r"""

@@ -21,7 +21,8 @@ rollouts = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 if len(sys.argv) > 2:
     board, blocks, filters, head = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
 weights = torch_ref.abi_tensors(torch_ref.make_net(board, blocks, filters, head, seed=0, randomize_bn=False))
-for games in (32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384):
+widths = [int(g) for g in os.environ["GAMES"].split(",")] if os.environ.get("GAMES") else (32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384)
+for games in widths:
     e = tak_amd.Engine(board, res_blocks=blocks, filters=filters, policy_head=tak_amd.HEAD_FC5 if head == "fc5" else tak_amd.HEAD_CONV,
                        evaluator=tak_amd.EVAL_RESNET, max_batch=games)
     e.load_state_dict(weights)

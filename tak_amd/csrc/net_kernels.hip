@@ -2039,6 +2039,8 @@ hipError_t launch_tower_states(hipStream_t st, const uint8_t* states, const Towe
     }
     if (T.cb) {  // the same tilings with layer 0 over the board planes (identical bits for every batch size)
         if (n == 5 && T.F == 64) {
+            // (round 6, measured at 300 … 2048 positions with 1 / 2 / 4 / 8 positions per workgroup: these brackets are within 11 % of the
+            // best choice everywhere — two co-resident workgroups of half the size take as long as one — profiles/r06_e_tower_pw_sweep.txt)
             if (B <= 256) return launch_tower_t<2, 4, 2, 4, true, true>(st, in, T, out, B, n, 1, 4);
             if (B <= 512) return launch_tower_t<4, 4, 2, 4, true, true>(st, in, T, out, B, n, 2, 4);
             if (B <= 1024) return launch_tower_t<7, 4, 2, 4, true, true>(st, in, T, out, B, n, 4, 4);

@@ -702,7 +702,9 @@ int net_poll_errors(TgEngine* e) {
     TG_HIP(hipMemcpy(&err, e->net->split_ctl.as<int>() + TOWER_SPLIT_CTL_WORDS - 32, 4, hipMemcpyDeviceToHost));
     if (!err) return TG_OK;
     TG_HIP(hipMemset(e->net->split_ctl.p, 0, (size_t)TOWER_SPLIT_CTL_WORDS * 4));
-    return fail(TG_ERR_HIP, "k_tower_split: a workgroup waited for its position's siblings beyond the bound; the forward's results are invalid");
+    return fail(TG_ERR_HIP, err == 2 ? "k_tower_split: the workgroups of one position ran on different XCDs (the same-L2 exchange is not safe on this "
+                                       "device: set TG_SPLIT_AGENT_FENCES=1 or TG_NO_SPLIT_TOWER=1); the forward's results are invalid"
+                                     : "k_tower_split: a workgroup waited for its position's siblings beyond the bound; the forward's results are invalid");
 }
 
 int net_profile_enable(TgEngine* e, int sample_every) {

@@ -588,6 +588,14 @@ __global__ __launch_bounds__(NRT * CTW * 64) void k_tower_split(const uint8_t* _
     const int blk = blockIdx.x / (8 * G), rem = blockIdx.x - blk * (8 * G);
     const int p = blk * 8 + (rem & 7), g = rem >> 3;
     if (p >= B) return;
+    // the guarantee the fast exchange rests on — a position's siblings on ONE XCD — is checked by every workgroup of every launch:
+    // group 0 posts its XCD in the position's counter line, the others compare at the first meeting (the dispatcher's round robin may
+    // start anywhere, so the id alone does not name the XCD; ids that agree mod 8 share one — k_xcc_probe)
+    unsigned my_xcc = 0;
+    if (SAME_L2 && tid == 0) {
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+        my_xcc = (my_xcc & 15u) + 1u;
+    }
     const int wave = tid >> 6, lane = tid & 63;
     const int ct = wave % CTW, rt = wave / CTW;
     const int r16 = lane & 15, q = lane >> 4;
@@ -639,6 +647,7 @@ __global__ __launch_bounds__(NRT * CTW * 64) void k_tower_split(const uint8_t* _
         conv_tile_first_weights<CH>((const f32x4*)T.w[layer + 1] + wlane, (size_t)F * 4, wf);
         if (tid == 0) {
             if (!SAME_L2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (SAME_L2 && layer == 0 && g == 0) __hip_atomic_store(flag + 1, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned target = (unsigned)G * (unsigned)(layer + 1);
             unsigned spins = 0;
@@ -647,12 +656,12 @@ __global__ __launch_bounds__(NRT * CTW * 64) void k_tower_split(const uint8_t* _
             auto poll = [&]() -> unsigned { return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
             while (!failed && poll() < target) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > SPLIT_SPIN_LIMIT || ((spins & 4095u) == 0 && __hip_atomic_load(T.split_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                    __hip_atomic_store(T.split_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    failed = true;
-                }
+                if (++spins > SPLIT_SPIN_LIMIT) { __hip_atomic_store(T.split_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); failed = true; }
+                else if ((spins & 4095u) == 0 && __hip_atomic_load(T.split_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) failed = true;
             }
             if (!SAME_L2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (SAME_L2 && layer == 0 && !failed && __hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != my_xcc)
+                __hip_atomic_store(T.split_err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         if (SAME_L2) asm volatile("buffer_inv sc0" ::: "memory");  // this CU's L1 may hold the buffer's lines of two layers ago
@@ -682,7 +691,10 @@ __global__ __launch_bounds__(NRT * CTW * 64) void k_tower_split(const uint8_t* _
     __syncthreads();
     if (tid == 0) {
         const unsigned old = __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1u == (unsigned)G * (unsigned)T.nlayers) __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == (unsigned)G * (unsigned)T.nlayers) {
+            __hip_atomic_store(flag + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -2040,7 +2052,8 @@ hipError_t launch_tower_states(hipStream_t st, const uint8_t* states, const Towe
     if (T.cb) {  // the same tilings with layer 0 over the board planes (identical bits for every batch size)
         if (n == 5 && T.F == 64) {
             // (round 6, measured at 300 … 2048 positions with 1 / 2 / 4 / 8 positions per workgroup: these brackets are within 11 % of the
-            // best choice everywhere — two co-resident workgroups of half the size take as long as one — profiles/r06_e_tower_pw_sweep.txt)
+            // best choice everywhere — two co-resident workgroups of half the size take as long as one; eight waves instead of four: 5 %;
+            // every layer streaming the same L2-hot weights: no difference — profiles/r06_e_tower_pw_sweep.txt)
             if (B <= 256) return launch_tower_t<2, 4, 2, 4, true, true>(st, in, T, out, B, n, 1, 4);
             if (B <= 512) return launch_tower_t<4, 4, 2, 4, true, true>(st, in, T, out, B, n, 2, 4);
             if (B <= 1024) return launch_tower_t<7, 4, 2, 4, true, true>(st, in, T, out, B, n, 4, 4);

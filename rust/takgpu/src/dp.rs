@@ -42,3 +42,40 @@ pub fn comm_info<const N: usize>(net: &mut GpuNet<N>) -> Result<sys::TgCommInfo,
     check(unsafe { sys::tg_train_comm_info(e, info.as_mut_ptr()) })?;
     Ok(unsafe { info.assume_init() })
 }
+
+/// One float through the reduction the optimiser step will use — RCCL's first collective on the communicator or the caller's
+/// function — before anything of a training step is enqueued: a launch that cannot form a ring stops here.  Collective: every
+/// rank calls it after `init_rccl` / `init_hook`.  Returns the wall-clock milliseconds of the round trip (0.0 on a single rank).
+pub fn preflight<const N: usize>(net: &mut GpuNet<N>) -> Result<f64, crate::TgError> {
+    let e = net.trainer_handle()?;
+    let mut ms = 0.0f64;
+    check(unsafe { sys::tg_train_comm_preflight(e, &mut ms) })?;
+    Ok(ms)
+}
+
+/// The card this rank's engine runs on, as the HIP runtime names it (PCI bus id, name, CU count): gather it over the ranks and
+/// refuse to run if two ranks report the same bus id — one shard per process means one GPU per process
+/// (train/src/self_play.rs:98,102-104).
+pub fn device_info<const N: usize>(net: &mut GpuNet<N>) -> Result<sys::TgDeviceInfo, crate::TgError> {
+    let e = net.trainer_handle()?;
+    let mut info = std::mem::MaybeUninit::<sys::TgDeviceInfo>::zeroed();
+    check(unsafe { sys::tg_device_info(e, info.as_mut_ptr()) })?;
+    Ok(unsafe { info.assume_init() })
+}
+
+/// The permutation `tg_train(seed)` visits `n` examples in (the reference shuffles with `thread_rng`, network.rs:49-50): chunk k of
+/// `Network::train` = examples `order[k * 500 .. (k + 1) * 500]`.
+pub fn train_order(seed: u64, n: usize) -> Result<Vec<i32>, crate::TgError> {
+    let mut order = vec![0i32; n];
+    check(unsafe { sys::tg_train_order(seed, n as c_int, order.as_mut_ptr()) })?;
+    Ok(order)
+}
+
+/// The `TG_*` A/B switches that are ON in this process's environment, as the library reads them ("NAME=value NAME=value"); empty
+/// in a measured run.
+pub fn debug_switches() -> String {
+    let mut buf = vec![0u8; 4096];
+    unsafe { sys::tg_debug_switches(buf.as_mut_ptr() as *mut std::os::raw::c_char, buf.len()) };
+    let end = buf.iter().position(|&b| b == 0).unwrap_or(buf.len());
+    String::from_utf8_lossy(&buf[..end]).into_owned()
+}

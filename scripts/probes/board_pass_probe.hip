@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include "../../tak_amd/csrc/board_kernels.hip"
+#include "probe_env.h"
 
 __global__ void k_pick(const uint16_t* moves, const int32_t* counts, int count, uint32_t salt, uint16_t* chosen) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -9,6 +9,7 @@
 #include <vector>
 #include <algorithm>
 #include "../../tak_amd/csrc/net_kernels.hip"
+#include "probe_env.h"
 using namespace tg;
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 4000, n = 5, F = 128, M = B * n * n;

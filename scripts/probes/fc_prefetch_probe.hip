@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <vector>
 #include "../../tak_amd/csrc/net_kernels.hip"
+#include "probe_env.h"
 using namespace tg;
 
 // workgroup b runs on XCD b % 8 (round robin by linear index); k_fc_ring<0> gives XCD x the column blocks 4 (x & 1) … + 3

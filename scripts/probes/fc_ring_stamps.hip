@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <vector>
 #include "../../tak_amd/csrc/net_kernels.hip"
+#include "probe_env.h"
 using namespace tg;
 int main() {
     const int M = 4096, K = 1600, NP = 1664, nsteps = K / 64;

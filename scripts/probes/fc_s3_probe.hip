@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include "../../tak_amd/csrc/net_s3_kernels.hip"
+#include "probe_env.h"
 
 int main() {
     using namespace tg;

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <vector>
 #include "../../tak_amd/csrc/net_s3_kernels.hip"
+#include "probe_env.h"
 
 int main() {
     using namespace tg;

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <vector>
 #include "../../tak_amd/csrc/net_s3_kernels.hip"
+#include "probe_env.h"
 using namespace tg;
 int main(int argc, char** argv) {
     const char* cfg = argc > 1 ? argv[1] : "c2";

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <vector>
 #include "../../tak_amd/csrc/net_kernels.hip"
+#include "probe_env.h"
 using namespace tg;
 int main(int argc, char** argv) {
     const int variant = argc > 1 ? atoi(argv[1]) : 8;

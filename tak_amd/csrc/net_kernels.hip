@@ -18,7 +18,7 @@
 //                           ds_read immediates, conflict-free slot table): full batches, 89 – 94 % of the MFMA peak
 //   k_gemm                  generic GEMM
 //   k_fc_ring               policy FC for full batches: LDS-DMA ring of three K-steps, flag counters instead of barriers
-//   k_fc_small              policy FC for ≤ 512 rows (no LDS, no barrier)
+//   k_fc_small              policy FC for ≤ 2048 rows (no LDS, no barrier)
 //   k_softmax(_conv), k_value_head
 // Every variant of a layer type performs the same products in the same order: a position's outputs are the same bits
 // whatever batch (and therefore kernel) evaluates it (tests/test_gpu_net.py, tests/test_gpu_variants.py).
@@ -1475,7 +1475,11 @@ __global__ __launch_bounds__(512) void k_fc_ring(const float* __restrict__ A, in
 // barrier): M/16 × NP/32 waves.  Every output element is accumulated over k in the same order by the same MFMA as in
 // k_fc_ring, so the two kernels return identical bits and the choice between them is invisible.
 constexpr int FCS_CT = 2;
-constexpr int FC_SMALL_ROWS = 512;  // up to here the small-batch kernel is the faster one (4 workgroups of k_fc_ring)
+// up to here the small-batch kernel is the faster one: k_fc_ring's launch takes ≈ 160 µs whatever the rows (M / 128 row blocks × 8 column
+// blocks of workgroups, each through the whole K loop: 64 of 256 CUs at 1024 rows), k_fc_small 39 µs per 512 rows.  Round 6 (the games sweep's
+// plateau between 512 and 1024 games was THIS, not the tower): 512 → 2048; 700 games 423 → 320 µs per iteration, 1024: 422 → 342, 1500:
+// 589 → 527, 2048: 591 → 566 (profiles/r06_e_tower_pw_sweep.txt)
+constexpr int FC_SMALL_ROWS = 2048;
 __global__ __launch_bounds__(256) void k_fc_small(const float* __restrict__ A, int lda, const float* __restrict__ Wp,
                                                   const float* __restrict__ bias, float* __restrict__ out, int M, int K, int NP,
                                                   int out_stride, int n_valid, int a_frag) {

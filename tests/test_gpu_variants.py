@@ -59,7 +59,7 @@ sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
 import numpy as np
 import tak_amd, torch_ref
 from oracle import oracle as orc
-G, BATCH = 1024 // {batch}, {batch}
+G, BATCH = 2560 // {batch}, {batch}
 net = torch_ref.make_net(5, 2, 64, "fc5", seed=5)
 e = tak_amd.Engine(5, res_blocks=2, filters=64, evaluator=tak_amd.EVAL_RESNET, max_batch=G * BATCH)
 if {precision!r} != "f32":
@@ -86,10 +86,10 @@ print("DIGEST", h.hexdigest())
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision,batch", [("f32", 1), ("bf16x3", 1), ("f32", 2)])
 def test_fc_gather_epilogue_builds_the_same_trees(precision, batch):
-    """Search iterations at ≥ 513 leaves run the policy FC with its gather epilogue (no logits rows: the children's logits of every
+    """Search iterations at ≥ 2049 leaves (round 6; ≥ 513 before) run the policy FC with its gather epilogue (no logits rows: the children's logits of every
     leaf and the statistics record with the value pre-activation); TG_NO_FC_GATHER=1 writes the logits rows and lets the backup
-    gather — the round-3 data flow.  Same logits, same statistics, so the same trees, bit for bit: 147 whole trees and all roots
-    of 1024 games after 40 iterations (and 512 games with two virtual rollouts per iteration: leaf slot = game · batch + pass).  On the
+    gather — the round-3 data flow.  Same logits, same statistics, so the same trees, bit for bit: 366 whole trees and all roots
+    of 2560 games after 40 iterations (and 1280 games with two virtual rollouts per iteration: leaf slot = game · batch + pass).  On the
     split-bf16 path the ring FC with its gather epilogue is also compared with the
     small-workgroup FC + statistics kernel + logits rows (TG_S3_NO_FC_RING)."""
     def digest(**env):

@@ -25,6 +25,8 @@ widths = [int(g) for g in os.environ["GAMES"].split(",")] if os.environ.get("GAM
 for games in widths:
     e = tak_amd.Engine(board, res_blocks=blocks, filters=filters, policy_head=tak_amd.HEAD_FC5 if head == "fc5" else tak_amd.HEAD_CONV,
                        evaluator=tak_amd.EVAL_RESNET, max_batch=games)
+    if os.environ.get("PRECISION"):
+        e.set_precision(os.environ["PRECISION"])
     e.load_state_dict(weights)
     e.selfplay_create(games, seed=0, rollouts=rollouts, max_examples=1 << 16)
     e.selfplay_step(1)

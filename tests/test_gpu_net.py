@@ -217,6 +217,48 @@ def test_result_does_not_depend_on_the_batch_size(orc, n, blocks, filters, head,
     e.close()
 
 
+def test_split_towers_of_several_engines_at_once(orc):
+    """k_tower_split's workgroups wait for each other (a position's 8 siblings meet at a counter between two layers).  Three engines on
+    three host threads — three streams, three sets of counters and exchange buffers — launch it at the same time, 150 forwards each at
+    batch sizes that fill the chip several times over between them: nothing hangs (the waits are bounded and a bound reached is an error),
+    and every forward returns the bits of a forward that ran alone."""
+    import threading
+
+    n, blocks, filters, head = 5, 4, 128, "fc5"
+    net = torch_ref.make_net(n, blocks, filters, head, seed=21)
+    tensors = torch_ref.abi_tensors(net)
+    sts = orc.random_positions(n, 200, seed=12, max_plies=60, half_komi=4)[:128]
+    engines = []
+    for _ in range(3):
+        e = _engine(n, blocks, filters, head, max_batch=128)
+        e.load_state_dict(tensors)
+        engines.append(e)
+    sizes = (128, 96, 64, 33, 128, 7)
+    alone = {k: engines[0].policy_eval(sts[:k]) for k in set(sizes)}
+    errors = []
+
+    def worker(e, shift):
+        try:
+            for it in range(150):
+                k = sizes[(it + shift) % len(sizes)]
+                p, v = e.policy_eval(sts[:k])
+                if not (np.array_equal(p, alone[k][0]) and np.array_equal(v, alone[k][1])):
+                    errors.append(f"engine {shift}, forward {it}, batch {k}: bits differ from the forward that ran alone")
+                    return
+        except Exception as ex:  # noqa: BLE001 — reported by the main thread
+            errors.append(repr(ex))
+
+    threads = [threading.Thread(target=worker, args=(e, i)) for i, e in enumerate(engines)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a forward did not return"
+    assert not errors, errors[:3]
+    for e in engines:
+        e.close()
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 @pytest.mark.parametrize("n,blocks,filters,head,batch", [(5, 2, 64, "fc5", 2500), (6, 1, 128, "conv", 700)])
 def test_planes_entry_equals_states_entry_at_full_batch(orc, n, blocks, filters, head, batch, precision):

@@ -358,6 +358,54 @@ def test_selfplay_config_c1_with_the_real_network(orc):
     ev.close()
 
 
+def test_the_references_own_constants_net6_32_games(orc):
+    """`extra.reference_constants` of the bench line (round 6): 6×6, 32 lock-step games, `Net6` = 16 blocks × 128 filters, conv head
+    (train/src/self_play.rs:10-12,94; alpha-tak/src/model/net6.rs:16-17) — the width at which every network kernel is the small-batch
+    form (k_tower_split: a position over 8 workgroups; k_conv_split).  Parity at that width: the forward of the 32 leaves against PyTorch
+    fp32 (≤ 1e-4), whole trees after 150 iterations bit for bit against the oracle's MCTS — whose evaluator is ANOTHER engine that sees
+    every leaf batch padded to 300 positions, i.e. through the one-workgroup-per-position tower — and three plies of the self-play driver
+    (opening, noise, sampling, tree reuse) against the oracle's, statistic for statistic and example for example."""
+    import tak_amd
+
+    n, games, blocks, filters = 6, 32, 16, 128
+    net = torch_ref.make_net(n, blocks, filters, "conv", seed=6, randomize_bn=True)
+    tensors = torch_ref.abi_tensors(net)
+    e = _mk(n, tak_amd.EVAL_RESNET, games, res_blocks=blocks, filters=filters)
+    e.load_state_dict(tensors)
+    ev = _mk(n, tak_amd.EVAL_RESNET, 512, res_blocks=blocks, filters=filters)
+    ev.load_state_dict(tensors)
+    sts = _roots(orc, n, games, seed=31, max_plies=40)
+    pad = np.concatenate([sts] * 10)[:300 - games]
+
+    def padded_eval(st):  # the same positions inside a 300-position batch: k_tower<3,8>, not the split tower
+        k = len(st)
+        p, v = ev.policy_eval(np.concatenate([st, pad[: 300 - k]]))
+        return p[:k], v[:k]
+
+    p, v = e.policy_eval(sts)
+    p_ref, v_ref = torch_ref.forward(net, orc.encode(n, sts))
+    assert np.abs(p - p_ref).max() <= 1e-4 and np.abs(v - v_ref).max() <= 1e-4
+    p2, v2 = padded_eval(sts)
+    assert np.array_equal(p, p2) and np.array_equal(v, v2)
+    e.search_create(games, arena_nodes=1 << 15, seed=2)
+    e.search_reset(sts)
+    e.search_run(150)
+    s = orc.Search(n, head=orc.HEAD_CONV, py_eval=padded_eval, seed=2)
+    s.reset(sts)
+    s.run(150)
+    _assert_same_trees(e, s, games)
+    kw = dict(rollouts=60, noise_plies=80, exploit_plies=40, noise_alpha=0.2, noise_ratio=0.3, komi=2, total_games=0)
+    e.selfplay_create(games, arena_nodes=1 << 15, seed=7, max_examples=1 << 12, **kw)
+    sp = orc.SelfPlay(n, games, head=orc.HEAD_CONV, py_eval=padded_eval, seed=7, **kw)
+    for step in range(3):
+        e.selfplay_step(1)
+        sp.step(1)
+        assert e.selfplay_stats() == sp.stats(), step
+    assert np.array_equal(e.search_states(), sp.states()[0])
+    e.close()
+    ev.close()
+
+
 @pytest.mark.parametrize("n,games,rollouts,total", [(4, 8, 24, 20), (5, 6, 16, 9), (5, 64, 100, 80), (6, 8, 24, 14), (6, 16, 48, 24)])
 def test_selfplay_driver_matches_oracle(orc, n, games, rollouts, total):
     # self_play_parallel end to end: openings, instant wins, noise, rollouts, sampling / argmax,

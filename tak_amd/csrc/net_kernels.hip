@@ -570,9 +570,12 @@ __device__ __forceinline__ void conv_mainloop_tile(const f32x4* __restrict__ lds
 
 // SAME_L2: the launcher has verified on this device that workgroup id i runs on XCD i mod 8 (k_xcc_probe), so a position's siblings
 // share one L2 and the exchange needs no agent-scope fences — those write back and INVALIDATE the XCD's whole L2 (buffer_wbl2 sc1 /
-// buffer_inv sc1: 256 workgroups × every layer), after which every weight load of the next layer misses it.  What it needs instead:
-// the slice's stores complete (the vector L1 writes through: s_waitcnt vmcnt(0) = in L2), the counter as an L2 atomic, and this CU's
-// L1 dropped before the image is staged (buffer_inv sc0).  Without the guarantee: the agent-scope fences, correct wherever the siblings sit.
+// buffer_inv sc1: 256 workgroups × every layer), after which every weight load of the next layer misses it (tower 359 against 252 µs).
+// What it needs instead: the slice's stores complete (the vector L1 writes through: s_waitcnt vmcnt(0) = in L2), the counter as an L2
+// atomic polled at device scope, and the image staged with device-scope loads (sc1: past this CU's L1).  Without the guarantee: the
+// agent-scope fences, correct wherever the siblings sit.  (Measured and not kept, profiles/r06_k_split_exchange_variants.txt: the data as
+// its own flag — three sentinel-filled buffers polled directly, no counter: 242 µs, i.e. the exchange is the siblings' skew, not the
+// protocol's round trips.)
 template <int NRT, int CTW, int CH, bool SAME_L2>
 __global__ __launch_bounds__(NRT * CTW * 64) void k_tower_split(const uint8_t* __restrict__ states, TowerParams T, float* __restrict__ out,
                                                                 float* __restrict__ scratch, int B, int n) {
@@ -664,8 +667,10 @@ __global__ __launch_bounds__(NRT * CTW * 64) void k_tower_split(const uint8_t* _
                 __hip_atomic_store(T.split_err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        if (SAME_L2) asm volatile("buffer_inv sc0" ::: "memory");  // this CU's L1 may hold the buffer's lines of two layers ago
         // ---- the next layer's image: all F channels of position p, pitch F + 8 floats ----
+        // SAME_L2: DEVICE-scope loads (sc1) — past this CU's L1, which may hold the buffer's lines of two layers ago, to the L2 the siblings'
+        // stores went to.  (`buffer_inv sc0` + plain loads was 5 % faster and passed every test, but a counter polled that way saw the
+        // siblings' atomics only after a long delay: the L1 was being emptied by the weight stream, not by the invalidate.)
         LS4 = (F + LDS_PAD16) >> 2;
         const f32x4* src = (const f32x4*)(xbuf + (size_t)p * nsq * F);
         const int total = nsq * F4;
@@ -675,8 +680,11 @@ __global__ __launch_bounds__(NRT * CTW * 64) void k_tower_split(const uint8_t* _
 #pragma unroll
             for (int u = 0; u < UNR; u++) {
                 const int idx = base + u * NW * 64 + tid;
-                tmp[u] = src[idx < total ? idx : total - 1];
+                const f32x4* a = src + (idx < total ? idx : total - 1);
+                if (SAME_L2) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(tmp[u]) : "v"(a) : "memory");
+                else tmp[u] = *a;
             }
+            if (SAME_L2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int u = 0; u < UNR; u++) {
                 const int idx = base + u * NW * 64 + tid;

@@ -197,6 +197,24 @@ def test_bench_gpus_4_runs_unaided_on_one_card():
     assert c5["gradient_allreduce"]["rccl"]["attached"] == 2 and c5["gradient_allreduce"]["rccl"]["world_size"] == 4  # the host hook
 
 
+def test_device_info_and_switches_of_this_process():
+    """tg_device_info: what bench.py's config.devices is built from — the card's PCI bus id as HIP names it, 256 CUs, gfx950 — and
+    tg_debug_switches: nothing is switched in a test run that did not set a switch"""
+    import tak_amd
+
+    e = tak_amd.Engine(5, evaluator=tak_amd.EVAL_DUMMY, max_batch=1)
+    info = e.device_info()
+    e.close()
+    assert info["hip_device"] == 0 and info["cu_count"] == 256 and info["arch"].startswith("gfx950") and info["total_mem"] > 200 << 30
+    dom, bus, rest = info["pci_bus_id"].split(":")
+    assert len(dom) == 4 and len(bus) == 2 and "." in rest and info["name"]
+    from tak_amd import dist as tdist
+
+    rec = tdist.device_record(3, None)
+    assert rec["rank"] == 3 and rec["pci_bus_id"] is None
+    assert tak_amd.debug_switches() == [s for s in tak_amd.debug_switches() if s.split("=")[0] in os.environ]
+
+
 COMM_INFO = r"""
 import json, sys
 sys.path.insert(0, {root!r})

@@ -1316,7 +1316,10 @@ bool tower_s3_supported(int n, int F) { return (n == 5 && (F == 64 || F == 128))
 
 template <bool FROM_STATES, bool OUT_SPLIT>
 static hipError_t launch_s3(hipStream_t st, const void* in, const TowerS3Params& T, float* out, int B, int n) {
-    static const bool no_halo = env_on("TG_NO_HALO_TOWER");
+    // (a tower without a residual block is layer 0 alone: the halo kernel's layer 0 writes halo cells that only a later layer reads — found
+    // in round 6 by the batch-independence test on a 0-block network — so it stays on the plain image, whose loop ends behind layer 0)
+    static const bool no_halo_env = env_on("TG_NO_HALO_TOWER");
+    const bool no_halo = no_halo_env || T.nlayers < 2;
     if (FROM_STATES && T.cb) {  // layer 0 over one chunk of board planes, constant planes as a bias (KC0 = 1): the same tilings
         if (T.slotmap && !no_halo && B >= 256) {
             if (n == 5 && T.F == 64) return launch_s3_halo_t<7, 1, 2, 5, FROM_STATES, OUT_SPLIT, 4, FROM_STATES>(st, in, T, out, B, 8, 2);

@@ -49,6 +49,8 @@ def test_golden_fixture(path, orc):
     (5, 10, 128, "fc5", 77),    # config C5 topology
     (5, 2, 64, "conv", 64),     # conv head on 5x5
     (3, 1, 32, "conv", 50),     # DummyNet-sized board (search/tests.rs)
+    (5, 0, 128, "fc5", 100),    # no residual block: conv0 and the heads alone (the split tower without an exchange)
+    (6, 0, 128, "conv", 40),
 ])
 def test_config_topologies_vs_torch(orc, n, blocks, filters, head, batch):
     net = torch_ref.make_net(n, blocks, filters, head, seed=n * 100 + blocks)
@@ -73,6 +75,7 @@ def test_config_topologies_vs_torch(orc, n, blocks, filters, head, batch):
     (5, 10, 128, "fc5", 77),    # C5 network
     (5, 2, 64, "conv", 45),     # conv head on 5x5 (two head passes of two channel groups)
     (5, 1, 128, "conv", 9),     # one partial workgroup
+    (5, 0, 128, "fc5", 100),    # no residual block (round 6: the halo form of the split-bf16 tower mishandled it at ≥ 256 positions)
 ])
 def test_bf16x3_tower_within_tolerance(orc, n, blocks, filters, head, batch):
     """The split-bf16 tower (TG_PRECISION_BF16X3): same 1e-4 gate as the exact path, and its measured deviation."""
@@ -195,6 +198,8 @@ def test_c_host_runs_selfplay_through_the_abi(tmp_path):
     (5, 2, 128, "fc5", (1, 17, 32, 33, 64, 100, 128, 129, 255, 300, 600, 1100)),
     (6, 2, 128, "conv", (5, 32, 40, 64, 65, 128, 129, 260, 520)), # C3 shape, conv head
     (5, 2, 64, "conv", (40, 500, 1100, 2100)),            # conv head on 5×5
+    (5, 0, 128, "fc5", (9, 128, 300)),                    # no residual block: the split tower's layer loop without an exchange
+    (6, 1, 128, "conv", (3, 64, 65, 300)),                # one block, 6×6: three layers, two exchanges
 ])
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 def test_result_does_not_depend_on_the_batch_size(orc, n, blocks, filters, head, sizes, precision):

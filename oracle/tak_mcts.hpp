@@ -282,7 +282,7 @@ inline float devirtualize_path(Node& nd, const std::vector<int>& path, size_t po
     if (pos < path.size()) {
         eval = devirtualize_path(nd.children[path[pos]], path, pos + 1, policy, net_eval, n);
     } else {
-        for (size_t i = 0; i < nd.children.size(); i++) nd.children[i].policy = policy[move_index(nd.moves[i], n)];
+        for (size_t i = 0; i < nd.children.size(); i++) nd.children[i].policy = policy[move_index(nd.moves[i], n, (int)policy.size())];
         eval = net_eval;
     }
     eval = -eval;

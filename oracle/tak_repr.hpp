@@ -125,9 +125,13 @@ inline const std::vector<Move>& legacy5_table() {
     return table;
 }
 
-// returns -1 where the reference panics ("could not map turn to index", move_map.rs:24)
-inline int move_index(const Move& m, int n) {
-    if (n == 5) {
+// returns -1 where the reference panics ("could not map turn to index", move_map.rs:24).
+// legacy5: the reference takes the legacy table for EVERY 5×5 move (move_map.rs:21-24) — its only 5×5 network, Net5, has the table's
+// 1575 outputs.  A 5×5 network with Net6's conv head (output_size(5) = 3075 outputs) is not a reference configuration; the ABI allows
+// it (TG_HEAD_CONV) and defines its index as the conv formula below (include/takgpu.h), so callers that know the head's size pass
+// legacy5 = false there (move_index(m, n, policy_size)).
+inline int move_index(const Move& m, int n, bool legacy5 = true) {
+    if (n == 5 && legacy5) {
         static const std::vector<int> lut = [] {  // keyed by move code; thread-safe one-time initialisation
             std::vector<int> l(1 << 16, -1);
             const auto& t = legacy5_table();
@@ -147,6 +151,8 @@ inline int move_index(const Move& m, int n) {
     }
     return channel * n * n + m.row * n + m.col;
 }
+// the same for a head of `policy_size` outputs: 5×5 with 1575 outputs is the legacy table, everything else the conv formula
+inline int move_index(const Move& m, int n, int policy_size) { return move_index(m, n, n == 5 && policy_size == possible_moves_count(5)); }
 
 
 // ---------------------------------------------------------------------------------------
@@ -199,7 +205,7 @@ inline void example_symmetries(const Game& g, const std::vector<Move>& moves, co
         out_games[i] = game_symmetry(i, g);
         out_pi[i].assign(policy_size, 0.0f);
         for (size_t k = 0; k < moves.size(); k++) {
-            int idx = move_index(move_symmetry(g.n, i, moves[k]), g.n);
+            int idx = move_index(move_symmetry(g.n, i, moves[k]), g.n, policy_size);
             if (idx >= 0 && idx < policy_size) out_pi[i][idx] = (float)visits[k] / total;
         }
     }

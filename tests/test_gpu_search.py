@@ -197,7 +197,9 @@ def test_one_pool_for_all_trees(orc):
     e.close()
 
 
-@pytest.mark.parametrize("n,blocks,filters,head", [(5, 2, 32, "fc5"), (6, 1, 32, "conv")])
+# (5×5 with Net6's conv head is not a reference configuration — its move index is the conv formula, as include/takgpu.h defines
+# TG_HEAD_CONV; round 6: the oracle took the legacy table for every 5×5 move, whatever the head's size)
+@pytest.mark.parametrize("n,blocks,filters,head", [(5, 2, 32, "fc5"), (6, 1, 32, "conv"), (5, 1, 64, "conv")])
 def test_tree_parity_with_real_network(orc, n, blocks, filters, head):
     # the oracle's MCTS evaluates its leaves through tg_policy_eval; the GPU search feeds the same
     # kernels from its own leaf batch — identical trees require identical per-position network outputs
@@ -206,9 +208,10 @@ def test_tree_parity_with_real_network(orc, n, blocks, filters, head):
     games = 12
     net = torch_ref.make_net(n, blocks, filters, head, seed=3)
     tensors = torch_ref.abi_tensors(net)
-    e = _mk(n, tak_amd.EVAL_RESNET, games, res_blocks=blocks, filters=filters)
+    h = tak_amd.HEAD_FC5 if head == "fc5" else tak_amd.HEAD_CONV
+    e = _mk(n, tak_amd.EVAL_RESNET, games, head=h, res_blocks=blocks, filters=filters)
     e.load_state_dict(tensors)
-    ev = _mk(n, tak_amd.EVAL_RESNET, games, res_blocks=blocks, filters=filters)
+    ev = _mk(n, tak_amd.EVAL_RESNET, games, head=h, res_blocks=blocks, filters=filters)
     ev.load_state_dict(tensors)
     e.search_create(games, arena_nodes=1 << 15)
     s = orc.Search(n, head=orc.HEAD_FC5 if head == "fc5" else orc.HEAD_CONV, py_eval=lambda st: ev.policy_eval(st))

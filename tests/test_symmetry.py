@@ -47,13 +47,14 @@ def test_oracle_symmetry_properties(orc, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [4, 5, 6])
-def test_gpu_augment_matches_oracle(orc, n):
+@pytest.mark.parametrize("n,conv5", [(4, False), (5, False), (6, False), (5, True)])
+def test_gpu_augment_matches_oracle(orc, n, conv5):
     import tak_amd
 
-    head = orc.HEAD_FC5 if n == 5 else orc.HEAD_CONV
+    # conv5: a 5×5 network with the conv head (3075 outputs) — the policy targets are indexed by the conv formula, not the legacy table
+    head = orc.HEAD_FC5 if n == 5 and not conv5 else orc.HEAD_CONV
     e = tak_amd.Engine(n, evaluator=tak_amd.EVAL_DUMMY, max_batch=512,
-                       policy_head=tak_amd.HEAD_FC5 if n == 5 else tak_amd.HEAD_CONV)
+                       policy_head=tak_amd.HEAD_FC5 if n == 5 and not conv5 else tak_amd.HEAD_CONV)
     sts, cnt, mv, visits = _examples(orc, n, 1500, seed=10 + n)   # crosses the 1024-example chunk
     g_states, g_pi = e.augment_examples(sts, cnt, mv, visits)
     o_states, o_pi = orc.augment(n, head, sts, cnt, mv, visits)

@@ -29,7 +29,9 @@ def _oracle_pit(orc, n, evals, pairs, rollouts, idle, random_plies, komi, seed, 
         assert not status.any()
     G = 2 * pairs
     states = np.repeat(op, 2, axis=0)
-    trees = [orc.Search(n, head=head, evaluator=ev, seed=seed, batch=batch) for ev in evals]
+    # an evaluator is one of the oracle's deterministic kinds or a callable (states → policy, eval): a network behind tg_policy_eval
+    trees = [orc.Search(n, head=head, py_eval=ev, seed=seed, batch=batch) if callable(ev) else orc.Search(n, head=head, evaluator=ev, seed=seed, batch=batch)
+             for ev in evals]
     for t in trees:
         t.reset(states)
     alive = np.ones(G, bool)
@@ -111,6 +113,43 @@ def test_pit_matches_oracle_replay(orc, n, pairs, rollouts, batch):
         assert abs(got["win_rate"] - got["wins"] / (got["wins"] + got["losses"])) < 1e-12
     new.close()
     old.close()
+
+
+def test_pit_of_two_networks_matches_oracle_replay(orc):
+    """The pit as the reference uses it — two NETWORKS (train/src/pit.rs:15-96, main.rs:100) — at a width where both engines run the
+    small-batch kernels (2 · 3 pairs · 4 virtual rollouts = 24 leaves: k_tower_split on 128 filters): game for game against the replay
+    on the oracle's MCTS, whose two evaluators are two MORE engines that see every leaf batch padded to 300 positions (the
+    one-workgroup-per-position tower)."""
+    import tak_amd
+
+    import torch_ref
+
+    n, blocks, filters, pairs, rollouts, batch = 5, 2, 128, 3, 10, 4
+    nets = [torch_ref.abi_tensors(torch_ref.make_net(n, blocks, filters, "fc5", seed=s)) for s in (1, 2)]
+
+    def engine(tensors, max_batch):
+        e = tak_amd.Engine(n, res_blocks=blocks, filters=filters, evaluator=tak_amd.EVAL_RESNET, max_batch=max_batch)
+        e.load_state_dict(tensors)
+        return e
+
+    new, old = engine(nets[0], 64), engine(nets[1], 64)
+    ev = [engine(nets[0], 320), engine(nets[1], 320)]
+    pad = np.stack([orc.new_game(n, half_komi=4)] * 300)
+
+    def padded(e):
+        def f(st):
+            k = len(st)
+            p, v = e.policy_eval(np.concatenate([st, pad[: 300 - k]]))
+            return p[:k], v[:k]
+        return f
+
+    kw = dict(pairs=pairs, rollouts=rollouts, batch=batch, idle_rollouts=1, random_plies=2, komi=2, seed=5, max_plies=24)
+    got = tak_amd.pit(new, old, arena_nodes=1 << 16, **kw)
+    want = _oracle_pit(orc, n, (padded(ev[0]), padded(ev[1])), pairs, rollouts, 1, 2, 2, 5, max_plies=24, batch=batch)
+    for k in ("wins", "losses", "draws", "plies", "unfinished", "ref_wins", "ref_losses", "ref_draws", "ref_pairs"):
+        assert got[k] == want[k], (got, want)
+    for e in (new, old, *ev):
+        e.close()
 
 
 def test_identical_networks_split_every_pair(orc):

@@ -28,3 +28,17 @@ def orc():
 
     oracle.lib()
     return oracle
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_threads():
+    """The GPU box gives one GPU's share of the host (16 cores) while PyTorch defaults to one thread per VISIBLE core (128 +): the CPU
+    references (fp64 autograd of the C5 network, the PyTorch-fed MCTS) then fight over the share — the same test took 2 s on one box and
+    30 s on another.  Cap the pool at the share."""
+    try:
+        import torch
+
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+    except ImportError:
+        pass
+    yield

@@ -280,7 +280,7 @@ class Search:
         self.games = 0
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:  # (at interpreter shutdown the module's globals may be gone already)
             lib().orc_search_free(self.h)
             self.h = None
 
@@ -353,7 +353,7 @@ class SelfPlay:
                                         self.psize, base, init, seed, C.byref(cfg), slot_base)
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib().orc_selfplay_free(self.h)
             self.h = None
 

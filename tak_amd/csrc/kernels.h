@@ -158,8 +158,9 @@ bool fc_gather_supported(int M, int K, int NP);
 hipError_t launch_softmax_stats(hipStream_t st, const float* logits, int row_stride, const float* stats, int blocks, int stat_stride, int P,
                                 int B, float* policy, float* eval);
 hipError_t launch_value_head(hipStream_t st, const float* act, const float* wv, float bv, int B, int len, float* eval);
+struct ValueHeadArgs { const float* act; const float* wv; float bv; int len; float* eval; };  // k_value_head's inputs
 hipError_t launch_softmax(hipStream_t st, const float* logits, int row_stride, bool conv_head, int nsq, int ch_stride, int P,
-                          int B, float* policy, float* eval = nullptr);
+                          int B, float* policy, float* eval = nullptr, const ValueHeadArgs* value = nullptr, bool* value_done = nullptr);
 hipError_t launch_nchw_to_nhwc(hipStream_t st, const float* src, int B, int C, int nsq, int Cpad, float* dst);
 
 // train_kernels.hip

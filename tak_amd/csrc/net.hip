@@ -663,11 +663,15 @@ static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const ui
         }
     }
     float* logits = n->logits.as<float>() + (size_t)pos0 * n->logit_row;
+    bool value_done = false;
     if (e->cfg.policy_head == TG_HEAD_CONV) {
         const ConvLayer& L = n->policy_conv;
         if (!(n->s3 && n->s3_head_on))
             TG_HIP(launch_conv3x3(st, x, L.w.as<float>(), L.b.as<float>(), nullptr, logits, M, N, F, L.cout_pad, L.cout_pad, L.cout, false));
-        TG_HIP(launch_softmax(st, logits, nsq * L.cout_pad, true, nsq, L.cout_pad, e->policy_size, nb, d_policy));
+        // (exact-f32 path: the softmax's launch computes the value head too — one launch less per forward)
+        const ValueHeadArgs vh{x, n->value_w.as<float>(), n->value_b, nsq * F, d_eval};
+        const bool plain_value = !(n->s3 && (n->s3_fc_on || n->s3_head_on));
+        TG_HIP(launch_softmax(st, logits, nsq * L.cout_pad, true, nsq, L.cout_pad, e->policy_size, nb, d_policy, nullptr, plain_value ? &vh : nullptr, &value_done));
     } else if (n->s3 && n->s3_fc_on) {
         float* stats = n->fc_stats_on ? n->fc_stats.as<float>() + (size_t)pos0 * n->fc_stat_stride * 2 : nullptr;
         const bool gather = !d_policy && pos0 == 0 && n->gather_on && net_gather_ok(e, nb);
@@ -689,7 +693,7 @@ static int net_forward_impl(TgEngine* e, int nb, const float* d_planes, const ui
     if (e->cfg.policy_head == TG_HEAD_FC5 && n->value_in_fc) {
         // eval = tanh(logit P), written by the softmax kernel (or taken by the tree backup straight from the logits)
     } else if (n->s3 && (n->s3_fc_on || n->s3_head_on)) TG_HIP(launch_value_head_s3(st, x, n->value_w.as<float>(), n->value_b, nb, nsq * F, d_eval));
-    else TG_HIP(launch_value_head(st, x, n->value_w.as<float>(), n->value_b, nb, nsq * F, d_eval));
+    else if (!value_done) TG_HIP(launch_value_head(st, x, n->value_w.as<float>(), n->value_b, nb, nsq * F, d_eval));
     if (chain) chain->push_back(prof_event(n, st));
     return TG_OK;
 }

@@ -1671,8 +1671,11 @@ __global__ __launch_bounds__(256) void k_softmax(const float* __restrict__ logit
 // Conv policy head (net6.rs:98-103): the logits sit in NHWC ([sq][ch_stride]) and the probabilities leave in the
 // reference's order p = ch·N² + sq.  One block per position: the row is read once, coalesced, into LDS (pitch
 // ch_stride + 1 so that the transposed read-out is bank-conflict free), exp is evaluated once per output.
+// act != nullptr (round 6): the block's first wave also computes the position's value head — k_value_head's sum, lane for lane — so the
+// conv-head forward is one launch shorter (7 µs of the 291 µs iteration at the reference's 32 leaves)
 __global__ __launch_bounds__(256) void k_softmax_conv(const float* __restrict__ logits, int nsq, int ch_stride, int C,
-                                                      float* __restrict__ policy) {
+                                                      float* __restrict__ policy, const float* __restrict__ act,
+                                                      const float* __restrict__ wv, float bv, int len, float* __restrict__ eval) {
     extern __shared__ float row[];  // nsq × (ch_stride + 1)
     __shared__ float red[4];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -1712,6 +1715,20 @@ __global__ __launch_bounds__(256) void k_softmax_conv(const float* __restrict__ 
     for (int p = tid; p < P; p += 256) {
         int ch = p / nsq, sq = p - ch * nsq;
         o[p] = row[sq * pitch + ch] * inv;
+    }
+    if (act && tid < 64) {  // value head: Linear(F·N² → 1) + tanh, exactly as k_value_head (one wave per position, lane = tid)
+        const float4* a = (const float4*)(act + (size_t)b * len);
+        const float4* w = (const float4*)wv;
+        float v = 0.0f;
+        for (int k = tid; k < (len >> 2); k += 64) {
+            float4 x = a[k], y = w[k];
+            v = fmaf(x.x, y.x, v);
+            v = fmaf(x.y, y.y, v);
+            v = fmaf(x.z, y.z, v);
+            v = fmaf(x.w, y.w, v);
+        }
+        v = wave_sum(v);
+        if (tid == 0) eval[b] = tanhf(v + bv);
     }
 }
 
@@ -2167,10 +2184,17 @@ hipError_t launch_value_head(hipStream_t st, const float* act, const float* wv, 
     return hipGetLastError();
 }
 
+// value (optional, conv head only): the value head's inputs — when the transposing kernel takes the batch it computes the eval too and
+// *value_done is set; otherwise the caller launches k_value_head as before
 hipError_t launch_softmax(hipStream_t st, const float* logits, int row_stride, bool conv_head, int nsq, int ch_stride, int P,
-                          int B, float* policy, float* eval) {
+                          int B, float* policy, float* eval, const ValueHeadArgs* value, bool* value_done) {
+    if (value_done) *value_done = false;
     if (conv_head && (ch_stride & 3) == 0 && (size_t)nsq * (ch_stride + 1) * 4 <= 64 * 1024) {
-        hipLaunchKernelGGL(k_softmax_conv, dim3(B), dim3(256), (size_t)nsq * (ch_stride + 1) * 4, st, logits, nsq, ch_stride, P / nsq, policy);
+        const bool fuse = value && value->act && value->eval && (value->len & 3) == 0;
+        hipLaunchKernelGGL(k_softmax_conv, dim3(B), dim3(256), (size_t)nsq * (ch_stride + 1) * 4, st, logits, nsq, ch_stride, P / nsq, policy,
+                           fuse ? value->act : nullptr, fuse ? value->wv : nullptr, fuse ? value->bv : 0.0f, fuse ? value->len : 0,
+                           fuse ? value->eval : nullptr);
+        if (value_done) *value_done = fuse;
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_softmax, dim3(B), dim3(256), 0, st, logits, row_stride, conv_head ? 1 : 0, nsq, ch_stride, P, policy, conv_head ? nullptr : eval);

@@ -622,11 +622,13 @@ __global__ __launch_bounds__(NRT * CTW * 64) void k_tower_split(const uint8_t* _
     for (int layer = 0; layer < T.nlayers; layer++) {
         const f32x4* wp = (const f32x4*)(layer == 0 ? T.w0_board : T.w[layer]) + wlane;
         const f32x4 bv = *(const f32x4*)&T.b[layer][ch0 + 4 * q];
+        TG_STAMP(layer, 0);
         if (layer == 0) {  // (cb_last_t = 3, one 32-channel chunk pair: the launcher checks)
             f32x4 wf0[2];
             conv_tile_first_weights<2>(wp, (size_t)F * 4, wf0);
             conv_mainloop_tile<2, 3>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho, q, vmask[0], acc, wf0);
         } else conv_mainloop_tile<CH>(lds4, wp, (size_t)F * 4, LS4, rows, n, rho, q, vmask[0], acc, wf);
+        TG_STAMP(layer, 1);
         f32x4 v = acc + (layer == 0 ? pb4[tower_cb_index(rho, rows, n, nsq, F4, (ch0 >> 2) + q)] : bv);
         v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f);
         if (layer + 1 == T.nlayers) {
@@ -647,6 +649,7 @@ __global__ __launch_bounds__(NRT * CTW * 64) void k_tower_split(const uint8_t* _
         if (SAME_L2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();  // every wave's slice is in L2 (SAME_L2) / on its way and every wave has finished reading the image
+        TG_STAMP(layer, 2);
         conv_tile_first_weights<CH>((const f32x4*)T.w[layer + 1] + wlane, (size_t)F * 4, wf);
         if (tid == 0) {
             if (!SAME_L2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -667,6 +670,7 @@ __global__ __launch_bounds__(NRT * CTW * 64) void k_tower_split(const uint8_t* _
                 __hip_atomic_store(T.split_err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
+        TG_STAMP(layer, 3);
         // ---- the next layer's image: all F channels of position p, pitch F + 8 floats ----
         // SAME_L2: DEVICE-scope loads (sc1) — past this CU's L1, which may hold the buffer's lines of two layers ago, to the L2 the siblings'
         // stores went to.  (`buffer_inv sc0` + plain loads was 5 % faster and passed every test, but a counter polled that way saw the
@@ -694,6 +698,7 @@ __global__ __launch_bounds__(NRT * CTW * 64) void k_tower_split(const uint8_t* _
         if (layer == 0)
             for (int idx = tid; idx < LS4; idx += NW * 64) lds4[rows * LS4 + idx] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         __syncthreads();
+        TG_STAMP(layer, 4);
     }
     // the counter returns to zero with the launch: the last of the position's G workgroups to finish resets it
     __syncthreads();

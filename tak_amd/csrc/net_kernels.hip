@@ -506,17 +506,20 @@ __global__ __launch_bounds__(NWAVES * 64) void k_tower(const float* __restrict__
 // The fused tower for SMALL batches of wide networks (round 6): k_tower gives every position to one workgroup — at the reference's
 // own constants (32 lock-step games → 32 leaves per forward, Net6 = 16 blocks × 128 filters; train/src/self_play.rs:94,
 // alpha-tak/src/model/net6.rs:16-17) that is 32 busy CUs of 256, each issuing 8 channel tiles × 3 row tiles × 288 MFMAs per layer
-// (23 µs per layer, 882 µs per forward).  Here a position is SPLIT over G = 8 / 4 / 2 workgroups by output channel tile: workgroup
+// (23 µs per layer, 882 µs per forward).  Here a position is SPLIT over G = F / 16 workgroups by output channel tile: workgroup
 // (position p, group g) holds the whole input image of p in LDS and computes CTW channel tiles × NRT row tiles, one (row tile, channel
 // tile) pair per wave = ONE chain of 9·16·CH/4 MFMAs — the shortest critical path the arithmetic allows (a chain cannot be cut: every
 // output element is accumulated over k in k_tower's order, so the results are bit-identical).  Between two layers the G workgroups of a
 // position exchange their 16·CTW-channel slices through global memory (two buffers used in turn; L2-resident: n²·F floats per
 // position) and meet at a counter per position: slice stored → release → flag += 1; wait for flag = G·(layer + 1) → acquire → stage the
-// next image.  The siblings of a position have the same blockIdx.x, so with B a multiple of 8 they sit on one XCD and the exchange
-// stays in that XCD's L2 (the fences make it correct wherever they sit).  Weights: a wave with one tile issues 4 MFMAs per 16-k chunk —
-// far less than an L2 round trip — so they are fetched a whole TAP ahead (CH quads per lane, two sets) instead of two chunks ahead.
-// A workgroup never waits for more than its own G − 1 siblings, all of one launch whose grid (≤ 512 small workgroups) is co-resident;
-// the wait is bounded all the same: after SPLIT_SPIN_LIMIT polls it raises T.split_err (→ TG_ERR_HIP on the host) and the waits stop.
+// next image.  Workgroup ids come in blocks of 8 positions × G groups with the position's low bits in the id's low bits, so the siblings
+// of a position sit on one XCD (id mod 8) and the exchange stays in that XCD's L2 (SAME_L2, below; without that guarantee agent-scope
+// fences make it correct wherever they sit).  Weights: a wave with one tile issues 4 MFMAs per 16-k chunk — far less than an L2 round
+// trip — so they are fetched a whole TAP ahead (CH quads per lane, two sets) instead of two chunks ahead.  What bounds a layer is the
+// chain itself: 288 DEPENDENT MFMAs at 46 cycles each (6.0 µs of a layer's 8.2; scripts/probes/split_stamps.hip).
+// A workgroup never waits for more than its own G − 1 siblings, all of one launch whose grid (≤ 512 three-wave workgroups on 6×6, ≤ 1024
+// two-wave ones on 5×5) is co-resident, and whose ids put a position's siblings within 8·G of each other in the dispatch order; the wait
+// is bounded all the same: after SPLIT_SPIN_LIMIT polls it raises T.split_err (→ TG_ERR_HIP on the host) and the waits stop.
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned SPLIT_SPIN_LIMIT = 1u << 21;
 constexpr int SPLIT_FLAG_STRIDE = 32;  // u32 words between two positions' counters (kernels.h: TOWER_SPLIT_CTL_WORDS)

@@ -365,6 +365,8 @@ def train_c5(args, rank, world, local_rank, dist, backend, barrier_fn, progress=
     eng = stage("engine setup", setup)
     transport = "single rank"
     if world > 1:
+        # (collective from here on: the watchdog's line names this stage if the communicator never forms)
+        progress["stage"] = "communicator set-up (ncclGetUniqueId broadcast, ncclCommInitRank inside libtakgpu)" if backend == "nccl" else "host all-reduce hook"
         if backend == "nccl":
             uid = tdist.broadcast_unique_id(dist, tak_amd.comm_unique_id, device="cuda")
             eng.train_comm_init(rank, world, uid)
